@@ -1,0 +1,187 @@
+/*
+ * lumina_dit.h -- C ABI of the MI355X (gfx950) Next-DiT / Flag-DiT denoising engine.
+ *
+ * The reference (Alpha-VLLM/Lumina-T2X) has NO plugin / FFI interface: the hot path sits behind two
+ * Python conventions:
+ *   1. the model-callable protocol  model_fn(x[B,C,H,W], t[B], **kw) -> [B,C,H,W]
+ *      (lumina_next_t2i/transport/transport.py:192-195, integrators.py:104-116), concretely
+ *      NextDiT.forward_with_cfg (lumina_next_t2i/models/model.py:866-913) and
+ *      NextDiT.forward (model.py:836-864);
+ *   2. module construction + state_dict key contract (lumina_next_t2i/sample.py:125-142).
+ * This header is what a ctypes / cffi / pybind stub on the reference side would bind to replace the
+ * body of those two methods and of transport/integrators.py:ode.sample (integrators.py:104-116).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; lt_last_error() gives the message
+ *     (thread-local, valid until the next call on the same thread).  No C++ exception crosses the ABI.
+ *   - all pointers named *_dev are DEVICE pointers owned by the caller (PyTorch in our host code);
+ *     the engine never frees or retains them beyond the call, except where stated.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  No call synchronises the
+ *     stream or the device; nothing inside the denoising loop reads device data on the host.
+ *   - dtype codes: LT_F32 = 0, LT_BF16 = 1, LT_F16 = 2 (f16 only accepted for weights upload).
+ */
+#ifndef LUMINA_DIT_H
+#define LUMINA_DIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_F32 0
+#define LT_BF16 1
+#define LT_F16 2
+
+/* model variants (which reference class the engine reproduces) */
+#define LT_VARIANT_NEXT_T2I 0      /* lumina_next_t2i/models/model.py:665 NextDiT              */
+#define LT_VARIANT_NEXT_IMAGENET 1 /* Next-DiT-ImageNet/models/models.py:836 DiT_Llama         */
+#define LT_VARIANT_FLAG_T2I 2      /* lumina_t2i/models/model.py:661 DiT_Llama (Flag-DiT)      */
+
+/* fixed-grid ODE methods, torchdiffeq names (lumina_next_t2i/transport/integrators.py:115) */
+#define LT_ODE_EULER 0
+#define LT_ODE_MIDPOINT 1
+#define LT_ODE_RK4 2
+
+typedef struct lt_engine lt_engine;
+
+typedef struct lt_config {
+    int32_t variant;       /* LT_VARIANT_*                                                        */
+    int32_t dim;           /* model width d            (model.py:674)                             */
+    int32_t n_layers;      /* L                        (model.py:675)                             */
+    int32_t n_heads;       /* H                        (model.py:676)                             */
+    int32_t n_kv_heads;    /* GQA kv heads, == n_heads for MHA (model.py:158)                     */
+    int32_t ffn_hidden;    /* F, already rounded as in FeedForward.__init__ (model.py:469-473)    */
+    int32_t patch_size;    /* 2                                                                   */
+    int32_t in_channels;   /* 4                                                                   */
+    int32_t out_channels;  /* 8 when learn_sigma (model.py:689)                                   */
+    int32_t cap_feat_dim;  /* text feature width (2048 Gemma-2B); 0 for class-conditional         */
+    int32_t adaln_dim;     /* min(dim, 1024)           (model.py:563)                             */
+    int32_t qk_norm;       /* 1: affine LayerNorm over the full q/k projection (model.py:211-215) */
+    int32_t num_classes;   /* class-conditional variants only (label table has num_classes+1 rows)*/
+    float   norm_eps;      /* RMSNorm eps, 1e-5        (model.py:680)                             */
+    int32_t max_batch;     /* max rows of the (cond+uncond) batch the workspace is sized for      */
+    int32_t max_tokens;    /* max latent tokens per sample (N)                                    */
+    int32_t max_text;      /* max text tokens per sample (T)                                      */
+    int32_t rope_table_len;/* 384 (model.py:734); positions per axis in the 2-D RoPE table        */
+} lt_config;
+
+/* kwargs of NextDiT.forward_with_cfg (model.py:866-877) that are not tensors */
+typedef struct lt_step_args {
+    float   cfg_scale;         /* model.py:872                                                    */
+    float   scale_factor;      /* model.py:873   RoPE extrapolation factor                         */
+    float   scale_watershed;   /* model.py:874   t < watershed -> linear interp, else NTK          */
+    int32_t base_seqlen;       /* model.py:875   0 = None                                          */
+    int32_t proportional_attn; /* model.py:876                                                     */
+    int32_t latent_h;          /* H of x[B,C,H,W]                                                  */
+    int32_t latent_w;          /* W of x[B,C,H,W]                                                  */
+    int32_t batch;             /* B (cond+uncond rows), even for forward_with_cfg                  */
+    int32_t io_dtype;          /* LT_BF16 or LT_F32: dtype of x and out                            */
+    int32_t cfg_channels;      /* 3 = reference quirk (model.py:908); in_channels = standard CFG   */
+} lt_step_args;
+
+const char* lt_last_error(void);
+/* library / build identification: returns e.g. "lumina_dit gfx950 r1" */
+const char* lt_version(void);
+
+/* ---- engine lifetime ------------------------------------------------------------------------- */
+int  lt_create(const lt_config* cfg, lt_engine** out);
+void lt_destroy(lt_engine* e);
+
+/* Upload one checkpoint tensor by its reference state_dict key, e.g.
+ * "layers.3.attention.wq.weight".  The engine converts to bf16 and repacks into its own HBM arena
+ * (QKV concatenated, w1/w3 interleaved in 32-row groups for the fused SwiGLU epilogue); the source
+ * pointer is not retained.  Unknown keys are an error; lt_weights_ready() reports missing keys. */
+int lt_set_weight(lt_engine* e, const char* key, const void* src_dev, int32_t dtype,
+                  const int64_t* shape, int32_t ndim, void* stream);
+int lt_weights_ready(lt_engine* e); /* 0 if every required tensor has been uploaded */
+
+/* Step-invariant text work (model.py:421-422,602,847-850): masked mean pool + cap_embedder, and per
+ * layer RMSNorm_y -> wk_y/wv_y -> ky_norm K/V.  cap_feats [B,T,cap_dim], cap_mask int32 [B,T]. */
+int lt_prepare_prompt(lt_engine* e, const void* cap_feats_dev, int32_t cap_dtype,
+                      const int32_t* cap_mask_dev, int32_t B, int32_t T, void* stream);
+/* class-conditional variants: labels int32 [B] (null class = num_classes) */
+int lt_prepare_labels(lt_engine* e, const int32_t* labels_dev, int32_t B, void* stream);
+
+/* NextDiT.forward (model.py:836-864): x [B,C,H,W] -> out [B,C,H,W] (first in_channels kept). */
+int lt_forward(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev,
+               const lt_step_args* a, void* stream);
+/* NextDiT.forward_with_cfg (model.py:866-913): duplicates the first half, CFG on cfg_channels. */
+int lt_forward_cfg(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev,
+                   const lt_step_args* a, void* stream);
+
+/* ode.sample (integrators.py:104-116) with torchdiffeq's fixed-grid euler / midpoint / rk4:
+ * tgrid host pointer, n_grid points; z [B,C,H,W]; traj_dev (may be NULL) receives all n_grid
+ * states [n_grid,B,C,H,W]; final_dev (may be NULL) receives the last state.  Every model call is
+ * forward_with_cfg when use_cfg != 0, else forward.  t_round_to_state_dtype mirrors torchdiffeq's
+ * _PerturbFunc cast of t to the state dtype. */
+int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, void* final_dev,
+                  const float* tgrid_host, int32_t n_grid, int32_t method, int32_t use_cfg,
+                  int32_t t_round_to_state_dtype, const lt_step_args* a, void* stream);
+
+/* number of model evaluations issued by the last lt_sample_ode call */
+int64_t lt_last_nfe(lt_engine* e);
+
+/* ---- profiling hooks (bench.py roofline object) ----------------------------------------------- */
+/* class 0 = MFMA GEMM kernel, 1 = attention kernel, 2 = everything else.  When enabled, every
+ * launch of that class is bracketed by HIP events on the launch stream. */
+int lt_profile_enable(lt_engine* e, int32_t on);
+/* after the caller synchronised the stream: total ms, launches and algorithmic flops per class */
+int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t* launches, double* flops);
+int lt_profile_reset(lt_engine* e);
+
+/* ---- operator-level entry points (parity tests call each kernel through these) ---------------- */
+/* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in/out, fp32 accumulate.  K % 64 == 0.
+ * epilogue 0: plain, 1: SwiGLU on 32-row interleaved W (out has N/2 columns: silu(w1 x) * (w3 x)). */
+int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, int32_t bias_dtype,
+                    void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
+                    void* stream);
+/* interleave w1[F,K], w3[F,K] into the packed [2F,K] layout epilogue 1 expects */
+int lt_op_pack_w13(const void* w1_dev, const void* w3_dev, void* out_dev, int32_t F, int32_t K,
+                   void* stream);
+/* out = RMSNorm(x; w, eps) * (1 + scale[b]) (+ shift[b]);  w/scale/shift may be NULL.
+ * x,out bf16 [B*N, d]; scale/shift bf16 [B, ld_mod] (row stride ld_mod elements). */
+int lt_op_rmsnorm_mod(const void* x_dev, const void* w_dev, const void* scale_dev,
+                      const void* shift_dev, int32_t ld_mod, void* out_dev, int32_t B, int32_t N,
+                      int32_t d, float eps, void* stream);
+/* x += gate' * post(y) ; h = pre_next(x) * (1+scale) (+shift)      (model.py:597-610)
+ * post_mode 0: y, 1: RMSNorm(y; post_w).  gate_mode 0: gate, 1: tanh(gate), 2: no gate.
+ * next_mode 0: none, 1: RMSNorm(x; next_w)(w may be NULL), 2: LayerNorm no-affine (eps_next). */
+int lt_op_gated_residual_norm(void* x_dev, const void* y_dev, const void* post_w_dev,
+                              const void* gate_dev, int32_t post_mode, int32_t gate_mode,
+                              const void* next_w_dev, const void* next_scale_dev,
+                              const void* next_shift_dev, int32_t next_mode, int32_t ld_mod,
+                              void* h_dev, int32_t B, int32_t N, int32_t d, float eps,
+                              float eps_next, void* stream);
+/* q/k post-processing (model.py:361-371): affine LayerNorm over the full width (optional), 2-D or
+ * 1-D RoPE, cast bf16, write head-major [B,heads,N,hd].  src bf16 [B*N, ld_src] at column col0.
+ * rope_mode 0 none, 1 2-D interleaved (Next-DiT, model.py:959-961), 2 1-D (Flag-DiT).
+ * cs_table_dev float2 [pos][hd/4 or hd/2] (cos,sin); grid_w = latent tokens per row. */
+int lt_op_qk_norm_rope(const void* src_dev, int32_t ld_src, int32_t col0, const void* ln_w_dev,
+                       const void* ln_b_dev, float ln_eps, void* dst_dev, int32_t B, int32_t N,
+                       int32_t heads, int32_t hd, int32_t rope_mode, const void* cs_table_dev,
+                       int32_t grid_w, void* stream);
+/* V -> transposed, key-permuted layout the attention kernel consumes: [B,kvh,hd,Npad] */
+int lt_op_v_transpose(const void* src_dev, int32_t ld_src, int32_t col0, void* dst_dev, int32_t B,
+                      int32_t N, int32_t Npad, int32_t kv_heads, int32_t hd, void* stream);
+/* non-causal softmax(q k^T * scale + bias) v  (model.py:392-405 / 427-432).
+ * q [B,H,N,hd], k [B,Hkv,Nk,hd], vt [B,Hkv,hd,Nkpad] (lt_op_v_transpose layout), bias float
+ * [B,Nkpad] or NULL (0 / -inf per key), out bf16 [B,N,H*hd].
+ * accumulate != 0: out = out + tanh(gate[h]) * result (model.py:433-434), gate bf16 [H]. */
+int lt_op_attention(const void* q_dev, const void* k_dev, const void* vt_dev, const float* bias_dev,
+                    void* out_dev, const void* gate_dev, int32_t accumulate, int32_t B, int32_t H,
+                    int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t hd, float scale,
+                    void* stream);
+/* y[m,n] = sum_k act(a[m,k]) w[n,k] + b[n], m < M <= 8 (GEMV-style; adaLN / embedders).
+ * act_in 0 none, 1 SiLU.  a bf16 [M,K], w bf16 [N,K], b bf16 [N] or NULL, y bf16 [M,N]. */
+int lt_op_linear_small_m(const void* a_dev, const void* w_dev, const void* b_dev, void* y_dev,
+                         int32_t M, int32_t N, int32_t K, int32_t act_in, void* stream);
+/* 2-D RoPE (cos,sin) table builder (model.py:915-963): out float2 [2 branches][len][hd/4];
+ * branch 0 = linear-interpolation (t < watershed), branch 1 = NTK. */
+int lt_op_rope_table_2d(void* out_dev, int32_t len, int32_t hd, float theta, float scale_factor,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUMINA_DIT_H */

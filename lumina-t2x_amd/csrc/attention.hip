@@ -1,0 +1,239 @@
+// Non-causal flash attention for gfx950, head_dim 48 / 72 / 96 (Next-DiT 600M / 2B, Flag-DiT 5B).
+//
+// Replaces flash_attn_varlen_func on the all-ones mask (lumina_next_t2i/models/model.py:378-405; the
+// unpad/pad gathers are identities in sampling, model.py:781) and, in accumulate mode, the zero-init
+// tanh-gated text cross-attention (model.py:420-434):  out += tanh(gate_h) * softmax(q ky^T/sqrt(hd)+mask) vy.
+//
+// Structure (wave64 / MFMA-first):
+//  * workgroup = 4 waves, each wave owns 32 query rows; K/V tiles of 64 keys are shared through LDS,
+//    double buffered, filled with buffer_load...lds (K tile is one contiguous 64*hd*2-byte run thanks
+//    to the head-major layout written by qk_norm_rope; V^T tile rows are 128 B, bank-swizzled on the
+//    source address).
+//  * "swapped" QK^T: S^T = K * Q^T via v_mfma_f32_32x32x16_bf16, so a lane holds 16 scores of ONE
+//    query row per 32-key sub-tile -> running max / sum are lane-local (one shuffle with lane^32).
+//  * O^T = V^T * P^T: the P fragment is exactly the lane's own registers (converted to bf16) because
+//    v_transpose stores keys in the matching permuted order -> no cross-lane traffic for P.
+//  * hd = 72 is padded to 80 in the QK^T reduction (5 k-steps, Q's tail zero) and to 96 rows of O^T.
+//  * workgroup -> (head, q-block) map keeps all q-blocks of a head on one XCD (private L2) in order.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int KS = (HD + 15) / 16;   // QK^T k-steps
+    constexpr int DT = (HD + 31) / 32;   // O^T row tiles
+    constexpr int CPR = HD / 8;          // 16-byte chunks per K row == 1-KiB pieces per tile
+    constexpr int KTILE = 64 * HD * 2;   // bytes of a K tile
+    constexpr int VTILE = HD * 128;      // bytes of a V^T tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int nqb = (p.N + 127) / 128;
+    const int BH = p.B * p.H;
+    int bh, qb;
+    if ((BH & 7) == 0) {  // XCD-aware: head bh lives on XCD bh % 8, its q-blocks run back to back
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bh = xcd + 8 * (idx / nqb);
+        qb = idx % nqb;
+    } else {
+        bh = blockIdx.x / nqb;
+        qb = blockIdx.x % nqb;
+    }
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int bhk = b * p.Hkv + h / (p.H / p.Hkv);
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane = (q row l31, d = 16 s + 8 hi .. +8) ----------
+    int qrow = qb * 128 + wave * 32 + l31;
+    const bool q_ok = qrow < p.N;
+    if (!q_ok) qrow = p.N - 1;
+    const u16* qptr = p.q + ((size_t)bh * p.N + qrow) * HD;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int d0 = 16 * s + 8 * hi;
+        if (d0 < HD) qf[s] = *(const bf16x8*)(qptr + d0);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)0.0f;
+        }
+    }
+
+    // ---- staging descriptors (bounded to this head: keys past the end read as zero) ---------------
+    const size_t kbytes = (size_t)p.Nk * HD * 2;
+    __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + (size_t)bhk * p.Nk * HD), 0, (int)kbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vt + (size_t)bhk * HD * p.Nkpad), 0, (int)((size_t)HD * p.Nkpad * 2), 0x00020000);
+    auto stage = [&](int buf, int k0) {
+        char* kb = smem + buf * KTILE;
+        char* vb = smem + 2 * KTILE + buf * VTILE;
+#pragma unroll
+        for (int i = 0; i < (CPR + 3) / 4; ++i) {
+            const int j = wave + 4 * i;
+            if (j < CPR) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, LDS_PTR(kb + j * 1024), 16, j * 1024 + lane * 16, k0 * HD * 2, 0, 0);
+                const int d = 8 * j + (lane >> 3);
+                const int sc = (lane & 7) ^ ((d >> 1) & 7);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(vb + j * 1024), 16, d * p.Nkpad * 2 + sc * 16, k0 * 2, 0, 0);
+            }
+        }
+    };
+
+    // ---- per-lane LDS read offsets --------------------------------------------------------------------
+    int koff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        int ch = 2 * s + hi;
+        if (ch > CPR - 1) ch = CPR - 1;  // hd=72: pad chunk re-reads valid data, multiplied by Q's zero tail
+        koff[s] = l31 * HD * 2 + ch * 16;
+    }
+    int voff[DT][4];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        int d = dt * 32 + l31;
+        if (d > HD - 1) d = HD - 1;  // rows past hd are never stored
+#pragma unroll
+        for (int g = 0; g < 4; ++g) voff[dt][g] = d * 128 + (((2 * g + hi) ^ ((d >> 1) & 7)) << 4);
+    }
+
+    const float sl2 = p.scale * 1.44269504088896340736f;  // work in the log2 domain
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;
+
+    const int ntile = (p.Nk + 63) / 64;
+    const float* bias = p.bias ? p.bias + (size_t)b * p.Nkpad : nullptr;
+    stage(0, 0);
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntile) stage(cur ^ 1, (t + 1) * 64);
+        const char* kb = smem + cur * KTILE;
+        const char* vb = smem + 2 * KTILE + cur * VTILE;
+        const int k0 = t * 64;
+
+        // S^T sub-tiles: lane holds keys 32 kt2 + (r&3) + 8 (r>>2) + 4 hi for its query row
+        f32x16 sc[2];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt2][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *(const bf16x8*)(kb + kt2 * 32 * HD * 2 + koff[s]);
+                sc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[kt2], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+        const bool tail = (k0 + 64 > p.Nk);
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int kbase = k0 + 32 * kt2 + 8 * q4 + 4 * hi;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+                    const f32x4 t4 = *(const f32x4*)(bias + kbase);
+                    bv[0] = t4[0]; bv[1] = t4[1]; bv[2] = t4[2]; bv[3] = t4[3];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = sc[kt2][4 * q4 + j] * sl2 + bv[j];
+                    if (tail && kbase + j >= p.Nk) v = -INFINITY;
+                    sc[kt2][4 * q4 + j] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(sc[kt2][r] - m_new);
+                sc[kt2][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // O^T += V^T P^T : group g = keys 16g..16g+15, P fragment = this lane's own 8 values
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[g >> 1][8 * (g & 1) + e];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vf = *(const bf16x8*)(vb + voff[dt][g]);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds out[q = l31][d = 32 dt + 8 q4 + 4 hi + j] ---------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    float gate = 0.f;
+    if (p.accumulate) gate = bfr(tanhf(bf2f(p.gate[h])));
+    if (q_ok) {
+        u16* orow = p.out + ((size_t)b * p.N + qrow) * ((size_t)p.H * HD) + (size_t)h * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int d0 = 32 * dt + 8 * q4 + 4 * hi;
+                if (d0 < HD) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * q4 + j] * inv;
+                    u32x2* dst = (u32x2*)(orow + d0);
+                    if (p.accumulate) {
+                        // output + bf16(output_y * tanh(gate))  (model.py:433-434, bf16 rounding points)
+                        const u32x2 prev = *dst;
+                        const float pv[4] = {bf_lo(prev[0]), bf_hi(prev[0]), bf_lo(prev[1]), bf_hi(prev[1])};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = pv[j] + bfr(bfr(v[j]) * gate);
+                    }
+                    u32x2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                    *dst = w;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+int launch_attention(const AttnArgs& a, hipStream_t stream) {
+    LT_REQUIRE(a.H % a.Hkv == 0, "attention: H=%d not a multiple of Hkv=%d", a.H, a.Hkv);
+    LT_REQUIRE(a.Nkpad % 64 == 0 && a.Nkpad >= a.Nk && a.Nk > 0 && a.N > 0, "attention: bad key counts Nk=%d Nkpad=%d", a.Nk, a.Nkpad);
+    LT_REQUIRE(!a.accumulate || a.gate != nullptr, "attention: accumulate mode needs a gate");
+    const int nqb = (a.N + 127) / 128;
+    dim3 grid(a.B * a.H * nqb), block(256);
+#define LAUNCH_HD(HD_)                                                                                         \
+    hipLaunchKernelGGL(attn_fwd_kernel<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128), stream, a)
+    switch (a.hd) {
+        case 48: LAUNCH_HD(48); break;
+        case 72: LAUNCH_HD(72); break;
+        case 96: LAUNCH_HD(96); break;
+        default: lt_set_error("attention: head_dim %d not built (48, 72, 96)", a.hd); return 2;
+    }
+#undef LAUNCH_HD
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,70 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the Next-DiT denoising engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t u16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// bf16 <-> f32.  f2bf is round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+// round an fp32 value to the nearest bf16 and keep it as fp32 (reference rounding points)
+__device__ __forceinline__ float bfr(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// full-wave (64 lanes) butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// 16-byte vector of 8 bf16 as raw words
+struct __attribute__((aligned(16))) bf8_t { unsigned w[4]; };
+
+__device__ __forceinline__ void unpack8(const bf8_t& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf_lo(v.w[i]); f[2 * i + 1] = bf_hi(v.w[i]); }
+}
+__device__ __forceinline__ bf8_t pack8(const float* f) {
+    bf8_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.w[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// host-side error plumbing shared by the launchers
+void lt_set_error(const char* fmt, ...);
+#define LT_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            lt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
+#define LT_REQUIRE(cond, ...)                \
+    do {                                     \
+        if (!(cond)) {                       \
+            lt_set_error(__VA_ARGS__);       \
+            return 2;                        \
+        }                                    \
+    } while (0)

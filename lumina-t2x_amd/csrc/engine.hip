@@ -1,0 +1,705 @@
+// Host side of the C ABI (include/lumina_dit.h): engine object, weight arena, workspace, the per-NFE
+// launch sequence of NextDiT.forward / forward_with_cfg (lumina_next_t2i/models/model.py:836-913) and the
+// fixed-grid ODE loop of transport/integrators.py:104-116 (torchdiffeq euler / midpoint / rk4).
+//
+// Everything here is asynchronous on the caller's stream: no host<->device sync inside a step (the
+// reference syncs >= 25 times per NFE: t[0].item() model.py:888, nonzero/.item() per layer :288-289).
+// Step-invariant work is hoisted: text K/V of all layers and the caption embedding are computed once per
+// prompt (lt_prepare_prompt); the adaLN vectors of all layers are one GEMV per NFE; the RoPE table is
+// a 2 x 384 x hd/4 (cos,sin) table rebuilt only when scale_factor changes.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lumina_dit.h"
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void lt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* lt_last_error(void) { return g_err; }
+extern "C" const char* lt_version(void) { return "lumina_dit gfx950 r1"; }
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct LayerW {
+    u16 *wqkv = nullptr, *wo = nullptr, *w13 = nullptr, *w2 = nullptr, *wkvy = nullptr;
+    u16 *q_norm_w = nullptr, *q_norm_b = nullptr, *k_norm_w = nullptr, *k_norm_b = nullptr;
+    u16 *ky_norm_w = nullptr, *ky_norm_b = nullptr, *gate = nullptr;
+    u16 *attn_norm1 = nullptr, *attn_norm2 = nullptr, *ffn_norm1 = nullptr, *ffn_norm2 = nullptr, *y_norm = nullptr;
+    u16 *ky = nullptr, *vty = nullptr;  // hoisted text K / V^T of the current prompt
+};
+
+struct ProfClass {
+    double flops = 0;
+    long long launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+};
+
+}  // namespace
+
+struct lt_engine {
+    lt_config cfg;
+    int d, L, H, Hkv, hd, F, dkv, qkvn, A, cap, nfinal, kpad, chunks, ld_mod;
+    std::vector<DevBuf> allocs;
+    std::vector<LayerW> lw;
+    // globals
+    u16 *xemb_w = nullptr, *xemb_b = nullptr, *t0_w = nullptr, *t0_b = nullptr, *t2_w = nullptr, *t2_b = nullptr;
+    u16 *capln_w = nullptr, *capln_b = nullptr, *cape_w = nullptr, *cape_b = nullptr, *pad_token = nullptr;
+    u16 *adaln_w = nullptr, *adaln_b = nullptr;  // [L*chunks*d + d, A], [L*chunks*d + d]
+    u16 *final_w = nullptr, *final_b = nullptr;
+    u16 *label_table = nullptr;
+    std::map<std::string, bool> need;
+    bool weights_ok = false;
+    // workspace
+    u16 *x = nullptr, *h = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr;
+    u16 *o = nullptr, *u = nullptr, *patches = nullptr, *frows = nullptr, *mod = nullptr;
+    u16 *tfeat = nullptr, *t1 = nullptr, *temb = nullptr, *cap_ln = nullptr, *cap_emb = nullptr, *adaln_in = nullptr;
+    u16 *capb = nullptr, *capn = nullptr, *kvy = nullptr;
+    float* txt_bias = nullptr;
+    float* rope = nullptr;
+    float rope_scale = -1.f;
+    int prompt_B = 0, prompt_T = 0, prompt_Tpad = 0;
+    // ode
+    void *ys[2] = {nullptr, nullptr}, *ymid = nullptr, *kbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* t_dev = nullptr;
+    int t_cap = 0;
+    std::vector<float> t_host;
+    long long last_nfe = 0;
+    // profiling
+    bool prof_on = false;
+    ProfClass prof[3];
+};
+
+namespace {
+
+int dev_alloc(lt_engine* e, void** out, size_t bytes, bool zero = true) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    LT_CHECK_HIP(hipMalloc(&p, bytes));
+    if (zero) LT_CHECK_HIP(hipMemset(p, 0, bytes));
+    e->allocs.push_back({p, bytes});
+    *out = p;
+    return 0;
+}
+struct ProfScope {
+    lt_engine* e;
+    int k;
+    hipStream_t s;
+    bool on = false;
+    size_t slot = 0;
+    ProfScope(lt_engine* e_, int klass, double flops, hipStream_t s_) : e(e_), k(klass), s(s_) {
+        if (!e->prof_on) return;
+        ProfClass& pc = e->prof[k];
+        pc.flops += flops;
+        pc.launches += 1;
+        if (pc.used < pc.ev.size()) {
+            on = true;
+            slot = pc.used++;
+            hipEventRecord(pc.ev[slot].first, s);
+        }
+    }
+    ~ProfScope() {
+        if (on) hipEventRecord(e->prof[k].ev[slot].second, s);
+    }
+};
+
+int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int ldc, int M, int N, int K,
+         const u16* bias, int epi, hipStream_t s) {
+    GemmArgs g;
+    g.A = A; g.W = W; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
+    g.bias_dtype = bias ? 1 : -1;
+    ProfScope ps(e, 0, 2.0 * M * (double)N * K, s);
+    return launch_gemm_bf16(g, epi, 0, s);
+}
+
+int attention(lt_engine* e, const AttnArgs& a, hipStream_t s) {
+    ProfScope ps(e, 1, 4.0 * a.B * a.H * (double)a.N * a.Nk * a.hd, s);
+    return launch_attention(a, s);
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- weight table -----------------------------------------------------------------------------------
+struct Slot {
+    u16* dst;
+    int rows, cols, dst_ld, r0, row_map;
+};
+
+bool parse_layer_key(const char* key, int* layer, std::string* rest) {
+    if (strncmp(key, "layers.", 7) != 0) return false;
+    char* end = nullptr;
+    long l = strtol(key + 7, &end, 10);
+    if (end == key + 7 || *end != '.') return false;
+    *layer = (int)l;
+    *rest = std::string(end + 1);
+    return true;
+}
+
+int find_slot(lt_engine* e, const std::string& key, Slot* s) {
+    const int d = e->d, A = e->A, cap = e->cap, F = e->F, dkv = e->dkv;
+    int l;
+    std::string r;
+    auto set = [&](u16* dst, int rows, int cols, int ld, int r0 = 0, int map = 0) {
+        s->dst = dst; s->rows = rows; s->cols = cols; s->dst_ld = ld; s->r0 = r0; s->row_map = map;
+        return 0;
+    };
+    if (parse_layer_key(key.c_str(), &l, &r)) {
+        LT_REQUIRE(l >= 0 && l < e->L, "weight key %s: layer out of range", key.c_str());
+        LayerW& w = e->lw[l];
+        const int cd = e->chunks * d;
+        if (r == "attention.wq.weight") return set(w.wqkv, d, d, d, 0);
+        if (r == "attention.wk.weight") return set(w.wqkv, dkv, d, d, d);
+        if (r == "attention.wv.weight") return set(w.wqkv, dkv, d, d, d + dkv);
+        if (r == "attention.wo.weight") return set(w.wo, d, d, d);
+        if (r == "attention.wk_y.weight") return set(w.wkvy, dkv, cap, cap, 0);
+        if (r == "attention.wv_y.weight") return set(w.wkvy, dkv, cap, cap, dkv);
+        if (r == "attention.q_norm.weight") return set(w.q_norm_w, 1, d, d);
+        if (r == "attention.q_norm.bias") return set(w.q_norm_b, 1, d, d);
+        if (r == "attention.k_norm.weight") return set(w.k_norm_w, 1, dkv, dkv);
+        if (r == "attention.k_norm.bias") return set(w.k_norm_b, 1, dkv, dkv);
+        if (r == "attention.ky_norm.weight") return set(w.ky_norm_w, 1, dkv, dkv);
+        if (r == "attention.ky_norm.bias") return set(w.ky_norm_b, 1, dkv, dkv);
+        if (r == "attention.gate") return set(w.gate, 1, e->H, e->H);
+        if (r == "feed_forward.w1.weight") return set(w.w13, F, d, d, 0, 1);
+        if (r == "feed_forward.w3.weight") return set(w.w13, F, d, d, 0, 2);
+        if (r == "feed_forward.w2.weight") return set(w.w2, d, F, F);
+        if (r == "attention_norm1.weight") return set(w.attn_norm1, 1, d, d);
+        if (r == "attention_norm2.weight") return set(w.attn_norm2, 1, d, d);
+        if (r == "ffn_norm1.weight") return set(w.ffn_norm1, 1, d, d);
+        if (r == "ffn_norm2.weight") return set(w.ffn_norm2, 1, d, d);
+        if (r == "attention_y_norm.weight") return set(w.y_norm, 1, cap, cap);
+        if (r == "adaLN_modulation.1.weight") return set(e->adaln_w, cd, A, A, l * cd);
+        if (r == "adaLN_modulation.1.bias") return set(e->adaln_b + (size_t)l * cd, 1, cd, cd);
+    } else {
+        const int cd = e->chunks * d;
+        if (key == "x_embedder.weight") return set(e->xemb_w, d, e->cfg.in_channels * e->cfg.patch_size * e->cfg.patch_size, e->kpad);
+        if (key == "x_embedder.bias") return set(e->xemb_b, 1, d, d);
+        if (key == "t_embedder.mlp.0.weight") return set(e->t0_w, A, 256, 256);
+        if (key == "t_embedder.mlp.0.bias") return set(e->t0_b, 1, A, A);
+        if (key == "t_embedder.mlp.2.weight") return set(e->t2_w, A, A, A);
+        if (key == "t_embedder.mlp.2.bias") return set(e->t2_b, 1, A, A);
+        if (key == "cap_embedder.0.weight") return set(e->capln_w, 1, cap, cap);
+        if (key == "cap_embedder.0.bias") return set(e->capln_b, 1, cap, cap);
+        if (key == "cap_embedder.1.weight") return set(e->cape_w, A, cap, cap);
+        if (key == "cap_embedder.1.bias") return set(e->cape_b, 1, A, A);
+        if (key == "pad_token") return set(e->pad_token, 1, d, d);
+        if (key == "final_layer.linear.weight") return set(e->final_w, e->nfinal, d, d);
+        if (key == "final_layer.linear.bias") return set(e->final_b, 1, e->nfinal, e->nfinal);
+        if (key == "final_layer.adaLN_modulation.1.weight") return set(e->adaln_w, d, A, A, e->L * cd);
+        if (key == "final_layer.adaLN_modulation.1.bias") return set(e->adaln_b + (size_t)e->L * cd, 1, d, d);
+    }
+    lt_set_error("unknown weight key '%s' for this variant", key.c_str());
+    return 2;
+}
+
+int ensure_rope(lt_engine* e, float scale_factor, hipStream_t s) {
+    if (e->rope_scale == scale_factor) return 0;
+    if (launch_rope_table_2d(e->rope, e->cfg.rope_table_len, e->hd, 10000.0f, scale_factor, s)) return 1;
+    e->rope_scale = scale_factor;
+    return 0;
+}
+
+// one NextDiT.forward (model.py:836-864) [+ CFG combine model.py:901-913]
+int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, const lt_step_args* a, int use_cfg,
+                hipStream_t s) {
+    const lt_config& c = e->cfg;
+    const int B = a->batch, p = c.patch_size;
+    LT_REQUIRE(B >= 1 && B <= c.max_batch, "batch %d exceeds max_batch %d", B, c.max_batch);
+    LT_REQUIRE(!use_cfg || B % 2 == 0, "forward_with_cfg needs an even batch (cond+uncond)");
+    LT_REQUIRE(a->latent_h % p == 0 && a->latent_w % p == 0, "latent %dx%d not divisible by patch", a->latent_h, a->latent_w);
+    const int Hp = a->latent_h / p, Wp = a->latent_w / p, N = Hp * Wp, M = B * N;
+    LT_REQUIRE(N <= c.max_tokens, "%d latent tokens exceed max_tokens %d", N, c.max_tokens);
+    LT_REQUIRE(Hp <= c.rope_table_len && Wp <= c.rope_table_len, "latent grid exceeds the RoPE table (%d)", c.rope_table_len);
+    LT_REQUIRE(a->io_dtype == LT_BF16 || a->io_dtype == LT_F32, "io_dtype must be bf16 or f32");
+    LT_REQUIRE(e->prompt_B == B, "lt_prepare_prompt was called for batch %d, step has batch %d", e->prompt_B, B);
+    if (!e->weights_ok && lt_weights_ready(e)) return 2;
+    const int d = e->d, L = e->L, H = e->H, Hkv = e->Hkv, hd = e->hd, F = e->F, dkv = e->dkv, A = e->A;
+    const int Npad = round_up(N, 64);
+    const int cd = e->chunks * d;
+
+    if (ensure_rope(e, a->scale_factor, s)) return 1;
+    float sm_scale;
+    if (a->proportional_attn) {
+        LT_REQUIRE(a->base_seqlen > 1, "proportional_attn needs base_seqlen");
+        // math.sqrt(math.log(seqlen, base_seqlen) / head_dim)  (model.py:374)
+        sm_scale = (float)std::sqrt(std::log((double)N) / std::log((double)a->base_seqlen) / (double)hd);
+    } else {
+        sm_scale = (float)std::sqrt(1.0 / (double)hd);  // model.py:376
+    }
+    const float txt_scale = (float)(1.0 / std::sqrt((double)hd));  // SDPA default (model.py:427-432)
+
+    // patchify + x_embedder (model.py:777-779)
+    {
+        ProfScope ps(e, 2, 0, s);
+        if (launch_patchify(x_in, a->io_dtype, e->patches, B, c.in_channels, a->latent_h, a->latent_w, p, e->kpad, use_cfg, s)) return 1;
+    }
+    if (gemm(e, e->patches, e->kpad, e->xemb_w, e->kpad, e->x, d, M, d, e->kpad, e->xemb_b, 0, s)) return 1;
+    // conditioning: t_embedder (model.py:84-87) + cap_emb (hoisted) -> adaLN vectors of every layer + final
+    {
+        ProfScope ps(e, 2, 0, s);
+        if (launch_timestep_features(t_dev, 0, e->tfeat, B, 256, s)) return 1;
+        if (launch_linear_small_m(e->tfeat, e->t0_w, e->t0_b, e->t1, B, A, 256, 0, s)) return 1;
+        if (launch_linear_small_m(e->t1, e->t2_w, e->t2_b, e->temb, B, A, A, 1, s)) return 1;
+        if (launch_add_bf16(e->temb, e->cap_emb, e->adaln_in, (long long)B * A, s)) return 1;
+        if (launch_linear_small_m(e->adaln_in, e->adaln_w, e->adaln_b, e->mod, B, e->ld_mod, A, 1, s)) return 1;
+    }
+    // first pre-norm: modulate(attention_norm1(x), scale_msa) (model.py:599)
+    {
+        ProfScope ps(e, 2, 0, s);
+        NormModArgs n;
+        n.x = e->x; n.w = e->lw[0].attn_norm1; n.scale = e->mod + 0; n.shift = nullptr; n.out = e->h;
+        n.rows = M; n.rows_per_batch = N; n.d = d; n.ld_mod = e->ld_mod; n.eps = c.norm_eps;
+        if (launch_rmsnorm_mod(n, s)) return 1;
+    }
+    for (int l = 0; l < L; ++l) {
+        LayerW& w = e->lw[l];
+        const u16* modl = e->mod + (size_t)l * cd;  // chunks: scale_msa, gate_msa, scale_mlp, gate_mlp (model.py:595)
+        if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, nullptr, 0, s)) return 1;
+        {
+            ProfScope ps(e, 2, 0, s);
+            QkPostArgs qa;
+            qa.src = e->qkv; qa.ld_src = e->qkvn; qa.B = B; qa.N = N; qa.hd = hd; qa.rope_mode = 1;
+            qa.cs = e->rope; qa.t = t_dev; qa.grid_w = Wp; qa.cs_len = c.rope_table_len; qa.ln_eps = 1e-5f;
+            qa.watershed = a->scale_watershed;
+            qa.col0 = 0; qa.heads = H; qa.dst = e->q;
+            qa.ln_w = c.qk_norm ? w.q_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.q_norm_b : nullptr;
+            if (launch_qk_norm_rope(qa, s)) return 1;
+            qa.col0 = d; qa.heads = Hkv; qa.dst = e->k;
+            qa.ln_w = c.qk_norm ? w.k_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.k_norm_b : nullptr;
+            if (launch_qk_norm_rope(qa, s)) return 1;
+            if (launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
+        }
+        AttnArgs at;
+        at.q = e->q; at.k = e->k; at.vt = e->vt; at.bias = nullptr; at.out = e->attn; at.gate = nullptr; at.accumulate = 0;
+        at.B = B; at.H = H; at.Hkv = Hkv; at.N = N; at.Nk = N; at.Nkpad = Npad; at.hd = hd; at.scale = sm_scale;
+        if (attention(e, at, s)) return 1;
+        if (e->cap > 0) {  // zero-init gated text cross-attention (model.py:420-434)
+            at.k = w.ky; at.vt = w.vty; at.bias = e->txt_bias; at.gate = w.gate; at.accumulate = 1;
+            at.Nk = e->prompt_T; at.Nkpad = e->prompt_Tpad; at.scale = txt_scale;
+            if (attention(e, at, s)) return 1;
+        }
+        if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s)) return 1;
+        {
+            ProfScope ps(e, 2, 0, s);
+            GatedResArgs g;
+            g.x = e->x; g.y = e->o; g.post_w = w.attn_norm2; g.gate = modl + d; g.post_mode = 1; g.gate_mode = 1;
+            g.next_w = w.ffn_norm1; g.next_scale = modl + 2 * d; g.next_shift = nullptr; g.next_mode = 1; g.h = e->h;
+            g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
+            if (launch_gated_residual_norm(g, s)) return 1;
+        }
+        if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s)) return 1;
+        if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s)) return 1;
+        {
+            ProfScope ps(e, 2, 0, s);
+            GatedResArgs g;
+            g.x = e->x; g.y = e->o; g.post_w = w.ffn_norm2; g.gate = modl + 3 * d; g.post_mode = 1; g.gate_mode = 1;
+            g.next_shift = nullptr; g.h = e->h;
+            g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
+            if (l + 1 < L) {
+                g.next_w = e->lw[l + 1].attn_norm1; g.next_scale = e->mod + (size_t)(l + 1) * cd; g.next_mode = 1;
+            } else {  // final layer: LayerNorm(no affine, 1e-6) * (1 + scale) (model.py:657-661)
+                g.next_w = nullptr; g.next_scale = e->mod + (size_t)L * cd; g.next_mode = 2;
+            }
+            if (launch_gated_residual_norm(g, s)) return 1;
+        }
+    }
+    if (gemm(e, e->h, d, e->final_w, d, e->frows, e->nfinal, M, e->nfinal, d, e->final_b, 0, s)) return 1;
+    {
+        ProfScope ps(e, 2, 0, s);
+        const int cfg_ch = a->cfg_channels > 0 ? a->cfg_channels : 3;
+        if (launch_unpatchify_cfg(e->frows, e->nfinal, out, a->io_dtype, B, c.in_channels, c.out_channels, a->latent_h,
+                                  a->latent_w, p, use_cfg, a->cfg_scale, cfg_ch, s)) return 1;
+    }
+    return 0;
+}
+
+float bf16_round_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
+    LT_REQUIRE(cfg && out, "lt_create: null argument");
+    LT_REQUIRE(cfg->variant == LT_VARIANT_NEXT_T2I, "lt_create: variant %d not built in this round (next_t2i only)", cfg->variant);
+    LT_REQUIRE(cfg->dim % cfg->n_heads == 0, "dim %% n_heads != 0");
+    LT_REQUIRE(cfg->n_heads % cfg->n_kv_heads == 0, "n_heads %% n_kv_heads != 0");
+    const int hd = cfg->dim / cfg->n_heads;
+    LT_REQUIRE(hd == 48 || hd == 72 || hd == 96, "head_dim %d not built (48, 72, 96)", hd);
+    LT_REQUIRE(cfg->dim % 64 == 0 && cfg->ffn_hidden % 64 == 0, "dim and ffn_hidden must be multiples of 64");
+    LT_REQUIRE(cfg->cap_feat_dim % 64 == 0 && cfg->cap_feat_dim > 0, "cap_feat_dim must be a positive multiple of 64");
+    LT_REQUIRE(cfg->dim <= 4096 && cfg->cap_feat_dim <= 4096, "dim / cap_feat_dim above 4096 not supported by the row kernels");
+    LT_REQUIRE(cfg->adaln_dim % 8 == 0 && cfg->max_batch >= 1 && cfg->max_batch <= 8, "adaln_dim %% 8 and 1 <= max_batch <= 8 required");
+    LT_REQUIRE(cfg->in_channels * cfg->patch_size * cfg->patch_size <= 64, "patch vector longer than 64");
+    lt_engine* e = new lt_engine();
+    e->cfg = *cfg;
+    e->d = cfg->dim; e->L = cfg->n_layers; e->H = cfg->n_heads; e->Hkv = cfg->n_kv_heads; e->hd = hd;
+    e->F = cfg->ffn_hidden; e->dkv = e->Hkv * hd; e->qkvn = e->d + 2 * e->dkv; e->A = cfg->adaln_dim;
+    e->cap = cfg->cap_feat_dim; e->nfinal = cfg->patch_size * cfg->patch_size * cfg->out_channels;
+    e->kpad = 64; e->chunks = 4; e->ld_mod = e->L * e->chunks * e->d + e->d;
+    const int d = e->d, L = e->L, F = e->F, dkv = e->dkv, A = e->A, cap = e->cap, H = e->H, Hkv = e->Hkv;
+    e->lw.resize(L);
+    auto fail = [&]() { lt_destroy(e); return 1; };
+#define A16(ptr, n) do { void* _p; if (dev_alloc(e, &_p, (size_t)(n) * 2)) return fail(); (ptr) = (u16*)_p; } while (0)
+    const int Tmax = round_up(cfg->max_text > 0 ? cfg->max_text : 64, 64);
+    for (int l = 0; l < L; ++l) {
+        LayerW& w = e->lw[l];
+        A16(w.wqkv, (size_t)e->qkvn * d); A16(w.wo, (size_t)d * d); A16(w.w13, (size_t)2 * F * d); A16(w.w2, (size_t)d * F);
+        A16(w.wkvy, (size_t)2 * dkv * cap);
+        A16(w.q_norm_w, d); A16(w.q_norm_b, d); A16(w.k_norm_w, dkv); A16(w.k_norm_b, dkv);
+        A16(w.ky_norm_w, dkv); A16(w.ky_norm_b, dkv); A16(w.gate, H);
+        A16(w.attn_norm1, d); A16(w.attn_norm2, d); A16(w.ffn_norm1, d); A16(w.ffn_norm2, d); A16(w.y_norm, cap);
+        A16(w.ky, (size_t)cfg->max_batch * Hkv * Tmax * hd); A16(w.vty, (size_t)cfg->max_batch * Hkv * hd * Tmax);
+        char key[128];
+        const char* names[] = {"attention.wq.weight", "attention.wk.weight", "attention.wv.weight", "attention.wo.weight",
+                               "attention.wk_y.weight", "attention.wv_y.weight", "attention.gate", "feed_forward.w1.weight",
+                               "feed_forward.w2.weight", "feed_forward.w3.weight", "attention_norm1.weight",
+                               "attention_norm2.weight", "ffn_norm1.weight", "ffn_norm2.weight", "attention_y_norm.weight",
+                               "adaLN_modulation.1.weight", "adaLN_modulation.1.bias"};
+        for (const char* nm : names) { snprintf(key, sizeof(key), "layers.%d.%s", l, nm); e->need[key] = false; }
+        if (cfg->qk_norm) {
+            const char* qn[] = {"attention.q_norm.weight", "attention.q_norm.bias", "attention.k_norm.weight",
+                                "attention.k_norm.bias", "attention.ky_norm.weight", "attention.ky_norm.bias"};
+            for (const char* nm : qn) { snprintf(key, sizeof(key), "layers.%d.%s", l, nm); e->need[key] = false; }
+        }
+    }
+    A16(e->xemb_w, (size_t)d * e->kpad); A16(e->xemb_b, d); A16(e->t0_w, (size_t)A * 256); A16(e->t0_b, A);
+    A16(e->t2_w, (size_t)A * A); A16(e->t2_b, A); A16(e->capln_w, cap); A16(e->capln_b, cap);
+    A16(e->cape_w, (size_t)A * cap); A16(e->cape_b, A); A16(e->pad_token, d);
+    A16(e->adaln_w, (size_t)e->ld_mod * A); A16(e->adaln_b, e->ld_mod);
+    A16(e->final_w, (size_t)e->nfinal * d); A16(e->final_b, e->nfinal);
+    for (const char* nm : {"x_embedder.weight", "x_embedder.bias", "t_embedder.mlp.0.weight", "t_embedder.mlp.0.bias",
+                           "t_embedder.mlp.2.weight", "t_embedder.mlp.2.bias", "cap_embedder.0.weight", "cap_embedder.0.bias",
+                           "cap_embedder.1.weight", "cap_embedder.1.bias", "final_layer.linear.weight", "final_layer.linear.bias",
+                           "final_layer.adaLN_modulation.1.weight", "final_layer.adaLN_modulation.1.bias"})
+        e->need[nm] = false;
+    // workspace
+    const size_t Bm = cfg->max_batch, Nm = cfg->max_tokens, M = Bm * Nm;
+    const size_t Npad = round_up((int)Nm, 64);
+    A16(e->x, M * d); A16(e->h, M * d); A16(e->qkv, M * e->qkvn); A16(e->q, M * d); A16(e->k, M * dkv);
+    A16(e->vt, Bm * Hkv * hd * Npad); A16(e->attn, M * d); A16(e->o, M * d); A16(e->u, M * F);
+    A16(e->patches, M * e->kpad); A16(e->frows, M * e->nfinal); A16(e->mod, Bm * e->ld_mod);
+    A16(e->tfeat, Bm * 256); A16(e->t1, Bm * A); A16(e->temb, Bm * A); A16(e->cap_ln, Bm * cap);
+    A16(e->cap_emb, Bm * A); A16(e->adaln_in, Bm * A);
+    A16(e->capb, Bm * Tmax * cap); A16(e->capn, Bm * Tmax * cap); A16(e->kvy, Bm * Tmax * 2 * dkv);
+    {
+        void* p;
+        if (dev_alloc(e, &p, Bm * Tmax * sizeof(float))) return fail();
+        e->txt_bias = (float*)p;
+        if (dev_alloc(e, &p, (size_t)2 * cfg->rope_table_len * (hd / 2) * 2 * sizeof(float))) return fail();
+        e->rope = (float*)p;
+        const size_t state = Bm * cfg->in_channels * Nm * cfg->patch_size * cfg->patch_size * sizeof(float);
+        for (int i = 0; i < 2; ++i) { if (dev_alloc(e, &e->ys[i], state)) return fail(); }
+        if (dev_alloc(e, &e->ymid, state)) return fail();
+        for (int i = 0; i < 4; ++i) { if (dev_alloc(e, &e->kbuf[i], state)) return fail(); }
+    }
+#undef A16
+    *out = e;
+    return 0;
+}
+
+extern "C" void lt_destroy(lt_engine* e) {
+    if (!e) return;
+    for (auto& b : e->allocs) hipFree(b.p);
+    if (e->t_dev) hipFree(e->t_dev);
+    for (int k = 0; k < 3; ++k)
+        for (auto& pr : e->prof[k].ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    delete e;
+}
+
+extern "C" int lt_set_weight(lt_engine* e, const char* key, const void* src_dev, int32_t dtype, const int64_t* shape,
+                             int32_t ndim, void* stream) {
+    LT_REQUIRE(e && key && src_dev && shape, "lt_set_weight: null argument");
+    Slot s;
+    if (find_slot(e, key, &s)) return 2;
+    long long n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    LT_REQUIRE(n == (long long)s.rows * s.cols, "weight '%s': %lld elements given, %lld expected (%d x %d)", key, n,
+               (long long)s.rows * s.cols, s.rows, s.cols);
+    if (launch_upload_rows(src_dev, dtype, s.dst, s.rows, s.cols, s.dst_ld, s.r0, s.row_map, (hipStream_t)stream)) return 1;
+    auto it = e->need.find(key);
+    if (it != e->need.end()) it->second = true;
+    e->weights_ok = false;
+    return 0;
+}
+
+extern "C" int lt_weights_ready(lt_engine* e) {
+    LT_REQUIRE(e, "null engine");
+    for (auto& kv : e->need) LT_REQUIRE(kv.second, "weight '%s' was never uploaded", kv.first.c_str());
+    e->weights_ok = true;
+    return 0;
+}
+
+extern "C" int lt_prepare_prompt(lt_engine* e, const void* cap_feats_dev, int32_t cap_dtype, const int32_t* cap_mask_dev,
+                                 int32_t B, int32_t T, void* stream) {
+    LT_REQUIRE(e && cap_feats_dev && cap_mask_dev, "lt_prepare_prompt: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const lt_config& c = e->cfg;
+    const int Tmax = round_up(c.max_text > 0 ? c.max_text : 64, 64);
+    LT_REQUIRE(B >= 1 && B <= c.max_batch, "prompt batch %d exceeds max_batch %d", B, c.max_batch);
+    LT_REQUIRE(T >= 1 && T <= Tmax, "text length %d exceeds max_text %d", T, Tmax);
+    LT_REQUIRE(cap_dtype == LT_BF16 || cap_dtype == LT_F32, "cap_feats dtype must be bf16 or f32");
+    if (lt_weights_ready(e)) return 2;
+    const int Tpad = round_up(T, 64), cap = e->cap, dkv = e->dkv, A = e->A;
+    ProfScope ps(e, 2, 0, s);
+    if (launch_cast_to_bf16(cap_feats_dev, cap_dtype, e->capb, (long long)B * T * cap, s)) return 1;
+    if (launch_mask_to_bias(cap_mask_dev, e->txt_bias, B, T, Tpad, s)) return 1;
+    // adaln_input's caption half (model.py:847-850)
+    if (launch_cap_pool_ln(e->capb, LT_BF16, cap_mask_dev, e->capln_w, e->capln_b, e->cap_ln, B, T, cap, s)) return 1;
+    if (launch_linear_small_m(e->cap_ln, e->cape_w, e->cape_b, e->cap_emb, B, A, cap, 0, s)) return 1;
+    for (int l = 0; l < e->L; ++l) {
+        LayerW& w = e->lw[l];
+        NormModArgs n;  // attention_y_norm (model.py:602)
+        n.x = e->capb; n.w = w.y_norm; n.scale = nullptr; n.shift = nullptr; n.out = e->capn;
+        n.rows = B * T; n.rows_per_batch = T; n.d = cap; n.ld_mod = 0; n.eps = c.norm_eps;
+        if (launch_rmsnorm_mod(n, s)) return 1;
+        GemmArgs g;  // wk_y | wv_y (model.py:421-422)
+        g.A = e->capn; g.W = w.wkvy; g.C = e->kvy; g.bias = nullptr; g.M = B * T; g.N = 2 * dkv; g.K = cap;
+        g.lda = cap; g.ldw = cap; g.ldc = 2 * dkv; g.bias_dtype = -1;
+        if (launch_gemm_bf16(g, 0, 0, s)) return 1;
+        QkPostArgs qa;  // ky_norm, no rotary (model.py:421)
+        qa.src = e->kvy; qa.ld_src = 2 * dkv; qa.col0 = 0; qa.B = B; qa.N = T; qa.heads = e->Hkv; qa.hd = e->hd;
+        qa.rope_mode = 0; qa.cs = nullptr; qa.t = nullptr; qa.grid_w = 1; qa.cs_len = 0; qa.ln_eps = 1e-5f; qa.watershed = 0.f;
+        qa.ln_w = c.qk_norm ? w.ky_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.ky_norm_b : nullptr; qa.dst = w.ky;
+        if (launch_qk_norm_rope(qa, s)) return 1;
+        if (launch_v_transpose(e->kvy, 2 * dkv, dkv, w.vty, B, T, Tpad, e->Hkv, e->hd, s)) return 1;
+    }
+    e->prompt_B = B; e->prompt_T = T; e->prompt_Tpad = Tpad;
+    return 0;
+}
+
+extern "C" int lt_prepare_labels(lt_engine* e, const int32_t* labels_dev, int32_t B, void* stream) {
+    (void)e; (void)labels_dev; (void)B; (void)stream;
+    lt_set_error("lt_prepare_labels: class-conditional variant not built in this round");
+    return 2;
+}
+
+extern "C" int lt_forward(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev, const lt_step_args* a, void* stream) {
+    LT_REQUIRE(e && x_dev && t_dev && out_dev && a, "lt_forward: null argument");
+    return run_forward(e, x_dev, t_dev, out_dev, a, 0, (hipStream_t)stream);
+}
+
+extern "C" int lt_forward_cfg(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev, const lt_step_args* a, void* stream) {
+    LT_REQUIRE(e && x_dev && t_dev && out_dev && a, "lt_forward_cfg: null argument");
+    return run_forward(e, x_dev, t_dev, out_dev, a, 1, (hipStream_t)stream);
+}
+
+extern "C" int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, void* final_dev, const float* tgrid_host,
+                             int32_t n_grid, int32_t method, int32_t use_cfg, int32_t t_round, const lt_step_args* a,
+                             void* stream) {
+    LT_REQUIRE(e && z_dev && tgrid_host && a, "lt_sample_ode: null argument");
+    LT_REQUIRE(n_grid >= 2, "lt_sample_ode: need at least 2 grid points");
+    LT_REQUIRE(method >= LT_ODE_EULER && method <= LT_ODE_RK4, "lt_sample_ode: unknown method %d", method);
+    hipStream_t s = (hipStream_t)stream;
+    const int B = a->batch;
+    const int stages = method == LT_ODE_EULER ? 1 : (method == LT_ODE_MIDPOINT ? 2 : 4);
+    const int ncalls = (n_grid - 1) * stages;
+    const long long n = (long long)B * e->cfg.in_channels * a->latent_h * a->latent_w;
+    const size_t esz = a->io_dtype == LT_BF16 ? 2 : 4;
+    const size_t sbytes = (size_t)n * esz;
+    const bool bf = a->io_dtype == LT_BF16;
+    // stage times; torchdiffeq's _PerturbFunc casts t to the state dtype before calling the model, then
+    // integrators.py:108 broadcasts it to an fp32 [B] vector
+    e->t_host.assign((size_t)ncalls * B, 0.f);
+    std::vector<float> dts(n_grid - 1);
+    for (int i = 0; i + 1 < n_grid; ++i) {
+        const float t0 = tgrid_host[i], t1 = tgrid_host[i + 1];
+        const float dt = t1 - t0;
+        dts[i] = dt;
+        float ts[4];
+        if (method == LT_ODE_EULER) ts[0] = t0;
+        else if (method == LT_ODE_MIDPOINT) { ts[0] = t0; ts[1] = t0 + 0.5f * dt; }
+        else { ts[0] = t0; ts[1] = t0 + dt * (float)(1.0 / 3.0); ts[2] = t0 + dt * (float)(2.0 / 3.0); ts[3] = t1; }
+        for (int k = 0; k < stages; ++k) {
+            const float tv = (t_round && bf) ? bf16_round_host(ts[k]) : ts[k];
+            for (int b = 0; b < B; ++b) e->t_host[((size_t)i * stages + k) * B + b] = tv;
+        }
+    }
+    if (e->t_cap < ncalls * B) {
+        if (e->t_dev) LT_CHECK_HIP(hipFree(e->t_dev));
+        LT_CHECK_HIP(hipMalloc((void**)&e->t_dev, (size_t)ncalls * B * sizeof(float)));
+        e->t_cap = ncalls * B;
+    }
+    LT_CHECK_HIP(hipMemcpyAsync(e->t_dev, e->t_host.data(), (size_t)ncalls * B * sizeof(float), hipMemcpyHostToDevice, s));
+    LT_CHECK_HIP(hipMemcpyAsync(e->ys[0], z_dev, sbytes, hipMemcpyDeviceToDevice, s));
+    if (traj_dev) LT_CHECK_HIP(hipMemcpyAsync(traj_dev, z_dev, sbytes, hipMemcpyDeviceToDevice, s));
+    int cur = 0;
+    long long nfe = 0;
+    auto model = [&](const void* y, int call, void* out) {
+        ++nfe;
+        return run_forward(e, y, e->t_dev + (size_t)call * B, out, a, use_cfg, s);
+    };
+    const int dt_code = bf ? 1 : 0;
+    for (int i = 0; i + 1 < n_grid; ++i) {
+        void* y0 = e->ys[cur];
+        void* y1 = e->ys[cur ^ 1];
+        const float dt = dts[i];
+        const int c0 = i * stages;
+        if (method == LT_ODE_EULER) {
+            if (model(y0, c0, e->kbuf[0])) return 1;
+            if (launch_ode_combine(0, y0, e->kbuf[0], nullptr, nullptr, nullptr, y1, dt_code, dt, n, s)) return 1;
+        } else if (method == LT_ODE_MIDPOINT) {
+            if (model(y0, c0, e->kbuf[0])) return 1;
+            if (launch_ode_combine(0, y0, e->kbuf[0], nullptr, nullptr, nullptr, e->ymid, dt_code, 0.5f * dt, n, s)) return 1;
+            if (model(e->ymid, c0 + 1, e->kbuf[1])) return 1;
+            if (launch_ode_combine(0, y0, e->kbuf[1], nullptr, nullptr, nullptr, y1, dt_code, dt, n, s)) return 1;
+        } else {
+            if (model(y0, c0, e->kbuf[0])) return 1;
+            if (launch_ode_combine(1, y0, e->kbuf[0], nullptr, nullptr, nullptr, e->ymid, dt_code, dt, n, s)) return 1;
+            if (model(e->ymid, c0 + 1, e->kbuf[1])) return 1;
+            if (launch_ode_combine(2, y0, e->kbuf[0], e->kbuf[1], nullptr, nullptr, e->ymid, dt_code, dt, n, s)) return 1;
+            if (model(e->ymid, c0 + 2, e->kbuf[2])) return 1;
+            if (launch_ode_combine(3, y0, e->kbuf[0], e->kbuf[1], e->kbuf[2], nullptr, e->ymid, dt_code, dt, n, s)) return 1;
+            if (model(e->ymid, c0 + 3, e->kbuf[3])) return 1;
+            if (launch_ode_combine(4, y0, e->kbuf[0], e->kbuf[1], e->kbuf[2], e->kbuf[3], y1, dt_code, dt, n, s)) return 1;
+        }
+        if (traj_dev) LT_CHECK_HIP(hipMemcpyAsync((char*)traj_dev + (size_t)(i + 1) * sbytes, y1, sbytes, hipMemcpyDeviceToDevice, s));
+        cur ^= 1;
+    }
+    if (final_dev) LT_CHECK_HIP(hipMemcpyAsync(final_dev, e->ys[cur], sbytes, hipMemcpyDeviceToDevice, s));
+    e->last_nfe = nfe;
+    return 0;
+}
+
+extern "C" int64_t lt_last_nfe(lt_engine* e) { return e ? e->last_nfe : -1; }
+
+// ---- profiling ------------------------------------------------------------------------------------------
+extern "C" int lt_profile_enable(lt_engine* e, int32_t on) {
+    LT_REQUIRE(e, "null engine");
+    if (on) {
+        const size_t want[3] = {8192, 4096, 16384};
+        for (int k = 0; k < 3; ++k) {
+            while (e->prof[k].ev.size() < want[k]) {
+                hipEvent_t a, b;
+                LT_CHECK_HIP(hipEventCreate(&a));
+                LT_CHECK_HIP(hipEventCreate(&b));
+                e->prof[k].ev.push_back({a, b});
+            }
+        }
+    }
+    e->prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int lt_profile_reset(lt_engine* e) {
+    LT_REQUIRE(e, "null engine");
+    for (int k = 0; k < 3; ++k) { e->prof[k].flops = 0; e->prof[k].launches = 0; e->prof[k].used = 0; }
+    return 0;
+}
+
+extern "C" int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t* launches, double* flops) {
+    LT_REQUIRE(e && klass >= 0 && klass < 3, "lt_profile_read: bad class");
+    ProfClass& pc = e->prof[klass];
+    double total = 0;
+    for (size_t i = 0; i < pc.used; ++i) {
+        float t = 0;
+        LT_CHECK_HIP(hipEventElapsedTime(&t, pc.ev[i].first, pc.ev[i].second));
+        total += t;
+    }
+    // scale to all launches of the class if the event pool ran out (same launch mix every step)
+    if (pc.used > 0 && (long long)pc.used < pc.launches) total *= (double)pc.launches / (double)pc.used;
+    if (ms) *ms = total;
+    if (launches) *launches = pc.launches;
+    if (flops) *flops = pc.flops;
+    return 0;
+}
+
+// ---- operator-level entry points ---------------------------------------------------------------------------
+extern "C" int lt_op_gemm_bf16(const void* A, const void* W, const void* bias, int32_t bias_dtype, void* C, int32_t M,
+                               int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* stream) {
+    LT_REQUIRE(A && W && C, "lt_op_gemm_bf16: null pointer");
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = bias ? bias_dtype : -1;
+    return launch_gemm_bf16(g, epilogue, variant, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_pack_w13(const void* w1, const void* w3, void* out, int32_t F, int32_t K, void* stream) {
+    LT_REQUIRE(w1 && w3 && out, "lt_op_pack_w13: null pointer");
+    return launch_pack_w13((const u16*)w1, (const u16*)w3, (u16*)out, F, K, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_rmsnorm_mod(const void* x, const void* w, const void* scale, const void* shift, int32_t ld_mod,
+                                 void* out, int32_t B, int32_t N, int32_t d, float eps, void* stream) {
+    LT_REQUIRE(x && out, "lt_op_rmsnorm_mod: null pointer");
+    NormModArgs n;
+    n.x = (const u16*)x; n.w = (const u16*)w; n.scale = (const u16*)scale; n.shift = (const u16*)shift; n.out = (u16*)out;
+    n.rows = B * N; n.rows_per_batch = N; n.d = d; n.ld_mod = ld_mod; n.eps = eps;
+    return launch_rmsnorm_mod(n, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_gated_residual_norm(void* x, const void* y, const void* post_w, const void* gate, int32_t post_mode,
+                                         int32_t gate_mode, const void* next_w, const void* next_scale,
+                                         const void* next_shift, int32_t next_mode, int32_t ld_mod, void* h, int32_t B,
+                                         int32_t N, int32_t d, float eps, float eps_next, void* stream) {
+    LT_REQUIRE(x && y, "lt_op_gated_residual_norm: null pointer");
+    GatedResArgs g;
+    g.x = (u16*)x; g.y = (const u16*)y; g.post_w = (const u16*)post_w; g.gate = (const u16*)gate;
+    g.next_w = (const u16*)next_w; g.next_scale = (const u16*)next_scale; g.next_shift = (const u16*)next_shift;
+    g.h = (u16*)h; g.rows = B * N; g.rows_per_batch = N; g.d = d; g.ld_mod = ld_mod; g.post_mode = post_mode;
+    g.gate_mode = gate_mode; g.next_mode = next_mode; g.eps = eps; g.eps_next = eps_next;
+    return launch_gated_residual_norm(g, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_qk_norm_rope(const void* src, int32_t ld_src, int32_t col0, const void* ln_w, const void* ln_b,
+                                  float ln_eps, void* dst, int32_t B, int32_t N, int32_t heads, int32_t hd,
+                                  int32_t rope_mode, const void* cs_table, int32_t grid_w, void* stream) {
+    LT_REQUIRE(src && dst, "lt_op_qk_norm_rope: null pointer");
+    QkPostArgs q;
+    q.src = (const u16*)src; q.ld_src = ld_src; q.col0 = col0; q.ln_w = (const u16*)ln_w; q.ln_b = (const u16*)ln_b;
+    q.ln_eps = ln_eps; q.dst = (u16*)dst; q.B = B; q.N = N; q.heads = heads; q.hd = hd; q.rope_mode = rope_mode;
+    q.cs = (const float*)cs_table; q.t = nullptr; q.grid_w = grid_w > 0 ? grid_w : 1; q.watershed = 0.f;
+    q.cs_len = 0;  // op level: the caller hands over the single branch table it wants (no branch offset)
+    return launch_qk_norm_rope(q, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_v_transpose(const void* src, int32_t ld_src, int32_t col0, void* dst, int32_t B, int32_t N,
+                                 int32_t Npad, int32_t kv_heads, int32_t hd, void* stream) {
+    LT_REQUIRE(src && dst, "lt_op_v_transpose: null pointer");
+    return launch_v_transpose((const u16*)src, ld_src, col0, (u16*)dst, B, N, Npad, kv_heads, hd, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_attention(const void* q, const void* k, const void* vt, const float* bias, void* out, const void* gate,
+                               int32_t accumulate, int32_t B, int32_t H, int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad,
+                               int32_t hd, float scale, void* stream) {
+    LT_REQUIRE(q && k && vt && out, "lt_op_attention: null pointer");
+    AttnArgs a;
+    a.q = (const u16*)q; a.k = (const u16*)k; a.vt = (const u16*)vt; a.bias = bias; a.out = (u16*)out;
+    a.gate = (const u16*)gate; a.accumulate = accumulate; a.B = B; a.H = H; a.Hkv = Hkv; a.N = N; a.Nk = Nk;
+    a.Nkpad = Nkpad; a.hd = hd; a.scale = scale;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_linear_small_m(const void* a, const void* w, const void* b, void* y, int32_t M, int32_t N, int32_t K,
+                                    int32_t act_in, void* stream) {
+    LT_REQUIRE(a && w && y, "lt_op_linear_small_m: null pointer");
+    return launch_linear_small_m((const u16*)a, (const u16*)w, (const u16*)b, (u16*)y, M, N, K, act_in, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_rope_table_2d(void* out, int32_t len, int32_t hd, float theta, float scale_factor, void* stream) {
+    LT_REQUIRE(out, "lt_op_rope_table_2d: null pointer");
+    return launch_rope_table_2d((float*)out, len, hd, theta, scale_factor, (hipStream_t)stream);
+}

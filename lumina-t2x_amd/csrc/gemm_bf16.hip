@@ -1,0 +1,236 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T (+bias) ; fp32 accumulate, bf16 out.
+//
+// Replaces every fairscale Column/RowParallelLinear == F.linear at mp=1 on the denoising path
+// (lumina_next_t2i/models/model.py:165-209 wq/wk/wv/wo, :475-495 w1/w2/w3).
+//
+// Design (CDNA4-first, not a CUDA tiling):
+//  * 256x256x64 macro tile, 8 waves (2 along M x 4 along N), each wave owns 128x64 of C as
+//    4x2 tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator registers / lane).
+//  * A and W tiles go HBM -> LDS with buffer_load ... lds (16 B / lane, no VGPR round trip),
+//    double-buffered (2 x 64 KiB of the CU's 160 KiB).  The LDS image is lane-linear, so the bank
+//    swizzle is applied to the per-lane SOURCE address and again on the ds_read_b128 (guide rule 21):
+//    chunk' = chunk ^ ((row >> 1) & 7) makes the 32x32x16 fragment reads conflict-free.
+//  * Buffer descriptors carry the row bound: rows >= M (or >= N for W) read as zero and their
+//    stores are predicated, so M and N need not be tile multiples.  K must be a multiple of 64.
+//  * The MFMA is issued as D'[n][m] = W_frag x A_frag so that each lane ends up holding 4 consecutive
+//    N for one row of C; a v_permlane32_swap pair widens that to one 16-byte store per lane.
+//  * Epilogue 1 fuses SwiGLU (model.py:497-502): W is w1/w3 interleaved in 32-row groups, so the
+//    two accumulator tiles of a wave hold silu-input and gate for the same (m, n).
+//  * Workgroup -> tile map is XCD-aware: each XCD (private 4 MiB L2) gets a contiguous run of a
+//    grouped (4 tile-rows, column-major) order so neighbouring tiles share A/W panels in one L2.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int STAGE_BYTES = 65536;  // A 32 KiB + W 32 KiB
+constexpr int W_OFF = 32768;
+
+__device__ __forceinline__ void tile_coords(int bid, int nwg, int TM, int TN, int& tm, int& tn) {
+    const int NX = 8;
+    const int xcd = bid % NX, idx = bid / NX;
+    const int q = nwg / NX, r = nwg % NX;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int G = 4;
+    const int per_group = G * TN;
+    const int g = L / per_group;
+    const int first_m = g * G;
+    const int gsz = min(G, TM - first_m);
+    const int in = L - g * per_group;
+    tm = first_m + in % gsz;
+    tn = in / gsz;
+}
+
+__device__ __forceinline__ float load_bias(const void* bias, int dt, int n) {
+    return dt == 0 ? ((const float*)bias)[n] : bf2f(((const u16*)bias)[n]);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, TM, TN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // descriptors based at the tile's first row; num_records = bytes left => rows past the end read 0
+    const long long a_left = (long long)(p.M - m0) * p.lda * 2;
+    const long long w_left = (long long)(p.N - n0) * p.ldw * 2;
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.A + (size_t)m0 * p.lda), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
+    __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.W + (size_t)n0 * p.ldw), 0, (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left), 0x00020000);
+
+    // staging: wave w copies 1-KiB pieces j = w + 8 i (8 rows x 128 B each) of both tiles
+    const int srow = wave * 8 + (lane >> 3);
+    const int sswz = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16;
+    int a_voff[4], w_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_voff[i] = (srow + 64 * i) * p.lda * 2 + sswz;
+        w_voff[i] = (srow + 64 * i) * p.ldw * 2 + sswz;
+    }
+    auto stage = [&](int buf, int kt) {
+        const int soff = kt * BK * 2;
+        char* base = smem + buf * STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(base + i * 8192), 16, a_voff[i], soff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(base + W_OFF + i * 8192), 16, w_voff[i], soff, 0, 0);
+    };
+
+    // fragment read offsets (row ≡ l31 mod 32 in every sub-tile, so the swizzle key is per lane)
+    const int fswz = (l31 >> 1) & 7;
+    const int a_row_off = (wm * 128 + l31) * 128;
+    const int w_row_off = W_OFF + (wn * 64 + l31) * 128;
+    int coff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) coff[s] = ((2 * s + hi) ^ fswz) << 4;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 wf[2], af[4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wf[nt] = *(const bf16x8*)(sb + w_row_off + nt * 4096 + coff[s]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf16x8*)(sb + a_row_off + mt * 4096 + coff[s]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, per 32x32 tile, row m = l31 and columns 8q + 4hi + j (reg 4q+j) ----
+    const size_t ldc = p.ldc;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 128 + mt * 32 + l31;
+        u16* crow = p.C + (size_t)m * ldc;
+        if (EPI == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int nbase = n0 + wn * 64 + nt * 32;
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = acc[mt][nt][8 * qp + j];
+                    if (p.bias_dtype >= 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            int n = nbase + 16 * qp + 8 * (j >> 2) + 4 * hi + (j & 3);
+                            n = n < p.N ? n : p.N - 1;  // clamped (branch-free); out-of-range columns are not stored
+                            v[j] += load_bias(p.bias, p.bias_dtype, n);
+                        }
+                    }
+                    unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
+                    unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    const int col = nbase + 16 * qp + 8 * hi;
+                    if (m < p.M && col < p.N) {
+                        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        *(u32x4*)(crow + col) = o;
+                    }
+                }
+            }
+        } else {
+            const int obase = (n0 + wn * 64) / 2;
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
+                    const float a = bfr(acc[mt][0][8 * qp + j]);
+                    const float b = bfr(acc[mt][1][8 * qp + j]);
+                    v[j] = bfr(silu_f(a)) * b;
+                }
+                unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
+                unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
+                auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                const int col = obase + 16 * qp + 8 * hi;
+                if (m < p.M && col < p.N / 2) {
+                    u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                    *(u32x4*)(crow + col) = o;
+                }
+            }
+        }
+    }
+}
+
+// w1/w3 -> 32-row interleaved packed weight (row P: block = P/64; P%64 < 32 -> w1 else w3)
+__global__ void pack_w13_kernel(const u16* __restrict__ w1, const u16* __restrict__ w3, u16* __restrict__ out,
+                                int F, int K) {
+    const int chunks_per_row = K / 8;
+    const long long total = (long long)2 * F * chunks_per_row;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int P = (int)(i / chunks_per_row), c = (int)(i % chunks_per_row);
+        const int blk = P >> 6, w = P & 63;
+        const u16* src = (w < 32 ? w1 : w3) + (size_t)(blk * 32 + (w & 31)) * K + c * 8;
+        *(bf8_t*)(out + (size_t)P * K + c * 8) = *(const bf8_t*)src;
+    }
+}
+
+}  // namespace
+
+int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream) {
+    LT_REQUIRE(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
+    LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
+    LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
+    LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
+    (void)variant;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        attr_done = true;
+    }
+    const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
+    dim3 grid(TM * TN), block(512);
+    if (epilogue == 0)
+        hipLaunchKernelGGL(gemm_bf16_tn_256<0>, grid, block, 2 * STAGE_BYTES, stream, a);
+    else
+        hipLaunchKernelGGL(gemm_bf16_tn_256<1>, grid, block, 2 * STAGE_BYTES, stream, a);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream) {
+    LT_REQUIRE(F % 32 == 0 && K % 8 == 0, "pack_w13: F %% 32 and K %% 8 required");
+    hipLaunchKernelGGL(pack_w13_kernel, dim3(1024), dim3(256), 0, stream, w1, w3, out, F, K);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}

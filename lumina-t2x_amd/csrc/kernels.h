@@ -1,0 +1,106 @@
+// Internal launcher interface between the HIP kernel files and the engine / C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+struct GemmArgs {
+    const u16* A;      // [M, lda] bf16
+    const u16* W;      // [N, ldw] bf16 (K contiguous)
+    u16* C;            // [M, ldc] bf16 (ldc >= N, or N/2 for the SwiGLU epilogue)
+    const void* bias;  // [N] or null
+    int M, N, K;
+    int lda, ldw, ldc;
+    int bias_dtype;    // -1 none, 0 f32, 1 bf16
+};
+int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream);
+int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream);
+
+// ---- norm / residual kernels (norm.hip) --------------------------------------------------------
+struct NormModArgs {
+    const u16* x;      // [rows, d]
+    const u16* w;      // [d] or null
+    const u16* scale;  // [B, ld_mod] or null
+    const u16* shift;  // [B, ld_mod] or null
+    u16* out;          // [rows, d]
+    int rows, rows_per_batch, d, ld_mod;
+    float eps;
+};
+int launch_rmsnorm_mod(const NormModArgs& a, hipStream_t stream);
+
+struct GatedResArgs {
+    u16* x;                 // residual stream [rows, d], updated in place
+    const u16* y;           // branch output [rows, d]
+    const u16* post_w;      // RMSNorm weight applied to y (post_mode 1)
+    const u16* gate;        // [B, ld_mod] or null
+    const u16* next_w;      // weight of the next pre-norm or null
+    const u16* next_scale;  // [B, ld_mod] or null
+    const u16* next_shift;  // [B, ld_mod] or null
+    u16* h;                 // [rows, d] next branch input (next_mode != 0)
+    int rows, rows_per_batch, d, ld_mod;
+    int post_mode, gate_mode, next_mode;
+    float eps, eps_next;
+};
+int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream);
+
+// ---- q/k/v post-processing (qkv_post.hip) ------------------------------------------------------
+struct QkPostArgs {
+    const u16* src;      // [B*N, ld_src]
+    const u16* ln_w;     // [heads*hd] or null (no qk-norm)
+    const u16* ln_b;
+    u16* dst;            // [B, heads, N, hd]
+    const float* cs;     // (cos,sin) table, see lt_op_qk_norm_rope
+    const float* t;      // device timesteps (branch select) or null
+    int ld_src, col0, B, N, heads, hd;
+    int rope_mode, grid_w, cs_len;  // cs_len: positions per branch table
+    float ln_eps, watershed;
+};
+int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream);
+int launch_v_transpose(const u16* src, int ld_src, int col0, u16* dst, int B, int N, int Npad, int kv_heads,
+                       int hd, hipStream_t stream);
+
+// ---- attention (attention.hip) -----------------------------------------------------------------
+struct AttnArgs {
+    const u16* q;       // [B, H, N, hd]
+    const u16* k;       // [B, Hkv, Nk_rows, hd]
+    const u16* vt;      // [B, Hkv, hd, Nkpad]
+    const float* bias;  // [B, Nkpad] or null
+    u16* out;           // [B, N, H*hd]
+    const u16* gate;    // [H] bf16 (accumulate mode)
+    int accumulate;
+    int B, H, Hkv, N, Nk, Nkpad, hd;
+    float scale;
+};
+int launch_attention(const AttnArgs& a, hipStream_t stream);
+
+// ---- small kernels (misc.hip) ------------------------------------------------------------------
+int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int M, int N, int K, int act_in,
+                          hipStream_t stream);
+// weights upload: cast src (f32/bf16/f16) to bf16 rows at dst (+ row offset handled by caller)
+int launch_cast_to_bf16(const void* src, int dtype, u16* dst, long long n, hipStream_t stream);
+// x [B,C,H,W] (bf16/f32) -> patch rows [B*N, kpad] bf16, (c,ph,pw) order, zero padded (model.py:777)
+int launch_patchify(const void* x, int x_dtype, u16* out, int B, int C, int H, int W, int patch, int kpad,
+                    int dup_first_half, hipStream_t stream);
+// Flag-DiT eol variant handled by engine with the same kernel + a row fill (later round)
+// sinusoidal timestep features (model.py:63-82): t [B] f32 -> [B, dim] bf16 (cos block then sin block)
+int launch_timestep_features(const float* t, int t_index, u16* out, int B, int dim, hipStream_t stream);
+// masked mean pool + affine LayerNorm (model.py:847-849, cap_embedder.0): -> [B, C] bf16
+int launch_cap_pool_ln(const void* cap, int cap_dtype, const int32_t* mask, const u16* ln_w, const u16* ln_b,
+                       u16* out, int B, int T, int C, hipStream_t stream);
+// c = bfr(a + b) elementwise bf16
+int launch_add_bf16(const u16* a, const u16* b, u16* c, long long n, hipStream_t stream);
+// cap_feats (any dtype) -> bf16 copy, and mask -> additive float bias (0 / -inf), padded to Tpad
+int launch_mask_to_bias(const int32_t* mask, float* bias, int B, int T, int Tpad, hipStream_t stream);
+// final projection rows [B*N, ld] bf16 -> unpatchify (model.py:749-755), keep first C channels,
+// optional CFG combine on cfg_channels (model.py:908-913); out [B,C,H,W] bf16/f32
+int launch_unpatchify_cfg(const u16* rows, int ld, void* out, int out_dtype, int B, int C, int out_ch, int H, int W,
+                          int patch, int use_cfg, float cfg_scale, int cfg_channels, hipStream_t stream);
+// torchdiffeq fixed-grid state arithmetic (modes documented in misc.hip)
+int launch_ode_combine(int mode, const void* y0, const void* k1, const void* k2, const void* k3, const void* k4,
+                       void* out, int dtype, float dt, long long n, hipStream_t stream);
+// weight upload: cast rows of src [rows, cols] to bf16 at dst rows (row_map 0: r0 + r; 1/2: w1/w3 slots of
+// the 32-row interleaved SwiGLU layout), row stride dst_ld (>= cols; padding left untouched)
+int launch_upload_rows(const void* src, int dtype, u16* dst, int rows, int cols, int dst_ld, int r0, int row_map,
+                       hipStream_t stream);
+int launch_rope_table_2d(float* out, int len, int hd, float theta, float scale_factor, hipStream_t stream);
+int launch_fill_rows_bf16(u16* dst, const u16* row, long long rows, int d, hipStream_t stream);

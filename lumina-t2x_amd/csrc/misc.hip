@@ -1,0 +1,360 @@
+// Small / HBM-bound kernels around the transformer stack: patchify, timestep features, caption pooling,
+// GEMV-style linears for the conditioning path (M <= 8), unpatchify + classifier-free guidance, the
+// fixed-grid ODE update and weight upload casts.  Each cites the reference lines it restates.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ---- y[m,n] = sum_k act(a[m,k]) w[n,k] + b[n]  (adaLN_modulation model.py:560-569, t_embedder :44-60,
+//      cap_embedder :702-711, final adaLN :646-655).  Weight-bandwidth bound: one wave per output column.
+constexpr int SM_MAXM = 8;
+__global__ __launch_bounds__(256) void linear_small_m_kernel(const u16* __restrict__ a, const u16* __restrict__ w,
+                                                             const u16* __restrict__ bias, u16* __restrict__ y, int M,
+                                                             int N, int K, int act_in) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int nch = K >> 3;
+    float acc[SM_MAXM];
+#pragma unroll
+    for (int m = 0; m < SM_MAXM; ++m) acc[m] = 0.f;
+    const u16* wrow = w + (size_t)n * K;
+    for (int c = lane; c < nch; c += 64) {
+        float wf[8];
+        unpack8(*(const bf8_t*)(wrow + c * 8), wf);
+#pragma unroll
+        for (int m = 0; m < SM_MAXM; ++m) {
+            if (m < M) {
+                float af[8];
+                unpack8(*(const bf8_t*)(a + (size_t)m * K + c * 8), af);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = af[e];
+                    if (act_in == 1) x = bfr(silu_f(x));
+                    acc[m] += x * wf[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < SM_MAXM; ++m) {
+        if (m < M) {
+            float s = wave_sum(acc[m]);
+            if (lane == 0) {
+                if (bias) s += bf2f(bias[n]);
+                y[(size_t)m * N + n] = f2bf(s);
+            }
+        }
+    }
+}
+
+__global__ void cast_to_bf16_kernel(const void* __restrict__ src, int dtype, u16* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (dtype == 0) dst[i] = f2bf(((const float*)src)[i]);
+        else if (dtype == 1) dst[i] = ((const u16*)src)[i];
+        else dst[i] = f2bf((float)((const _Float16*)src)[i]);
+    }
+}
+
+// patchify (model.py:776-777): rows (b, i, j), columns (c, ph, pw); zero padded to kpad
+__global__ void patchify_kernel(const void* __restrict__ x, int x_dtype, u16* __restrict__ out, int B, int C, int H,
+                                int W, int patch, int kpad, int dup_first_half) {
+    const int Hp = H / patch, Wp = W / patch;
+    const long long total = (long long)B * Hp * Wp * kpad;
+    const int kreal = C * patch * patch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % kpad);
+        const long long row = i / kpad;
+        u16 v = 0;
+        if (k < kreal) {
+            const int j = (int)(row % Wp);
+            const int ii = (int)((row / Wp) % Hp);
+            int b = (int)(row / ((long long)Wp * Hp));
+            if (dup_first_half) b = b % (B / 2);  // combined = cat([half, half])  (model.py:901-902)
+            const int c = k / (patch * patch), ph = (k / patch) % patch, pw = k % patch;
+            const size_t idx = (((size_t)b * C + c) * H + (ii * patch + ph)) * W + (j * patch + pw);
+            v = x_dtype == 0 ? f2bf(((const float*)x)[idx]) : ((const u16*)x)[idx];
+        }
+        out[i] = v;
+    }
+}
+
+// timestep_embedding (model.py:63-82): [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / half), cast bf16 (:86)
+__global__ void timestep_features_kernel(const float* __restrict__ t, u16* __restrict__ out, int B, int dim) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, k = i % half;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);
+    const float arg = t[b] * freq;
+    out[(size_t)b * dim + k] = f2bf(cosf(arg));
+    out[(size_t)b * dim + half + k] = f2bf(sinf(arg));
+}
+
+// masked mean over tokens in fp32, cast back to the feature dtype (model.py:847-849), then the affine
+// LayerNorm of cap_embedder[0] (model.py:703; fp32 under autocast), stored bf16 (cast at the Linear).
+__global__ __launch_bounds__(256) void cap_pool_ln_kernel(const void* __restrict__ cap, int cap_dtype,
+                                                          const int32_t* __restrict__ mask, const u16* __restrict__ ln_w,
+                                                          const u16* __restrict__ ln_b, u16* __restrict__ out, int T, int C) {
+    extern __shared__ float sh[];  // pooled[C] + 8 reduction slots
+    float* pooled = sh;
+    float* red = sh + C;
+    const int b = blockIdx.x;
+    float cnt = 0.f;
+    for (int t = 0; t < T; ++t) cnt += (float)mask[b * T + t];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t idx = ((size_t)b * T + t) * C + c;
+            const float v = cap_dtype == 0 ? ((const float*)cap)[idx] : bf2f(((const u16*)cap)[idx]);
+            s += v * (float)mask[b * T + t];
+        }
+        s = s / cnt;
+        pooled[c] = cap_dtype == 0 ? s : bfr(s);
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) s += pooled[c];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float d = pooled[c] - mean;
+        q += d * d;
+    }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)C + 1e-5f);
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        out[(size_t)b * C + c] = f2bf((pooled[c] - mean) * rstd * bf2f(ln_w[c]) + bf2f(ln_b[c]));
+}
+
+__global__ void add_bf16_kernel(const u16* a, const u16* b, u16* c, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+
+__global__ void mask_to_bias_kernel(const int32_t* mask, float* bias, int B, int T, int Tpad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Tpad) return;
+    const int b = i / Tpad, t = i % Tpad;
+    bias[i] = (t < T && mask[b * T + t] != 0) ? 0.f : -INFINITY;
+}
+
+// unpatchify (model.py:749-755: row layout (pH, pW, C_out)), keep the first C channels (:859-861), then
+// CFG on the first cfg_channels channels only (model.py:908-913) with the bf16 rounding of each step.
+__global__ void unpatchify_cfg_kernel(const u16* __restrict__ rows, int ld, void* __restrict__ out, int out_dtype, int B,
+                                      int C, int out_ch, int H, int W, int patch, int use_cfg, float cfg_scale,
+                                      int cfg_channels) {
+    const long long total = (long long)B * C * H * W;
+    const int Wp = W / patch, Hp = H / patch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const int hh = (int)((i / W) % H);
+        const int c = (int)((i / ((long long)W * H)) % C);
+        const int b = (int)(i / ((long long)W * H * C));
+        const int e = ((hh % patch) * patch + (w % patch)) * out_ch + c;
+        const long long tok = (long long)(hh / patch) * Wp + (w / patch);
+        auto rd = [&](int bb) { return bf2f(rows[((long long)bb * Hp * Wp + tok) * ld + e]); };
+        float v;
+        if (use_cfg && c < cfg_channels) {
+            const int half = B / 2;
+            const int bc = b % half;
+            const float cond = rd(bc), unc = rd(bc + half);
+            v = bfr(unc + bfr(cfg_scale * bfr(cond - unc)));
+        } else {
+            v = rd(b);
+        }
+        if (out_dtype == 0) ((float*)out)[i] = v;
+        else ((u16*)out)[i] = f2bf(v);
+    }
+}
+
+// torchdiffeq fixed-grid solver arithmetic on the ODE state (euler / midpoint / rk4 "3/8 rule",
+// torchdiffeq rk_common.rk4_alt_step_func).  With a bf16 state every tensor op of the Python expression
+// rounds to bf16 (a 0-dim fp32 dt times a bf16 tensor stays bf16 - SURVEY.md 8c); R() marks those points.
+//   mode 0: y0 + R(dt k1)                               euler step, midpoint half step / full step
+//   mode 1: y0 + R(R(dt k1) / 3)                        rk4 stage-2 input
+//   mode 2: y0 + R(dt R(k2 - R(k1 / 3)))                rk4 stage-3 input
+//   mode 3: y0 + R(dt R(R(k1 - k2) + k3))               rk4 stage-4 input
+//   mode 4: y0 + R(R(R(R(k1 + R(3 R(k2 + k3))) + k4) dt) 0.125)
+template <bool BF>
+__global__ void ode_combine_kernel(int mode, const void* y0, const void* k1, const void* k2, const void* k3,
+                                   const void* k4, void* out, float dt, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto ld = [&](const void* p) { return BF ? bf2f(((const u16*)p)[i]) : ((const float*)p)[i]; };
+    auto R = [](float x) { return BF ? bfr(x) : x; };
+    const float y = ld(y0);
+    float r;
+    if (mode == 0) r = y + R(dt * ld(k1));
+    else if (mode == 1) r = y + R(R(dt * ld(k1)) * (1.0f / 3.0f));
+    else if (mode == 2) r = y + R(dt * R(ld(k2) - R(ld(k1) * (1.0f / 3.0f))));
+    else if (mode == 3) r = y + R(dt * R(R(ld(k1) - ld(k2)) + ld(k3)));
+    else r = y + R(R(R(R(ld(k1) + R(3.0f * R(ld(k2) + ld(k3)))) + ld(k4)) * dt) * 0.125f);
+    if (BF) ((u16*)out)[i] = f2bf(r);
+    else ((float*)out)[i] = r;
+}
+
+// precompute_freqs_cis (model.py:915-963) reduced to its two 1-D factors: out[branch][pos][fi] = cis(pos f_fi)
+__global__ void rope_table_2d_kernel(float* out, int len, int hd, float theta, float scale_factor) {
+    const int nf = hd / 4;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * len * nf) return;
+    const int fi = i % nf, pos = (i / nf) % len, branch = i / (nf * len);
+    const float lin = branch == 0 ? scale_factor : 1.0f;
+    const float ntk = branch == 0 ? 1.0f : scale_factor;
+    const float th = theta * ntk;
+    const float freq = 1.0f / powf(th, (float)(4 * fi) / (float)hd) / lin;
+    const float ang = (float)pos * freq;
+    out[2 * (size_t)i] = cosf(ang);
+    out[2 * (size_t)i + 1] = sinf(ang);
+}
+
+__global__ void fill_rows_bf16_kernel(u16* dst, const u16* row, long long rows, int d) {
+    const long long total = rows * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = row[i % d];
+}
+
+inline int nblk(long long n, int bs) { return (int)((n + bs - 1) / bs); }
+
+}  // namespace
+
+int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int M, int N, int K, int act_in,
+                          hipStream_t stream) {
+    LT_REQUIRE(M >= 1 && M <= SM_MAXM, "linear_small_m: M=%d out of range 1..%d", M, SM_MAXM);
+    LT_REQUIRE(K % 8 == 0, "linear_small_m: K=%d must be a multiple of 8", K);
+    hipLaunchKernelGGL(linear_small_m_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, a, w, b, y, M, N, K, act_in);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_cast_to_bf16(const void* src, int dtype, u16* dst, long long n, hipStream_t stream) {
+    LT_REQUIRE(dtype >= 0 && dtype <= 2, "cast_to_bf16: bad dtype %d", dtype);
+    if (n == 0) return 0;
+    int g = nblk(n, 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(cast_to_bf16_kernel, dim3(g), dim3(256), 0, stream, src, dtype, dst, n);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_patchify(const void* x, int x_dtype, u16* out, int B, int C, int H, int W, int patch, int kpad,
+                    int dup_first_half, hipStream_t stream) {
+    LT_REQUIRE(H % patch == 0 && W % patch == 0, "patchify: %dx%d not divisible by patch %d", H, W, patch);
+    LT_REQUIRE(C * patch * patch <= kpad, "patchify: kpad too small");
+    LT_REQUIRE(!dup_first_half || B % 2 == 0, "patchify: CFG needs an even batch");
+    const long long total = (long long)B * (H / patch) * (W / patch) * kpad;
+    int g = nblk(total, 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(patchify_kernel, dim3(g), dim3(256), 0, stream, x, x_dtype, out, B, C, H, W, patch, kpad,
+                       dup_first_half);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_timestep_features(const float* t, int t_index, u16* out, int B, int dim, hipStream_t stream) {
+    LT_REQUIRE(dim % 2 == 0, "timestep_features: odd dim unsupported");
+    hipLaunchKernelGGL(timestep_features_kernel, dim3(nblk((long long)B * dim / 2, 128)), dim3(128), 0, stream,
+                       t + (size_t)t_index * B, out, B, dim);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_cap_pool_ln(const void* cap, int cap_dtype, const int32_t* mask, const u16* ln_w, const u16* ln_b, u16* out,
+                       int B, int T, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(cap_pool_ln_kernel, dim3(B), dim3(256), (C + 8) * sizeof(float), stream, cap, cap_dtype, mask,
+                       ln_w, ln_b, out, T, C);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_add_bf16(const u16* a, const u16* b, u16* c, long long n, hipStream_t stream) {
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(nblk(n, 256)), dim3(256), 0, stream, a, b, c, n);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_mask_to_bias(const int32_t* mask, float* bias, int B, int T, int Tpad, hipStream_t stream) {
+    hipLaunchKernelGGL(mask_to_bias_kernel, dim3(nblk((long long)B * Tpad, 256)), dim3(256), 0, stream, mask, bias, B,
+                       T, Tpad);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_unpatchify_cfg(const u16* rows, int ld, void* out, int out_dtype, int B, int C, int out_ch, int H, int W,
+                          int patch, int use_cfg, float cfg_scale, int cfg_channels, hipStream_t stream) {
+    LT_REQUIRE(!use_cfg || B % 2 == 0, "unpatchify_cfg: CFG needs an even batch");
+    const long long total = (long long)B * C * H * W;
+    int g = nblk(total, 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(unpatchify_cfg_kernel, dim3(g), dim3(256), 0, stream, rows, ld, out, out_dtype, B, C, out_ch, H,
+                       W, patch, use_cfg, cfg_scale, cfg_channels);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_ode_combine(int mode, const void* y0, const void* k1, const void* k2, const void* k3, const void* k4,
+                       void* out, int dtype, float dt, long long n, hipStream_t stream) {
+    LT_REQUIRE(mode >= 0 && mode <= 4, "ode_combine: bad mode %d", mode);
+    LT_REQUIRE(dtype == 0 || dtype == 1, "ode_combine: state dtype must be f32 or bf16");
+    if (dtype == 1)
+        hipLaunchKernelGGL(ode_combine_kernel<true>, dim3(nblk(n, 256)), dim3(256), 0, stream, mode, y0, k1, k2, k3, k4, out, dt, n);
+    else
+        hipLaunchKernelGGL(ode_combine_kernel<false>, dim3(nblk(n, 256)), dim3(256), 0, stream, mode, y0, k1, k2, k3, k4, out, dt, n);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_rope_table_2d(float* out, int len, int hd, float theta, float scale_factor, hipStream_t stream) {
+    LT_REQUIRE(hd % 4 == 0, "rope_table_2d: hd %% 4 != 0");
+    hipLaunchKernelGGL(rope_table_2d_kernel, dim3(nblk(2LL * len * (hd / 4), 256)), dim3(256), 0, stream, out, len, hd,
+                       theta, scale_factor);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_fill_rows_bf16(u16* dst, const u16* row, long long rows, int d, hipStream_t stream) {
+    int g = nblk(rows * d, 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(fill_rows_bf16_kernel, dim3(g), dim3(256), 0, stream, dst, row, rows, d);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+namespace {
+__global__ void upload_rows_kernel(const void* __restrict__ src, int dtype, u16* __restrict__ dst, int rows, int cols,
+                                   int dst_ld, int r0, int row_map) {
+    const long long total = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        int dr;
+        if (row_map == 0) dr = r0 + r;
+        else dr = (r >> 5) * 64 + (r & 31) + (row_map == 2 ? 32 : 0);
+        u16 v;
+        if (dtype == 0) v = f2bf(((const float*)src)[i]);
+        else if (dtype == 1) v = ((const u16*)src)[i];
+        else v = f2bf((float)((const _Float16*)src)[i]);
+        dst[(size_t)dr * dst_ld + c] = v;
+    }
+}
+}  // namespace
+
+int launch_upload_rows(const void* src, int dtype, u16* dst, int rows, int cols, int dst_ld, int r0, int row_map,
+                       hipStream_t stream) {
+    LT_REQUIRE(dtype >= 0 && dtype <= 2, "upload_rows: bad dtype %d", dtype);
+    LT_REQUIRE(row_map == 0 || rows % 32 == 0, "upload_rows: interleaved layout needs rows %% 32 == 0");
+    const long long total = (long long)rows * cols;
+    if (total == 0) return 0;
+    long long g = (total + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(upload_rows_kernel, dim3((int)g), dim3(256), 0, stream, src, dtype, dst, rows, cols, dst_ld, r0, row_map);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}

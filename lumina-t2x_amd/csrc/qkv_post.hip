@@ -1,0 +1,167 @@
+// q/k/v post-processing between the fused QKV GEMM and the attention kernel.
+//
+//  qk_norm_rope : full-width affine LayerNorm (the reference's "qk_norm", model.py:211-215, :361-362;
+//                 fp32 under autocast) -> rotary embedding in fp32 (model.py:254-282; table layout
+//                 model.py:915-963: complex slot 2i rotates with the ROW position, slot 2i+1 with the
+//                 COLUMN position, both at frequency i) -> one bf16 rounding (model.py:371) -> head-major
+//                 [B, heads, N, hd] so an attention K tile is one contiguous 64*hd*2-byte run.
+//                 The 42 MB complex table the reference rebuilds on every call (model.py:883-889) is
+//                 replaced by a [pos][hd/4] (cos,sin) table per branch; the watershed branch is picked
+//                 on the device from t[0] (no .item() sync).
+//  v_transpose  : V -> [B, kvh, hd, Npad] with keys permuted inside each group of 16 (quads 1 and 2
+//                 swapped) - exactly the order in which a lane of the swapped QK^T MFMA holds its P
+//                 values, so the PV MFMA needs no cross-lane exchange (see attention.hip).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXCH = 8;
+
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkPostArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rows = p.B * p.N;
+    if (row >= rows) return;
+    const int b = row / p.N, n = row - b * p.N;
+    const int width = p.heads * p.hd;
+    const int nch = width >> 3;
+    const int cph = p.hd >> 3;  // chunks per head
+    const u16* src = p.src + (size_t)row * p.ld_src + p.col0;
+
+    float v[MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            unpack8(*(const bf8_t*)(src + c * 8), v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (p.ln_w) {
+        mean = wave_sum(s) / (float)width;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[i][e] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        rstd = rsqrtf(wave_sum(q) / (float)width + p.ln_eps);
+    }
+
+    // rotary table: branch 0 = linear interpolation (t < watershed), branch 1 = NTK (model.py:944-949)
+    int branch = 1;
+    if (p.t) branch = (p.t[0] < p.watershed) ? 0 : 1;
+    const int nfreq = (p.rope_mode == 1) ? (p.hd >> 2) : (p.hd >> 1);
+    const float* cs = p.cs ? p.cs + (size_t)branch * p.cs_len * nfreq * 2 : nullptr;
+    const int gr = n / p.grid_w, gc = n - gr * p.grid_w;
+
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const int head = c / cph, ci = c - head * cph;
+            float y[8];
+            if (p.ln_w) {
+                float wf[8], bf[8];
+                unpack8(*(const bf8_t*)(p.ln_w + c * 8), wf);
+                unpack8(*(const bf8_t*)(p.ln_b + c * 8), bf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (v[i][e] - mean) * rstd * wf[e] + bf[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = v[i][e];
+            }
+            float o[8];
+            if (p.rope_mode == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = y[e];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pr = 4 * ci + j;  // complex slot inside the head
+                    int pos, fi;
+                    if (p.rope_mode == 1) { fi = pr >> 1; pos = (pr & 1) ? gc : gr; }
+                    else { fi = pr; pos = n; }
+                    const float2 t = *(const float2*)(cs + ((size_t)pos * nfreq + fi) * 2);
+                    o[2 * j] = y[2 * j] * t.x - y[2 * j + 1] * t.y;
+                    o[2 * j + 1] = y[2 * j] * t.y + y[2 * j + 1] * t.x;
+                }
+            }
+            u16* dst = p.dst + (((size_t)b * p.heads + head) * p.N + n) * p.hd + ci * 8;
+            *(bf8_t*)dst = pack8(o);
+        }
+    }
+}
+
+// one block per (64-key tile, kv head, batch): V rows -> LDS (transposed, permuted) -> 128-byte rows
+__global__ __launch_bounds__(256) void v_transpose_kernel(const u16* __restrict__ src, int ld_src, int col0,
+                                                          u16* __restrict__ dst, int N, int Npad, int kv_heads,
+                                                          int hd) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    u16* T = (u16*)smem_raw;  // [hd][72] (row stride 144 B: 16-B aligned, spreads banks)
+    constexpr int LDT = 72;
+    const int n0 = blockIdx.x * 64, kvh = blockIdx.y, b = blockIdx.z;
+    const int cph = hd >> 3;
+    const int nin = 64 * cph;
+    for (int id = threadIdx.x; id < nin; id += 256) {
+        const int tok = id / cph, ci = id - tok * cph;
+        const int n = n0 + tok;
+        bf8_t t;
+        if (n < N) t = *(const bf8_t*)(src + ((size_t)b * N + n) * ld_src + col0 + kvh * hd + ci * 8);
+        else { t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0u; }
+        // key position inside its group of 16: swap bit 2 and bit 3
+        const int tp = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            T[(ci * 8 + 2 * e) * LDT + tp] = (u16)(t.w[e] & 0xffffu);
+            T[(ci * 8 + 2 * e + 1) * LDT + tp] = (u16)(t.w[e] >> 16);
+        }
+    }
+    __syncthreads();
+    const int nout = hd * 8;
+    for (int id = threadIdx.x; id < nout; id += 256) {
+        const int d = id >> 3, c = id & 7;
+        const bf8_t t = *(const bf8_t*)(T + d * LDT + c * 8);
+        *(bf8_t*)(dst + (((size_t)b * kv_heads + kvh) * hd + d) * Npad + n0 + c * 8) = t;
+    }
+}
+
+}  // namespace
+
+int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
+    const int width = a.heads * a.hd;
+    LT_REQUIRE(a.hd % 8 == 0 && width <= 64 * 8 * MAXCH, "qk_norm_rope: hd %% 8 == 0 and heads*hd <= 4096 required (got %d x %d)", a.heads, a.hd);
+    LT_REQUIRE(a.ld_src % 8 == 0 && a.col0 % 8 == 0, "qk_norm_rope: ld_src/col0 must be multiples of 8");
+    LT_REQUIRE(a.rope_mode == 0 || a.cs != nullptr, "qk_norm_rope: rotary table missing");
+    LT_REQUIRE(a.rope_mode != 1 || (a.hd % 4 == 0 && a.grid_w > 0), "qk_norm_rope: 2-D rope needs hd %% 4 == 0");
+    LT_REQUIRE((a.ln_w == nullptr) == (a.ln_b == nullptr), "qk_norm_rope: LayerNorm weight and bias must come together");
+    const int rows = a.B * a.N;
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_v_transpose(const u16* src, int ld_src, int col0, u16* dst, int B, int N, int Npad, int kv_heads, int hd,
+                       hipStream_t stream) {
+    LT_REQUIRE(hd % 8 == 0 && hd <= 128, "v_transpose: hd=%d unsupported", hd);
+    LT_REQUIRE(Npad % 64 == 0 && Npad >= N, "v_transpose: Npad=%d must be a multiple of 64 and >= N=%d", Npad, N);
+    LT_REQUIRE(ld_src % 8 == 0 && col0 % 8 == 0, "v_transpose: ld_src/col0 must be multiples of 8");
+    dim3 grid(Npad / 64, kv_heads, B);
+    hipLaunchKernelGGL(v_transpose_kernel, grid, dim3(256), hd * 72 * 2, stream, src, ld_src, col0, dst, N, Npad,
+                       kv_heads, hd);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
