@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoising-step throughput of Next-DiT 2B (Lumina-Next, BASELINE.json configs[1]) at
+1024x1024 with classifier-free guidance, flow-matching Euler ODE, bf16, synthetic data / random-init weights.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one denoising step = one ``forward_with_cfg`` (NFE) on a cond+uncond pair plus the Euler update,
+driven exactly as a user would: ``Sampler(transport).sample_ode(...)(z, model.forward_with_cfg, **kwargs)``.
+Each rank denoises ONE image (weak scaling: images shard over GPUs, no data-path collective; the text
+features are broadcast once from rank 0 over RCCL before the timed region).  Inputs are resident in HBM when
+the timed region starts.  Rank 0 prints one JSON line; ``value`` is whole-job latent-tokens/s
+(images x 4096 latent tokens x NFE / wall), ``denoising_steps_per_s`` the same in NFE/s.
+
+``roofline`` is measured live with HIP events around every launch of the dominant kernel (the bf16 MFMA GEMM,
+76 % of the algorithmic FLOPs) on the launch stream; ``cpu_baseline`` times the CPU oracle (fp32, all host
+cores) on a bounded sample: a full-width forward_with_cfg with 2 of the 24 layers, scaled to 24.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import lumina_t2x_amd  # noqa: E402,F401
+from lumina_t2x_amd import models, parallel  # noqa: E402
+from lumina_t2x_amd.transport import Sampler, create_transport  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
+RES = 1024
+LATENT = RES // 8            # 128
+N_TOKENS = (LATENT // 2) ** 2  # 4096
+TEXT_LEN = 128
+
+
+def random_init_(model, seed):
+    """Random-init weights of the named architecture directly on the GPU.  The reference zero-inits the adaLN /
+    final / cap-embedder / gate paths (model.py:567,643,652,709,201), which would turn every block into an
+    identity; give them the SURVEY.md 8d synthetic statistics instead so the timed work is representative."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("attention.gate"):
+                p.normal_(0.0, 0.5, generator=g)
+            elif p.dim() == 1 and name.endswith(".weight"):
+                p.copy_(1.0 + 0.02 * torch.randn(p.shape, device=p.device, generator=g))
+            elif p.dim() == 1:
+                p.normal_(0.0, 0.02, generator=g)
+            else:
+                p.normal_(0.0, min(0.06, p.shape[-1] ** -0.5), generator=g)
+
+
+def cpu_baseline(n_sample_layers=2):
+    """Oracle (CPU restatement of the reference forward, fp32, all host cores) on a bounded sample."""
+    from oracle import nextdit_oracle as O
+    from oracle import synth
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = synth.NextDiTConfig(n_layers=n_sample_layers)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    z, t, cap, mask = synth.synth_inputs(cfg, latent_hw=(LATENT, LATENT), text_len=TEXT_LEN, uncond_len=8, seed=1)
+    kw = dict(cfg_scale=4.0, proportional_attn=True, base_seqlen=N_TOKENS)
+    t0 = time.time()
+    O.forward_with_cfg(sd, cfg, z, t, cap, mask, n_layers=0, **kw)
+    t_fixed = time.time() - t0
+    t0 = time.time()
+    O.forward_with_cfg(sd, cfg, z, t, cap, mask, **kw)
+    t_sample = time.time() - t0
+    per_layer = max(t_sample - t_fixed, 1e-9) / n_sample_layers
+    t_nfe = t_fixed + 24 * per_layer
+    return {
+        "value": N_TOKENS / t_nfe, "unit": "latent-tokens/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle fp32 forward_with_cfg at full width (d=2304, N=4096, T=128, B=2) with {n_sample_layers} of 24 "
+                   f"layers: {t_sample:.1f} s; embed/final part {t_fixed:.2f} s; extrapolated to 24 layers = {t_nfe:.1f} s per NFE"),
+        "denoising_steps_per_s": 1.0 / t_nfe,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=29, help="timed denoising steps (NFE); 29 = one 30-point Euler grid")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gqa", action="store_true", help="NextDiT_2B_GQA_patch2 instead of the MHA model")
+    args = ap.parse_args()
+
+    rank, world, local = parallel.init_distributed("nccl" if args.gpus > 1 else None)
+    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(0)
+
+    with torch.device(dev):
+        ctor = models.NextDiT_2B_GQA_patch2 if args.gqa else models.NextDiT_2B_patch2
+        model = ctor(qk_norm=True, cap_feat_dim=2048).to(torch.bfloat16)
+    random_init_(model, seed=0)
+    model.eval()
+
+    # text features: rank 0 "runs the text encoder" (synthetic), one RCCL broadcast, each rank keeps its image
+    n_img = world
+    feats = mask = None
+    if rank == 0:
+        g = torch.Generator(device="cuda").manual_seed(1)
+        feats = torch.randn(n_img, 2, TEXT_LEN, 2048, device=dev, generator=g).to(torch.bfloat16)
+        mask = torch.ones(n_img, 2, TEXT_LEN, dtype=torch.int32, device=dev)
+        mask[:, 1, 8:] = 0  # empty prompt: BOS + padding (sample.py:38)
+    feats, mask = parallel.broadcast_prompts(feats, mask, src=0, device=dev)
+    mine = parallel.shard_range(n_img, rank, world)[0]
+    cap_feats, cap_mask = feats[mine].contiguous(), mask[mine].contiguous()
+
+    g = torch.Generator(device="cuda").manual_seed(100 + mine)
+    z = torch.randn(1, 4, LATENT, LATENT, device=dev, generator=g).to(torch.bfloat16).repeat(2, 1, 1, 1)
+    kw = dict(cap_feats=cap_feats, cap_mask=cap_mask, cfg_scale=4.0, proportional_attn=True, base_seqlen=(RES // 16) ** 2,
+              scale_factor=1.0, scale_watershed=1.0)
+    transport = create_transport("Linear", "velocity", None, None, None)
+
+    def run(nfe):
+        fn = Sampler(transport).sample_ode(sampling_method="euler", num_steps=nfe + 1, time_shifting_factor=4)
+        return fn(z, model.forward_with_cfg, **kw)
+
+    if args.warmup > 0:
+        run(args.warmup)
+    torch.cuda.synchronize()
+    eng = model._engine
+    eng.profile_enable(True)
+    eng.profile_reset()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    traj = run(args.steps)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt, dev)
+    eng.profile_enable(False)
+    assert eng.last_nfe() == args.steps
+    assert torch.isfinite(traj[-1].float()).all(), "non-finite latent"
+
+    if rank == 0:
+        from oracle.nextdit_oracle import flops_per_nfe
+        from oracle.synth import NEXT_2B, NextDiTConfig
+
+        cfgm = NextDiTConfig(n_kv_heads=8) if args.gqa else NEXT_2B
+        nfe_flops = flops_per_nfe(cfgm, N_TOKENS, TEXT_LEN, 2)
+        gemm_ms, gemm_n, gemm_fl = eng.profile_read(0)
+        attn_ms, attn_n, attn_fl = eng.profile_read(1)
+        oth_ms, oth_n, _ = eng.profile_read(2)
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "denoising-steps/s & latent-tokens/s, Next-DiT 2B 1024^2 CFG",
+            "value": world * N_TOKENS * args.steps / dt,
+            "unit": "latent-tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[1]: Lumina-Next-T2I 2B (NextDiT_2B_%spatch2, d2304 L24 H32 hd72 F6144), "
+                                    "1024x1024 (4096 latent tokens), text T=128, CFG=4 (cond+uncond B=2), proportional attention, "
+                                    "flow-matching Euler ODE t_shift 4, 1 image per GPU" % ("GQA_" if args.gqa else "")),
+                       "images_per_gpu": 1, "nfe_timed": args.steps, "parallelism": f"images sharded x{world}, weights replicated"},
+            "denoising_steps_per_s": world * args.steps / dt,
+            "model_tflops_per_s_per_gpu": nfe_flops * args.steps / dt / 1e12,
+            "mfma_roofline_frac_whole_step": nfe_flops * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "roofline": {
+                "bound": "mfma", "kernel": "gemm_bf16_tn_256 (all GEMM launches of the timed region)",
+                "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                "algorithmic_flops_per_launch": gemm_fl / max(gemm_n, 1),
+            },
+            "kernel_time_ms_per_step": {"gemm": gemm_ms / args.steps, "attention": attn_ms / args.steps,
+                                        "other": oth_ms / args.steps},
+            "attention_tflops_per_s": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

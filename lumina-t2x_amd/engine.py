@@ -1,0 +1,196 @@
+"""Thin PyTorch-side plumbing around the C-ABI engine: tensors in, tensors out, current HIP stream.
+
+PyTorch only supplies device memory, streams and (elsewhere) ``torch.distributed``; every FLOP of the
+denoising path runs in the HIP kernels behind ``liblumina_dit.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import LtConfig, LtStepArgs, LuminaLibError
+
+_DT = {torch.float32: _lib.LT_F32, torch.bfloat16: _lib.LT_BF16, torch.float16: _lib.LT_F16}
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise LuminaLibError(
+            f"{name} lives on {t.device}; the MI355X denoising engine only runs on a ROCm device "
+            "(there is no CPU fallback - use oracle/ for CPU reference numbers in tests)"
+        )
+
+
+@dataclass
+class EngineLimits:
+    max_batch: int = 2
+    max_tokens: int = 4096
+    max_text: int = 256
+
+
+class DiTEngine:
+    """Owns one ``lt_engine`` handle (weights arena + workspace in HBM) for one model on one GPU."""
+
+    def __init__(self, *, variant: int, dim: int, n_layers: int, n_heads: int, n_kv_heads: int, ffn_hidden: int,
+                 patch_size: int, in_channels: int, out_channels: int, cap_feat_dim: int, qk_norm: bool,
+                 norm_eps: float, num_classes: int = 0, limits: Optional[EngineLimits] = None,
+                 device: Optional[torch.device] = None):
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda")
+        if not torch.cuda.is_available():
+            raise LuminaLibError("no ROCm device visible: the denoising engine cannot run (no CPU fallback)")
+        lim = limits or EngineLimits()
+        self.limits = lim
+        cfg = LtConfig(
+            variant=variant, dim=dim, n_layers=n_layers, n_heads=n_heads, n_kv_heads=n_kv_heads,
+            ffn_hidden=ffn_hidden, patch_size=patch_size, in_channels=in_channels, out_channels=out_channels,
+            cap_feat_dim=cap_feat_dim, adaln_dim=min(dim, 1024), qk_norm=int(bool(qk_norm)), num_classes=num_classes,
+            norm_eps=norm_eps, max_batch=lim.max_batch, max_tokens=lim.max_tokens, max_text=lim.max_text,
+            rope_table_len=384,
+        )
+        self.cfg = cfg
+        self.in_channels = in_channels
+        self.patch_size = patch_size
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.lt_create(C.byref(cfg), C.byref(handle)), "lt_create")
+        self.handle = handle
+        self._prompt_key = None
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                self.lib.lt_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def load_state_dict(self, state: Dict[str, torch.Tensor], skip: Iterable[str] = ()) -> None:
+        """Upload every tensor of a reference-format state_dict into the engine."""
+        s = _stream_ptr(self.device)
+        skip = set(skip)
+        with torch.cuda.device(self.device):
+            for key, t in state.items():
+                if key in skip:
+                    continue
+                t = t.detach()
+                if t.device != self.device or t.dtype not in _DT or not t.is_contiguous():
+                    dt = t.dtype if t.dtype in _DT else torch.float32
+                    t = t.to(device=self.device, dtype=dt).contiguous()
+                shape = (C.c_int64 * max(t.dim(), 1))(*(t.shape if t.dim() else (1,)))
+                rc = self.lib.lt_set_weight(self.handle, key.encode(), C.c_void_p(t.data_ptr()), _DT[t.dtype], shape,
+                                            max(t.dim(), 1), C.c_void_p(s))
+                _lib.check(rc, f"lt_set_weight({key})")
+            torch.cuda.current_stream(self.device).synchronize()  # sources may be temporaries
+            _lib.check(self.lib.lt_weights_ready(self.handle), "lt_weights_ready")
+
+    # ---- prompt ----------------------------------------------------------------------------------
+    def prepare_prompt(self, cap_feats: torch.Tensor, cap_mask: torch.Tensor) -> None:
+        _require_gpu(cap_feats, "cap_feats")
+        key = (cap_feats.data_ptr(), cap_feats._version, tuple(cap_feats.shape), cap_feats.dtype,
+               cap_mask.data_ptr(), cap_mask._version)
+        if key == self._prompt_key:
+            return
+        feats = cap_feats if cap_feats.dtype in (torch.float32, torch.bfloat16) else cap_feats.float()
+        feats = feats.contiguous()
+        mask = cap_mask.to(device=feats.device, dtype=torch.int32).contiguous()
+        B, T, _ = feats.shape
+        with torch.cuda.device(self.device):
+            rc = self.lib.lt_prepare_prompt(self.handle, C.c_void_p(feats.data_ptr()), _DT[feats.dtype],
+                                            C.c_void_p(mask.data_ptr()), B, T, C.c_void_p(_stream_ptr(self.device)))
+        _lib.check(rc, "lt_prepare_prompt")
+        self._keep = (feats, mask)  # keep the temporaries alive until the stream has consumed them
+        self._prompt_key = key
+
+    # ---- one model evaluation --------------------------------------------------------------------
+    def _step_args(self, x: torch.Tensor, cfg_scale: float, scale_factor: float, scale_watershed: float,
+                   base_seqlen: Optional[int], proportional_attn: bool, cfg_channels: int = 3) -> LtStepArgs:
+        B, Cc, H, W = x.shape
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise LuminaLibError(f"state dtype {x.dtype} unsupported (bf16 or fp32)")
+        return LtStepArgs(cfg_scale=float(cfg_scale), scale_factor=float(scale_factor),
+                          scale_watershed=float(scale_watershed), base_seqlen=int(base_seqlen or 0),
+                          proportional_attn=int(bool(proportional_attn)), latent_h=H, latent_w=W, batch=B,
+                          io_dtype=_DT[x.dtype], cfg_channels=cfg_channels)
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, *, use_cfg: bool, cfg_scale: float = 1.0,
+                scale_factor: float = 1.0, scale_watershed: float = 1.0, base_seqlen: Optional[int] = None,
+                proportional_attn: bool = False) -> torch.Tensor:
+        _require_gpu(x, "x")
+        x = x.contiguous()
+        t32 = t.to(device=x.device, dtype=torch.float32).contiguous()
+        out = torch.empty_like(x)
+        a = self._step_args(x, cfg_scale, scale_factor, scale_watershed, base_seqlen, proportional_attn)
+        fn = self.lib.lt_forward_cfg if use_cfg else self.lib.lt_forward
+        with torch.cuda.device(self.device):
+            rc = fn(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(t32.data_ptr()), C.c_void_p(out.data_ptr()),
+                    C.byref(a), C.c_void_p(_stream_ptr(self.device)))
+        _lib.check(rc, "lt_forward_cfg" if use_cfg else "lt_forward")
+        return out
+
+    # ---- whole trajectory -------------------------------------------------------------------------
+    def sample_ode(self, z: torch.Tensor, tgrid: torch.Tensor, method: str, *, use_cfg: bool, cfg_scale: float = 1.0,
+                   scale_factor: float = 1.0, scale_watershed: float = 1.0, base_seqlen: Optional[int] = None,
+                   proportional_attn: bool = False, t_round_to_state_dtype: bool = True,
+                   return_trajectory: bool = True) -> torch.Tensor:
+        _require_gpu(z, "z")
+        if method not in _lib.ODE_METHODS:
+            raise LuminaLibError(f"fixed-grid method '{method}' not in {sorted(_lib.ODE_METHODS)}")
+        z = z.contiguous()
+        grid = [float(v) for v in tgrid.detach().to("cpu", torch.float32).tolist()]
+        n = len(grid)
+        garr = (C.c_float * n)(*grid)
+        a = self._step_args(z, cfg_scale, scale_factor, scale_watershed, base_seqlen, proportional_attn)
+        if return_trajectory:
+            out = torch.empty((n,) + tuple(z.shape), dtype=z.dtype, device=z.device)
+            traj_ptr, fin_ptr = C.c_void_p(out.data_ptr()), C.c_void_p(0)
+        else:
+            out = torch.empty_like(z)
+            traj_ptr, fin_ptr = C.c_void_p(0), C.c_void_p(out.data_ptr())
+        with torch.cuda.device(self.device):
+            rc = self.lib.lt_sample_ode(self.handle, C.c_void_p(z.data_ptr()), traj_ptr, fin_ptr, garr, n,
+                                        _lib.ODE_METHODS[method], int(use_cfg), int(t_round_to_state_dtype), C.byref(a),
+                                        C.c_void_p(_stream_ptr(self.device)))
+        _lib.check(rc, "lt_sample_ode")
+        return out
+
+    def last_nfe(self) -> int:
+        return int(self.lib.lt_last_nfe(self.handle))
+
+    # ---- profiling hooks used by bench.py -----------------------------------------------------------
+    def profile_enable(self, on: bool) -> None:
+        _lib.check(self.lib.lt_profile_enable(self.handle, int(on)), "lt_profile_enable")
+
+    def profile_reset(self) -> None:
+        _lib.check(self.lib.lt_profile_reset(self.handle), "lt_profile_reset")
+
+    def profile_read(self, klass: int) -> Tuple[float, int, float]:
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        _lib.check(self.lib.lt_profile_read(self.handle, klass, C.byref(ms), C.byref(n), C.byref(fl)), "lt_profile_read")
+        return ms.value, n.value, fl.value
+
+
+def ffn_hidden_dim(dim: int, multiple_of: int, ffn_dim_multiplier: Optional[float]) -> int:
+    """FeedForward hidden width rule of the reference (lumina_next_t2i/models/model.py:469-473)."""
+    hidden = int(2 * (4 * dim) / 3)
+    if ffn_dim_multiplier is not None:
+        hidden = int(ffn_dim_multiplier * hidden)
+    return multiple_of * ((hidden + multiple_of - 1) // multiple_of)
+
+
+def softmax_scale(seqlen: int, head_dim: int, proportional_attn: bool, base_seqlen: Optional[int]) -> float:
+    """model.py:373-376"""
+    if proportional_attn:
+        return math.sqrt(math.log(seqlen, base_seqlen) / head_dim)
+    return math.sqrt(1 / head_dim)

@@ -1,0 +1,99 @@
+"""One-process-per-GPU batch sharding for sampling (new functionality: every reference sampler asserts
+``num_gpus == 1`` - lumina_next_t2i/sample.py:339).
+
+Each image's ODE trajectory is independent, so images are partitioned over ranks and the only data-path
+exchange is ONE broadcast of the text features (``cap_feats [n_img*2, T, C]`` + mask, <= a few MB) from
+the rank that ran the text encoder, plus an optional gather of the final latents.  On ROCm the "nccl"
+backend is RCCL; a root->peers broadcast of this size is latency bound on the direct xGMI links, so no
+bucketing / ring tuning applies.  The same code runs on CPU with the gloo backend (tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the default group if world > 1."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """contiguous, balanced partition: the first n_items % world ranks get one extra item"""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def broadcast_prompts(cap_feats: Optional[torch.Tensor], cap_mask: Optional[torch.Tensor], *, src: int = 0,
+                      device: Optional[torch.device] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rank ``src`` holds cap_feats [n_img, 2, T, C] (cond, uncond per image) and cap_mask [n_img, 2, T]; every
+    rank returns the full tensors.  Shapes/dtype travel first as a tiny int64 header."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return cap_feats, cap_mask
+    rank = dist.get_rank()
+    dev = device or (cap_feats.device if cap_feats is not None else
+                     (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")))
+    dtypes = [torch.float32, torch.bfloat16, torch.float16]
+    if rank == src:
+        hdr = torch.tensor(list(cap_feats.shape) + [dtypes.index(cap_feats.dtype)], dtype=torch.int64, device=dev)
+    else:
+        hdr = torch.zeros(5, dtype=torch.int64, device=dev)
+    dist.broadcast(hdr, src)
+    n, two, T, C, di = (int(v) for v in hdr.tolist())
+    if rank != src:
+        cap_feats = torch.empty(n, two, T, C, dtype=dtypes[di], device=dev)
+        cap_mask = torch.empty(n, two, T, dtype=torch.int32, device=dev)
+    else:
+        cap_feats = cap_feats.to(dev).contiguous()
+        cap_mask = cap_mask.to(device=dev, dtype=torch.int32).contiguous()
+    dist.broadcast(cap_feats, src)
+    dist.broadcast(cap_mask, src)
+    return cap_feats, cap_mask
+
+
+def gather_latents(local: torch.Tensor, n_items: int, *, dst: int = 0) -> Optional[torch.Tensor]:
+    """inverse of shard_range: rank ``dst`` gets [n_items, ...] in item order, others None"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    counts = [len(shard_range(n_items, r, world)) for r in range(world)]
+    cap = max(counts)
+    pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs: Optional[List[torch.Tensor]] = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def max_over_ranks(value: float, device: torch.device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

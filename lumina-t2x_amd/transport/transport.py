@@ -1,0 +1,215 @@
+"""Transport (flow matching) object and sampler factories - API mirror of
+``lumina_next_t2i/transport/transport.py`` (Transport :41-219, Sampler :221-450).
+"""
+import enum
+import math
+
+import torch as th
+
+from . import path
+from .integrators import ode, sde
+from .utils import mean_flat
+
+
+class ModelType(enum.Enum):
+    NOISE = enum.auto()     # model predicts epsilon
+    SCORE = enum.auto()     # model predicts grad log p
+    VELOCITY = enum.auto()  # model predicts v
+
+
+class PathType(enum.Enum):
+    LINEAR = enum.auto()
+    GVP = enum.auto()
+    VP = enum.auto()
+
+
+class WeightType(enum.Enum):
+    NONE = enum.auto()
+    VELOCITY = enum.auto()
+    LIKELIHOOD = enum.auto()
+
+
+_PLANS = {PathType.LINEAR: path.ICPlan, PathType.GVP: path.GVPCPlan, PathType.VP: path.VPCPlan}
+
+
+class Transport:
+    def __init__(self, *, model_type, path_type, loss_type, train_eps, sample_eps, snr_type):
+        self.loss_type = loss_type
+        self.model_type = model_type
+        self.path_sampler = _PLANS[path_type]()
+        self.train_eps, self.sample_eps = train_eps, sample_eps
+        self.snr_type = snr_type
+
+    def prior_logp(self, z):
+        """log N(z; 0, I) per batch row"""
+        n = z[0].numel()
+        return -n / 2.0 * math.log(2 * math.pi) - z.flatten(1).pow(2).sum(dim=1) / 2.0
+
+    def check_interval(self, train_eps, sample_eps, *, diffusion_form="SBDM", sde=False, reverse=False, eval=False,
+                       last_step_size=0.0):
+        """integration interval (t0, t1); reference transport.py:67-93"""
+        t0, t1 = 0, 1
+        eps = sample_eps if eval else train_eps
+        plan = type(self.path_sampler)
+        tail = 1 - eps if (not sde or last_step_size == 0) else 1 - last_step_size
+        if plan is path.VPCPlan:
+            t1 = tail
+        elif plan in (path.ICPlan, path.GVPCPlan) and (self.model_type != ModelType.VELOCITY or sde):
+            t0 = eps if (diffusion_form == "SBDM" and sde) or self.model_type != ModelType.VELOCITY else 0
+            t1 = tail
+        if reverse:
+            t0, t1 = 1 - t0, 1 - t1
+        return t0, t1
+
+    def sample(self, x1):
+        """draw (t, x0) for training; reference transport.py:95-128"""
+        x0 = [th.randn_like(v) for v in x1] if isinstance(x1, (list, tuple)) else th.randn_like(x1)
+        t0, t1 = self.check_interval(self.train_eps, self.sample_eps)
+        n = len(x1)
+        if self.snr_type.startswith("uniform"):
+            assert t0 == 0.0 and t1 == 1.0, "not implemented."
+            if "_" in self.snr_type:
+                _, a, b = self.snr_type.split("_")
+                t0, t1 = float(a), float(b)
+            t = th.rand((n,)) * (t1 - t0) + t0
+        elif self.snr_type == "lognorm":
+            t = th.sigmoid(th.normal(mean=0.0, std=1.0, size=(n,))) * (t1 - t0) + t0
+        elif self.snr_type.startswith("shift"):
+            try:
+                shift = float(self.snr_type.split("_")[1])
+            except Exception:
+                raise ValueError(f"illegal snr_type: {self.snr_type}, if time shift is expected, snr_type should be "
+                                 "shift_{factor}, like shift_3.0")
+            t = th.rand((n,))
+            t = (shift * t) / (1 + (shift - 1) * t)
+        else:
+            raise ValueError(f"Unknown snr type: {self.snr_type}")
+        return t.to(x1[0]), x0, x1
+
+    def training_losses(self, model, x1, model_kwargs=None):
+        """flow-matching MSE to u_t (reference transport.py:130-164); velocity models only"""
+        model_kwargs = model_kwargs or {}
+        t, x0, x1 = self.sample(x1)
+        t, xt, ut = self.path_sampler.plan(t, x0, x1)
+        out = model(xt, t, **model_kwargs)
+        if self.model_type != ModelType.VELOCITY:
+            raise NotImplementedError
+        if isinstance(x1, (list, tuple)):
+            assert len(out) == len(ut) == len(x1)
+            loss = th.stack([((ut[i] - out[i]) ** 2).mean() for i in range(len(x0))], dim=0)
+        else:
+            loss = mean_flat((out - ut) ** 2)
+        return {"loss": loss, "task_loss": loss.clone().detach()}
+
+    def get_drift(self):
+        """drift of the probability-flow ODE as f(x, t, model, **kw); reference transport.py:166-197"""
+        plan = self.path_sampler
+
+        if self.model_type == ModelType.VELOCITY:
+            def raw(x, t, model, **kw):
+                return model(x, t, **kw)
+        elif self.model_type == ModelType.SCORE:
+            def raw(x, t, model, **kw):
+                mean, var = plan.compute_drift(x, t)
+                return -mean + var * model(x, t, **kw)
+        else:
+            def raw(x, t, model, **kw):
+                mean, var = plan.compute_drift(x, t)
+                sigma_t, _ = plan.compute_sigma_t(path.expand_t_like_x(t, x))
+                return -mean + var * (model(x, t, **kw) / -sigma_t)
+
+        def body_fn(x, t, model, **kw):
+            out = raw(x, t, model, **kw)
+            assert out.shape == x.shape, "Output shape from ODE solver must match input shape"
+            return out
+
+        # lets ode.sample() recognise "drift == model output" and run the whole loop inside the engine
+        body_fn.is_plain_velocity = self.model_type == ModelType.VELOCITY
+        return body_fn
+
+    def get_score(self):
+        """score of x_t = alpha_t x + sigma_t eps; reference transport.py:199-218"""
+        plan = self.path_sampler
+        if self.model_type == ModelType.NOISE:
+            return lambda x, t, model, **kw: model(x, t, **kw) / -plan.compute_sigma_t(path.expand_t_like_x(t, x))[0]
+        if self.model_type == ModelType.SCORE:
+            return lambda x, t, model, **kw: model(x, t, **kw)
+        if self.model_type == ModelType.VELOCITY:
+            return lambda x, t, model, **kw: plan.get_score_from_velocity(model(x, t, **kw), x, t)
+        raise NotImplementedError()
+
+
+class Sampler:
+    """Sampler factory (reference transport.py:221-450)."""
+
+    def __init__(self, transport):
+        self.transport = transport
+        self.drift = transport.get_drift()
+        self.score = transport.get_score()
+
+    # ---- ODE ------------------------------------------------------------------------------------------
+    def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False,
+                   time_shifting_factor=None):
+        """returns sample_fn(z, model_fn, **model_kwargs) -> Tensor[num_steps, *z.shape]; transport.py:346-391"""
+        if reverse:
+            def drift(x, t, model, **kw):
+                return self.drift(x, th.ones_like(t) * (1 - t), model, **kw)
+        else:
+            drift = self.drift
+        tr = self.transport
+        t0, t1 = tr.check_interval(tr.train_eps, tr.sample_eps, sde=False, eval=True, reverse=reverse, last_step_size=0.0)
+        solver = ode(drift=drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol, rtol=rtol,
+                     time_shifting_factor=time_shifting_factor)
+        return solver.sample
+
+    # ---- SDE ------------------------------------------------------------------------------------------
+    def _sde_terms(self, diffusion_form, diffusion_norm):
+        plan = self.transport.path_sampler
+
+        def diffusion(x, t):
+            return plan.compute_diffusion(x, t, form=diffusion_form, norm=diffusion_norm)
+
+        def drift(x, t, model, **kw):
+            return self.drift(x, t, model, **kw) + diffusion(x, t) * self.score(x, t, model, **kw)
+
+        return drift, diffusion
+
+    def _last_step(self, sde_drift, last_step, last_step_size):
+        plan = self.transport.path_sampler
+        if last_step is None:
+            return lambda x, t, model, **kw: x
+        if last_step == "Mean":
+            return lambda x, t, model, **kw: x + sde_drift(x, t, model, **kw) * last_step_size
+        if last_step == "Tweedie":
+            def tweedie(x, t, model, **kw):
+                a = plan.compute_alpha_t(t)[0][0]
+                s = plan.compute_sigma_t(t)[0][0]
+                return x / a + (s**2) / a * self.score(x, t, model, **kw)
+            return tweedie
+        if last_step == "Euler":
+            return lambda x, t, model, **kw: x + self.drift(x, t, model, **kw) * last_step_size
+        raise NotImplementedError()
+
+    def sample_sde(self, *, sampling_method="Euler", diffusion_form="SBDM", diffusion_norm=1.0, last_step="Mean",
+                   last_step_size=0.04, num_steps=250):
+        """returns sample_fn(init, model, **kw) -> list of num_steps states; reference transport.py:285-344"""
+        if last_step is None:
+            last_step_size = 0.0
+        sde_drift, sde_diffusion = self._sde_terms(diffusion_form, diffusion_norm)
+        tr = self.transport
+        t0, t1 = tr.check_interval(tr.train_eps, tr.sample_eps, diffusion_form=diffusion_form, sde=True, eval=True,
+                                   reverse=False, last_step_size=last_step_size)
+        solver = sde(sde_drift, sde_diffusion, t0=t0, t1=t1, num_steps=num_steps, sampler_type=sampling_method)
+        finish = self._last_step(sde_drift, last_step, last_step_size)
+
+        def _sample(init, model, **kw):
+            xs = solver.sample(init, model, **kw)
+            ts = th.ones(init.size(0), device=init.device) * t1
+            xs.append(finish(xs[-1], ts, model, **kw))
+            assert len(xs) == num_steps, "Samples does not match the number of steps"
+            return xs
+
+        return _sample
+
+    def sample_ode_likelihood(self, **kwargs):
+        raise NotImplementedError("likelihood ODE (reference transport.py:393-450) is a later row (SURVEY.md 8f)")

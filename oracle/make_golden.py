@@ -1,0 +1,115 @@
+"""Generates tests/golden/*.npz by running the UNMODIFIED reference (behind oracle/stubs) in the authoring
+container:  python -m oracle.make_golden        (needs /root/reference; TEST INFRASTRUCTURE ONLY)
+
+Fixtures store seeds + config + inputs + the reference's outputs; weights are regenerated from the seed by
+oracle.synth (numpy PCG64, bit-reproducible for the pinned numpy).  See tests/test_oracle_golden.py.
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+
+from oracle import ref_harness as R  # noqa: E402
+from oracle import synth  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def kats(models_mod, transport_mod):
+    """known answers of the reference's own helper functions"""
+    M = importlib.import_module("models.model")
+    integ = importlib.import_module("transport.integrators")
+    d = {}
+    o = integ.ode(drift=None, t0=0, t1=1, sampler_type="euler", num_steps=30, atol=1e-6, rtol=1e-3, time_shifting_factor=4)
+    d["tgrid_30_shift4"] = _np(o.t)
+    o = integ.ode(drift=None, t0=0, t1=1, sampler_type="euler", num_steps=5, atol=1e-6, rtol=1e-3)
+    d["tgrid_5"] = _np(o.t)
+    d["rope72_default"] = _np(torch.view_as_real(M.NextDiT.precompute_freqs_cis(72, 16)))
+    d["rope72_ntk2"] = _np(torch.view_as_real(M.NextDiT.precompute_freqs_cis(72, 16, scale_factor=2.0, scale_watershed=0.3, timestep=0.5)))
+    d["rope72_lin2"] = _np(torch.view_as_real(M.NextDiT.precompute_freqs_cis(72, 16, scale_factor=2.0, scale_watershed=0.3, timestep=0.1)))
+    x = (torch.arange(16, dtype=torch.float32) / 10).view(1, 2, 1, 8)
+    f = M.NextDiT.precompute_freqs_cis(8, 4)[:1, :2].flatten(0, 1).unsqueeze(0)
+    d["rotary_in"] = _np(x)
+    d["rotary_out"] = _np(M.Attention.apply_rotary_emb(x, f))
+    d["temb_half"] = _np(M.ParallelTimestepEmbedder.timestep_embedding(torch.tensor([0.5, 0.037, 1.0]), 256))
+    tr = transport_mod.create_transport("Linear", "velocity", None, None, None)
+    d["interval"] = np.array(tr.check_interval(tr.train_eps, tr.sample_eps, sde=False, eval=True, reverse=False, last_step_size=0.0), dtype=np.float64)
+    for meth in ("euler", "midpoint", "rk4"):
+        fn = transport_mod.Sampler(tr).sample_ode(sampling_method=meth, num_steps=5)
+        d[f"wiring_{meth}"] = _np(fn(torch.ones(2, 4, 8, 8), lambda x, t, **kw: -x))
+    ffn = {}
+    for dim in (1536, 2304, 3072, 4096, 576):
+        ffn[str(dim)] = M.FeedForward(dim, 4 * dim, 256, None).w1.weight.shape[0]
+    d["ffn_widths"] = np.array(json.dumps(ffn))
+    np.savez_compressed(os.path.join(OUT, "kat.npz"), **d)
+    print("kat.npz:", sorted(d))
+
+
+def model_case(name, cfg, pkg, latent_hw, text_len, uncond_len, seed_w, seed_x):
+    sd = synth.synth_state_dict(cfg, seed=seed_w)
+    z, t, cap, mask = synth.synth_inputs(cfg, latent_hw=latent_hw, text_len=text_len, uncond_len=uncond_len, seed=seed_x)
+    if pkg == "lumina_next_t2i":
+        model = R.build_reference_model(cfg, sd)
+        transport_mod = importlib.import_module("transport")
+    else:
+        for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
+            del sys.modules[m]
+        sys.path.insert(0, os.path.join(R.REFERENCE_ROOT, pkg))
+        nd = importlib.import_module("models.nextdit")
+        model = nd.NextDiT(use_flash_attn=False, **cfg.ctor_kwargs()).eval() if "use_flash_attn" in nd.NextDiT.__init__.__code__.co_varnames \
+            else nd.NextDiT(**cfg.ctor_kwargs()).eval()
+        model.load_state_dict(sd, strict=True)
+        transport_mod = None
+    N = (latent_hw[0] // 2) * (latent_hw[1] // 2)
+    out = {"config": np.array(json.dumps(cfg.to_dict())), "seed_w": seed_w, "seed_x": seed_x,
+           "z": _np(z), "t": _np(t), "cap": _np(cap), "mask": _np(mask), "package": np.array(pkg)}
+    hidden = []
+    hooks = [l.register_forward_hook(lambda m, i, o: hidden.append(_np(o))) for l in model.layers]
+    with torch.no_grad():
+        out["forward"] = _np(model(z, t, cap, mask))  # before any forward_with_cfg: default RoPE table
+        out["hidden"] = np.stack(hidden)
+        for h in hooks:
+            h.remove()
+        out["cfg4_prop"] = _np(model.forward_with_cfg(z, t, cap, mask, 4.0, scale_factor=1.0, scale_watershed=1.0,
+                                                      base_seqlen=16, proportional_attn=True))
+        t_lo = torch.full((2,), 0.1)
+        out["cfg4_lin2"] = _np(model.forward_with_cfg(z, t_lo, cap, mask, 4.0, scale_factor=2.0, scale_watershed=0.3,
+                                                      base_seqlen=16, proportional_attn=True))
+        t_hi = torch.full((2,), 0.8)
+        out["cfg4_ntk2"] = _np(model.forward_with_cfg(z, t_hi, cap, mask, 4.0, scale_factor=2.0, scale_watershed=0.3,
+                                                      base_seqlen=16, proportional_attn=True))
+        out["cfg1_plain"] = _np(model.forward_with_cfg(z, t, cap, mask, 1.0))
+        if transport_mod is not None:
+            tr = transport_mod.create_transport("Linear", "velocity", None, None, None)
+            for meth in ("euler", "midpoint"):
+                fn = transport_mod.Sampler(tr).sample_ode(sampling_method=meth, num_steps=5, time_shifting_factor=4)
+                traj = fn(z, model.forward_with_cfg, cap_feats=cap, cap_mask=mask, cfg_scale=4.0, proportional_attn=True,
+                          base_seqlen=16, scale_factor=1.0, scale_watershed=1.0)
+                out[f"traj_{meth}"] = _np(traj)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}.npz: N={N} T={text_len}", {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 0})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_grad_enabled(False)
+    models_mod, transport_mod = R.load_reference()
+    kats(models_mod, transport_mod)
+    model_case("nextdit_tiny", synth.TINY, "lumina_next_t2i", (16, 16), 16, 8, 0, 1)
+    model_case("nextdit_tiny_rect", synth.TINY, "lumina_next_t2i", (12, 20), 13, 5, 3, 4)
+    model_case("nextdit_tiny_gqa", synth.TINY_GQA, "lumina_next_t2i_mini", (16, 16), 16, 8, 5, 6)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""Fixed-grid ODE solvers restated from torchdiffeq (euler / midpoint / rk4).  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: torchdiffeq is a third-party dependency of the reference (call site
+``lumina_next_t2i/transport/integrators.py:115``; unpinned in pyproject.toml:50 / requirements.txt:7) that is
+neither vendored nor installed here.  Restated from its published algorithm (v0.2.x ``FixedGridODESolver``):
+the output grid is the step grid; each user-function call goes through ``_PerturbFunc`` which casts ``t`` to
+the state dtype; ``rk4`` is the 3/8-rule ``rk4_alt_step_func``.  Anchors: the reference's own midpoint step
+``visual_anagrams/generate.py:212-219`` and closed-form known answers in tests/test_oracle_golden.py.
+"""
+import torch
+
+
+def odeint(func, y0, t, *, method="euler", atol=None, rtol=None, t_cast=True):
+    if method not in ("euler", "midpoint", "rk4"):
+        raise NotImplementedError(method)
+
+    def f(tt, y):
+        return func(tt.to(y.dtype) if t_cast else tt, y)
+
+    sol = torch.empty((len(t),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+    sol[0] = y0
+    y = y0
+    for j in range(len(t) - 1):
+        t0, t1 = t[j], t[j + 1]
+        dt = t1 - t0
+        k1 = f(t0, y)
+        if method == "euler":
+            dy = dt * k1
+        elif method == "midpoint":
+            half_dt = 0.5 * dt
+            dy = dt * f(t0 + half_dt, y + k1 * half_dt)
+        else:
+            one_third, two_thirds = 1 / 3, 2 / 3
+            k2 = f(t0 + dt * one_third, y + dt * k1 * one_third)
+            k3 = f(t0 + dt * two_thirds, y + dt * (k2 - k1 * one_third))
+            k4 = f(t1, y + dt * (k1 - k2 + k3))
+            dy = (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+        y = y + dy
+        sol[j + 1] = y
+    return sol
+
+
+def time_grid(num_steps: int, time_shifting_factor=None, t0: float = 0.0, t1: float = 1.0) -> torch.Tensor:
+    """integrators.py:97-99: linspace then t / (t + s - s t)."""
+    t = torch.linspace(t0, t1, num_steps)
+    if time_shifting_factor:
+        s = time_shifting_factor
+        t = t / (t + s - s * t)
+    return t
+
+
+def sample_ode(model_fn, z, num_steps, method="euler", time_shifting_factor=None, t_cast=True, **model_kwargs):
+    """ode.sample, integrators.py:104-116 with velocity drift (transport.py:181-195)."""
+    t = time_grid(num_steps, time_shifting_factor)
+
+    def _fn(tt, x):
+        tvec = torch.ones(x.size(0)) * tt
+        out = model_fn(x, tvec, **model_kwargs)
+        assert out.shape == x.shape
+        return out
+
+    return odeint(_fn, z, t, method=method, t_cast=t_cast)

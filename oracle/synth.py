@@ -1,0 +1,131 @@
+"""Deterministic synthetic weights / inputs shared by the oracle, the golden generator, the GPU tests and
+bench.py.  numpy's PCG64 stream is bit-reproducible for a fixed numpy version, so fixtures
+only need to store seeds, not weights.  TEST INFRASTRUCTURE (see oracle/__init__.py)."""
+from __future__ import annotations
+
+from dataclasses import asdict, dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+
+@dataclass
+class NextDiTConfig:
+    dim: int = 2304
+    n_layers: int = 24
+    n_heads: int = 32
+    n_kv_heads: Optional[int] = None
+    multiple_of: int = 256
+    ffn_dim_multiplier: Optional[float] = None
+    norm_eps: float = 1e-5
+    qk_norm: bool = True
+    cap_feat_dim: int = 2048
+    patch_size: int = 2
+    in_channels: int = 4
+    learn_sigma: bool = True
+
+    @property
+    def kv_heads(self) -> int:
+        return self.n_heads if self.n_kv_heads is None else self.n_kv_heads
+
+    @property
+    def head_dim(self) -> int:
+        return self.dim // self.n_heads
+
+    @property
+    def ffn_hidden(self) -> int:
+        h = int(2 * (4 * self.dim) / 3)  # reference model.py:469-473
+        if self.ffn_dim_multiplier is not None:
+            h = int(self.ffn_dim_multiplier * h)
+        return self.multiple_of * ((h + self.multiple_of - 1) // self.multiple_of)
+
+    @property
+    def out_channels(self) -> int:
+        return self.in_channels * 2 if self.learn_sigma else self.in_channels
+
+    def ctor_kwargs(self) -> dict:
+        return dict(patch_size=self.patch_size, in_channels=self.in_channels, dim=self.dim, n_layers=self.n_layers,
+                    n_heads=self.n_heads, n_kv_heads=self.n_kv_heads, multiple_of=self.multiple_of,
+                    ffn_dim_multiplier=self.ffn_dim_multiplier, norm_eps=self.norm_eps, learn_sigma=self.learn_sigma,
+                    qk_norm=self.qk_norm, cap_feat_dim=self.cap_feat_dim)
+
+    def to_dict(self) -> dict:
+        return asdict(self)
+
+
+TINY = NextDiTConfig(dim=576, n_layers=2, n_heads=8, cap_feat_dim=128)            # hd 72, MHA
+TINY_GQA = NextDiTConfig(dim=576, n_layers=2, n_heads=8, n_kv_heads=2, cap_feat_dim=128)
+NEXT_2B = NextDiTConfig()                                                          # BASELINE cfg 2
+
+
+def state_shapes(cfg: NextDiTConfig) -> Dict[str, tuple]:
+    """key -> shape of the reference state_dict."""
+    d, A, cap, F = cfg.dim, min(cfg.dim, 1024), cfg.cap_feat_dim, cfg.ffn_hidden
+    dkv = cfg.kv_heads * cfg.head_dim
+    pp = cfg.patch_size * cfg.patch_size
+    s: Dict[str, tuple] = {
+        "pad_token": (d,), "x_embedder.weight": (d, pp * cfg.in_channels), "x_embedder.bias": (d,),
+        "t_embedder.mlp.0.weight": (A, 256), "t_embedder.mlp.0.bias": (A,),
+        "t_embedder.mlp.2.weight": (A, A), "t_embedder.mlp.2.bias": (A,),
+        "cap_embedder.0.weight": (cap,), "cap_embedder.0.bias": (cap,),
+        "cap_embedder.1.weight": (A, cap), "cap_embedder.1.bias": (A,),
+        "final_layer.linear.weight": (pp * cfg.out_channels, d), "final_layer.linear.bias": (pp * cfg.out_channels,),
+        "final_layer.adaLN_modulation.1.weight": (d, A), "final_layer.adaLN_modulation.1.bias": (d,),
+    }
+    for i in range(cfg.n_layers):
+        p = f"layers.{i}."
+        s[p + "attention.gate"] = (cfg.n_heads,)
+        s[p + "attention.wq.weight"] = (d, d)
+        s[p + "attention.wk.weight"] = (dkv, d)
+        s[p + "attention.wv.weight"] = (dkv, d)
+        s[p + "attention.wo.weight"] = (d, d)
+        s[p + "attention.wk_y.weight"] = (dkv, cap)
+        s[p + "attention.wv_y.weight"] = (dkv, cap)
+        if cfg.qk_norm:
+            for nm, w in (("q_norm", d), ("k_norm", dkv), ("ky_norm", dkv)):
+                s[p + f"attention.{nm}.weight"] = (w,)
+                s[p + f"attention.{nm}.bias"] = (w,)
+        s[p + "feed_forward.w1.weight"] = (F, d)
+        s[p + "feed_forward.w2.weight"] = (d, F)
+        s[p + "feed_forward.w3.weight"] = (F, d)
+        for nm in ("attention_norm1", "attention_norm2", "ffn_norm1", "ffn_norm2"):
+            s[p + nm + ".weight"] = (d,)
+        s[p + "attention_y_norm.weight"] = (cap,)
+        s[p + "adaLN_modulation.1.weight"] = (4 * d, A)
+        s[p + "adaLN_modulation.1.bias"] = (4 * d,)
+    return s
+
+
+def synth_state_dict(cfg: NextDiTConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """SURVEY.md 8d recipe: matrices ~ N(0, s^2) with s = min(0.02 * 3, 1/sqrt(fan_in)) so activations stay O(1)
+    through deep stacks, norm weights 1 + N(0, 0.02^2), biases N(0, 0.02^2), attention.gate ~ N(0, 0.5^2).
+    (The reference zero-initialises adaLN / final / cap-embedder / gate - model.py:567,643,652,709,201 - which
+    would make every block an identity and parity vacuous.)"""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for key, shape in state_shapes(cfg).items():
+        if key.endswith("attention.gate"):
+            a = rng.standard_normal(shape, dtype=np.float32) * 0.5
+        elif len(shape) == 1 and key.endswith(".weight"):  # every 1-D weight is a norm weight
+            a = 1.0 + rng.standard_normal(shape, dtype=np.float32) * 0.02
+        elif len(shape) == 1:  # biases, pad_token
+            a = rng.standard_normal(shape, dtype=np.float32) * 0.02
+        else:
+            a = rng.standard_normal(shape, dtype=np.float32) * min(0.06, 1.0 / np.sqrt(shape[-1]))
+        out[key] = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    return out
+
+
+def synth_inputs(cfg: NextDiTConfig, latent_hw=(16, 16), text_len: int = 16, uncond_len: int = 8, seed: int = 1,
+                 t_value: float = 0.5):
+    """z duplicated for cond+uncond (utils/cli.py:222-223), cap_feats ~ N(0,1), cond mask all ones, uncond mask
+    [1]*uncond_len + [0]*rest (empty prompt = BOS + padding to x8, sample.py:38)."""
+    rng = np.random.default_rng(seed)
+    H, W = latent_hw
+    z = torch.from_numpy(rng.standard_normal((1, cfg.in_channels, H, W), dtype=np.float32)).repeat(2, 1, 1, 1)
+    cap = torch.from_numpy(rng.standard_normal((2, text_len, cfg.cap_feat_dim), dtype=np.float32))
+    mask = torch.ones(2, text_len, dtype=torch.int32)
+    mask[1, uncond_len:] = 0
+    t = torch.full((2,), float(t_value), dtype=torch.float32)
+    return z, t, cap, mask

@@ -1,0 +1,273 @@
+"""-m gpu: every HIP kernel against a plain PyTorch fp32 reference of the same op, through the C ABI.
+
+Tolerances (stated here, justified in DESIGN.md): GEMM / attention outputs are bf16, so one output ulp is
+2^-8 relative; we require rel-L2 <= 4e-3 against an fp32-accumulated reference rounded once to bf16 and a
+max-abs error of a few ulp of the largest output.  Pure data-movement kernels must be bit exact.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import P, bf, lib, max_abs, ok, r16, rel_l2, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(A, W, bias=None, epilogue=0):
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.full((M, N // 2 if epilogue else N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_gemm_bf16(P(A), P(W), P(bias), 1, P(out), M, N, K, epilogue, 0, stream()), "gemm")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 576, 576), (300, 256, 128), (1024, 2304, 2304),
+                                   (130, 32, 576), (8192, 6912, 2304), (256, 1152, 128), (8192, 2304, 6144)])
+def test_gemm_plain(M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    out = _gemm(A, W)
+    ref = (A.float() @ W.float().t())  # fp32 reference on the device (rocBLAS), inputs are the same bf16 values
+    assert not torch.isnan(out.float()).any(), "unwritten outputs"
+    assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
+    assert max_abs(out, ref) < 0.04 * float(ref.abs().max())
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
+    K = N = 256
+    A = bf(torch.eye(256, K))
+    W = bf((torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 64.0)
+    out = _gemm(A, W)
+    assert torch.equal(out.float().cpu(), W.float().t().cpu())
+
+
+def test_gemm_bias_and_edges():
+    g = torch.Generator().manual_seed(5)
+    A = bf(torch.randn(200, 128, generator=g))
+    W = bf(torch.randn(40, 128, generator=g) / 11)
+    b = bf(torch.randn(40, generator=g))
+    out = _gemm(A, W, b)
+    ref = A.float() @ W.float().t() + b.float()
+    assert rel_l2(out, ref) < 4e-3
+    # guard: a larger buffer around the output must stay untouched (no stray stores past M or N)
+    big = torch.full((264, 40), 7.0, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_gemm_bf16(P(A), P(W), P(b), 1, P(big), 200, 40, 128, 0, 0, stream()))
+    torch.cuda.synchronize()
+    assert torch.all(big[200:] == 7.0)
+
+
+@pytest.mark.parametrize("M,F_,K", [(256, 128, 64), (300, 1536, 576), (4096, 6144, 2304)])
+def test_gemm_swiglu(M, F_, K):
+    g = torch.Generator().manual_seed(F_ + K)
+    A = bf(torch.randn(M, K, generator=g))
+    w1 = bf(torch.randn(F_, K, generator=g) / math.sqrt(K))
+    w3 = bf(torch.randn(F_, K, generator=g) / math.sqrt(K))
+    packed = torch.empty(2 * F_, K, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_pack_w13(P(w1), P(w3), P(packed), F_, K, stream()))
+    out = _gemm(A, packed, None, 1)
+    a = r16(A.float() @ w1.float().t())
+    b = r16(A.float() @ w3.float().t())
+    ref = r16(r16(F.silu(a)) * b)
+    assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
+
+
+def test_rmsnorm_mod():
+    B, N, d = 2, 70, 2304
+    g = torch.Generator().manual_seed(1)
+    x = bf(torch.randn(B * N, d, generator=g) * 3)
+    w = bf(1 + 0.1 * torch.randn(d, generator=g))
+    ld = 3 * d
+    mod = bf(torch.randn(B, ld, generator=g) * 0.5)
+    out = torch.empty_like(x)
+    ok(lib().lt_op_rmsnorm_mod(P(x), P(w), P(mod[:, d:]), None, ld, P(out), B, N, d, 1e-5, stream()))
+    torch.cuda.synchronize()
+    xf = x.float().cpu()
+    n = r16(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
+    n = r16(n * w.float().cpu())
+    sc = mod.float().cpu()[:, d:2 * d].repeat_interleave(N, dim=0)
+    ref = r16(n * r16(1 + sc))
+    assert rel_l2(out, ref) < 2e-3, rel_l2(out, ref)
+    assert max_abs(out, ref) <= 0.07  # a 1-ulp flip of an intermediate bf16 at |x| ~ 8
+
+
+@pytest.mark.parametrize("next_mode", [0, 1, 2])
+def test_gated_residual_norm(next_mode):
+    B, N, d = 2, 33, 576
+    g = torch.Generator().manual_seed(2 + next_mode)
+    x = bf(torch.randn(B * N, d, generator=g))
+    y = bf(torch.randn(B * N, d, generator=g) * 2)
+    pw = bf(1 + 0.1 * torch.randn(d, generator=g))
+    nw = bf(1 + 0.1 * torch.randn(d, generator=g))
+    ld = 4 * d
+    mod = bf(torch.randn(B, ld, generator=g))
+    x_dev = x.clone()
+    h = torch.full_like(x, float("nan"))
+    ok(lib().lt_op_gated_residual_norm(P(x_dev), P(y), P(pw), P(mod[:, d:]), 1, 1, P(nw) if next_mode == 1 else None,
+                                       P(mod[:, 2 * d:]) if next_mode else None, None, next_mode, ld, P(h), B, N, d,
+                                       1e-5, 1e-6, stream()))
+    torch.cuda.synchronize()
+    m = mod.float().cpu()
+    gate = r16(torch.tanh(m[:, d:2 * d])).repeat_interleave(N, dim=0)
+    scale = m[:, 2 * d:3 * d].repeat_interleave(N, dim=0)
+    yf = y.float().cpu()
+    yn = r16(r16(yf * torch.rsqrt(yf.pow(2).mean(-1, keepdim=True) + 1e-5)) * pw.float().cpu())
+    xn = r16(x.float().cpu() + r16(gate * yn))
+    assert rel_l2(x_dev, xn) < 2e-3
+    if next_mode == 1:
+        hn = r16(r16(xn * torch.rsqrt(xn.pow(2).mean(-1, keepdim=True) + 1e-5)) * nw.float().cpu())
+        ref = r16(hn * r16(1 + scale))
+        assert rel_l2(h, ref) < 3e-3, rel_l2(h, ref)
+    elif next_mode == 2:
+        ref = r16(F.layer_norm(xn, (d,), None, None, 1e-6) * r16(1 + scale))
+        assert rel_l2(h, ref) < 3e-3, rel_l2(h, ref)
+
+
+@pytest.mark.parametrize("heads,hd,qk_norm", [(8, 72, True), (2, 72, True), (32, 72, False), (32, 48, True)])
+def test_qk_norm_rope(heads, hd, qk_norm):
+    from oracle import nextdit_oracle as O
+    B, Hp, Wp = 2, 6, 10
+    N = Hp * Wp
+    width = heads * hd
+    g = torch.Generator().manual_seed(heads + hd)
+    ld = width + 64
+    src = bf(torch.randn(B * N, ld, generator=g))
+    w = bf(1 + 0.1 * torch.randn(width, generator=g))
+    b = bf(0.1 * torch.randn(width, generator=g))
+    table = torch.empty(2, 384, hd // 4, 2, device="cuda", dtype=torch.float32)
+    ok(lib().lt_op_rope_table_2d(P(table), 384, hd, 10000.0, 2.0, stream()))
+    dst = torch.empty(B, heads, N, hd, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_qk_norm_rope(P(src), ld, 64, P(w) if qk_norm else None, P(b) if qk_norm else None, 1e-5, P(dst), B, N,
+                                heads, hd, 1, P(table[1]), Wp, stream()))
+    torch.cuda.synchronize()
+    xs = src.float().cpu()[:, 64:]
+    if qk_norm:
+        xs = F.layer_norm(xs, (width,), w.float().cpu(), b.float().cpu(), 1e-5)
+    freqs = O.rope_table(hd, 384, scale_factor=2.0, scale_watershed=0.3, timestep=0.9)[:Hp, :Wp].flatten(0, 1).unsqueeze(0)
+    ref = r16(O.apply_rotary(xs.view(B, N, heads, hd), freqs)).permute(0, 2, 1, 3)
+    assert rel_l2(dst, ref) < 3e-3, rel_l2(dst, ref)
+    # table itself: branch 0 = linear interpolation, branch 1 = NTK (model.py:944-952)
+    lin = O.rope_table(hd, 384, scale_factor=2.0, scale_watershed=0.3, timestep=0.1)
+    tb = table.cpu()
+    got_row = torch.complex(tb[0, :, :, 0], tb[0, :, :, 1])  # [pos, freq]
+    assert (got_row - lin[:, 0, 0::2]).abs().max() < 2e-4
+    ntk = O.rope_table(hd, 384, scale_factor=2.0, scale_watershed=0.3, timestep=0.9)
+    got_row = torch.complex(tb[1, :, :, 0], tb[1, :, :, 1])
+    assert (got_row - ntk[0, :, 1::2]).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize("N,kvh,hd", [(64, 2, 72), (100, 8, 72), (256, 4, 48)])
+def test_v_transpose_is_exact(N, kvh, hd):
+    B = 2
+    Npad = (N + 63) // 64 * 64
+    ld = kvh * hd + 16
+    src = bf(torch.randn(B * N, ld))
+    dst = torch.full((B, kvh, hd, Npad), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_v_transpose(P(src), ld, 16, P(dst), B, N, Npad, kvh, hd, stream()))
+    torch.cuda.synchronize()
+    v = src.cpu()[:, 16:].view(B, N, kvh, hd).permute(0, 2, 3, 1)  # [B,kvh,hd,N]
+    want = torch.zeros(B, kvh, hd, Npad, dtype=torch.bfloat16)
+    idx = torch.arange(Npad)
+    pos = (idx & ~12) | ((idx & 4) << 1) | ((idx & 8) >> 1)
+    valid = idx < N
+    want[..., pos[valid]] = v[..., idx[valid]]
+    assert torch.equal(dst.cpu().view(torch.int16), want.view(torch.int16))
+
+
+def _attn_ref(q, k, v, scale, bias=None):
+    """exact softmax attention in fp32, one (batch, head) at a time to bound memory"""
+    q, k, v = q.cuda().float(), k.cuda().float(), v.cuda().float()
+    rep = q.shape[1] // k.shape[1]
+    out = torch.empty_like(q)
+    for b in range(q.shape[0]):
+        for h in range(q.shape[1]):
+            s = (q[b, h] @ k[b, h // rep].t()) * scale
+            if bias is not None:
+                s = s + bias[b].cuda()[None, :]
+            out[b, h] = torch.softmax(s, -1) @ v[b, h // rep]
+    return out.cpu()
+
+
+def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None):
+    B, H, N, hd = q.shape
+    Hkv, Nk = k.shape[1], k.shape[2]
+    Nkpad = (Nk + 63) // 64 * 64
+    vsrc = v.permute(0, 2, 1, 3).reshape(B * Nk, Hkv * hd).contiguous()
+    vt = torch.empty(B, Hkv, hd, Nkpad, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_v_transpose(P(vsrc), Hkv * hd, 0, P(vt), B, Nk, Nkpad, Hkv, hd, stream()))
+    out = prev.clone() if prev is not None else torch.full((B, N, H * hd), float("nan"), device="cuda", dtype=torch.bfloat16)
+    bias_dev = None
+    if bias is not None:
+        bias_dev = torch.full((B, Nkpad), float("-inf"), device="cuda", dtype=torch.float32)
+        bias_dev[:, :Nk] = bias.cuda()
+    ok(lib().lt_op_attention(P(q), P(k), P(vt), P(bias_dev), P(out), P(gate), 1 if gate is not None else 0, B, H, Hkv, N,
+                             Nk, Nkpad, hd, scale, stream()), "attention")
+    torch.cuda.synchronize()
+    return out.view(B, N, H, hd).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("B,H,Hkv,N,hd", [(1, 8, 8, 128, 72), (2, 8, 2, 320, 72), (2, 4, 4, 200, 72), (1, 3, 3, 64, 72),
+                                          (2, 32, 32, 4096, 72), (1, 8, 8, 256, 48), (1, 8, 8, 192, 96)])
+def test_attention_self(B, H, Hkv, N, hd):
+    g = torch.Generator().manual_seed(N + hd)
+    q = bf(torch.randn(B, H, N, hd, generator=g))
+    k = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    v = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    scale = math.sqrt(math.log(N, 64) / hd) if N > 64 else 1 / math.sqrt(hd)
+    out = _run_attn(q, k, v, scale)
+    ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), scale)
+    assert not torch.isnan(out.float()).any()
+    assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
+
+
+def test_attention_softmax_outlier_keys():
+    """forces a large running-max jump mid-sequence (guide 5.4 rule 26)"""
+    B, H, N, hd = 1, 8, 256, 72
+    g = torch.Generator().manual_seed(9)
+    q = bf(torch.randn(B, H, N, hd, generator=g))
+    k = bf(torch.randn(B, H, N, hd, generator=g))
+    v = bf(torch.randn(B, H, N, hd, generator=g))
+    k[:, :, 131] = q[:, :, 7] * 4.0
+    k[:, :, 3] = q[:, :, 200] * 2.0
+    out = _run_attn(q, k, v, 1 / math.sqrt(hd))
+    ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), 1 / math.sqrt(hd))
+    assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
+
+
+@pytest.mark.parametrize("T,valid1", [(16, 8), (13, 5), (128, 8), (77, 77)])
+def test_attention_text_accumulate(T, valid1):
+    B, H, Hkv, N, hd = 2, 8, 2, 96, 72
+    g = torch.Generator().manual_seed(T)
+    q = bf(torch.randn(B, H, N, hd, generator=g))
+    k = bf(torch.randn(B, Hkv, T, hd, generator=g))
+    v = bf(torch.randn(B, Hkv, T, hd, generator=g))
+    gate = bf(torch.randn(H, generator=g))
+    prev = bf(torch.randn(B, N, H * hd, generator=g))
+    mask = torch.ones(B, T)
+    mask[1, valid1:] = 0
+    bias = torch.where(mask > 0, 0.0, float("-inf"))
+    out = _run_attn(q, k, v, 1 / math.sqrt(hd), bias=bias, gate=gate, prev=prev)
+    oy = r16(_attn_ref(q.cpu(), k.cpu(), v.cpu(), 1 / math.sqrt(hd), bias))
+    gt = r16(torch.tanh(gate.float().cpu())).view(1, H, 1, 1)
+    ref = r16(prev.float().cpu().view(B, N, H, hd).permute(0, 2, 1, 3) + r16(oy * gt))
+    assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(2, 1000, 256, 0), (2, 9216, 1024, 1), (1, 37, 128, 1), (8, 64, 2048, 0)])
+def test_linear_small_m(M, N, K, act):
+    g = torch.Generator().manual_seed(N)
+    a = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = bf(torch.randn(N, generator=g))
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_linear_small_m(P(a), P(w), P(b), P(y), M, N, K, act, stream()))
+    torch.cuda.synchronize()
+    af = a.float().cpu()
+    if act:
+        af = r16(F.silu(af))
+    ref = af @ w.float().cpu().t() + b.float().cpu()
+    assert rel_l2(y, ref) < 4e-3

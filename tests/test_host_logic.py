@@ -1,0 +1,126 @@
+"""CPU: host-side mirror of the reference API (models/, transport/) - construction, state_dict contract,
+sampler factory wiring, and the 'no CPU fallback' rule of the product path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lumina_t2x_amd  # noqa: F401
+from lumina_t2x_amd import _lib, models
+from lumina_t2x_amd.transport import ModelType, PathType, Sampler, create_transport
+from lumina_t2x_amd.transport import integrators, path
+from oracle import synth
+
+
+def test_state_dict_contract_tiny():
+    cfg = synth.TINY
+    m = models.NextDiT(**cfg.ctor_kwargs())
+    want = synth.state_shapes(cfg)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == want
+    res = m.load_state_dict(synth.synth_state_dict(cfg), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_state_dict_contract_2b_on_meta():
+    with torch.device("meta"):
+        m = models.NextDiT_2B_patch2(qk_norm=True, cap_feat_dim=2048)
+        g = models.NextDiT_2B_GQA_patch2(qk_norm=True, cap_feat_dim=2048)
+    sd = m.state_dict()
+    assert len(sd) == 567
+    assert sum(v.numel() for v in sd.values()) == 1_988_531_232 or abs(sum(v.numel() for v in sd.values()) - 1.9885e9) < 2e6
+    assert tuple(sd["layers.23.feed_forward.w1.weight"].shape) == (6144, 2304)
+    assert tuple(sd["layers.0.adaLN_modulation.1.weight"].shape) == (9216, 1024)
+    assert tuple(g.state_dict()["layers.0.attention.wk.weight"].shape) == (576, 2304)
+    assert tuple(g.state_dict()["layers.0.attention.ky_norm.weight"].shape) == (576,)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == synth.state_shapes(synth.NEXT_2B)
+
+
+def test_forward_on_cpu_fails_loudly():
+    cfg = synth.TINY
+    m = models.NextDiT(**cfg.ctor_kwargs())
+    z, t, cap, mask = synth.synth_inputs(cfg)
+    with pytest.raises(_lib.LuminaLibError, match="no CPU fallback"):
+        m.forward_with_cfg(z, t, cap, mask, 4.0)
+    with pytest.raises(_lib.LuminaLibError, match="no CPU fallback"):
+        m(z, t, cap, mask)
+
+
+def test_create_transport_defaults_and_interval():
+    tr = create_transport("Linear", "velocity", None, None, None)
+    assert tr.model_type is ModelType.VELOCITY and isinstance(tr.path_sampler, path.ICPlan)
+    assert (tr.train_eps, tr.sample_eps) == (0, 0)
+    assert tr.check_interval(tr.train_eps, tr.sample_eps, sde=False, eval=True, reverse=False, last_step_size=0.0) == (0, 1)
+    vp = create_transport("VP", "velocity")
+    assert (vp.train_eps, vp.sample_eps) == (1e-5, 1e-3)
+    assert vp.check_interval(vp.train_eps, vp.sample_eps, eval=True) == (0, 1 - 1e-3)
+    sc = create_transport("Linear", "score")
+    assert sc.check_interval(sc.train_eps, sc.sample_eps, eval=True) == (1e-3, 1 - 1e-3)
+    assert sc.check_interval(sc.train_eps, sc.sample_eps, eval=True, reverse=True) == pytest.approx((1 - 1e-3, 1e-3))
+
+
+def test_time_grid_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat.npz"))
+    o = integrators.ode(drift=None, t0=0, t1=1, sampler_type="euler", num_steps=30, atol=1e-6, rtol=1e-3,
+                        time_shifting_factor=4)
+    np.testing.assert_array_equal(o.t.numpy(), g["tgrid_30_shift4"])
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_sampler_wiring_generic_callable(golden_dir, method):
+    """model-callable protocol (transport.py:192-195): t arrives as fp32 [B]; output keeps every grid point."""
+    g = np.load(os.path.join(golden_dir, "kat.npz"))
+    seen = []
+
+    def model(x, t, **kw):
+        seen.append((t.dtype, tuple(t.shape)))
+        return -x
+
+    fn = Sampler(create_transport()).sample_ode(sampling_method=method, num_steps=5)
+    out = fn(torch.ones(2, 4, 8, 8), model)
+    assert tuple(out.shape) == (5, 2, 4, 8, 8)
+    np.testing.assert_allclose(out.numpy(), g[f"wiring_{method}"], rtol=0, atol=1e-7)
+    stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    assert len(seen) == 4 * stages and all(s == (torch.float32, (2,)) for s in seen)
+
+
+def test_drift_shape_assert_and_unknown_method():
+    fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=3)
+    with pytest.raises(AssertionError, match="Output shape"):
+        fn(torch.ones(2, 4, 8, 8), lambda x, t, **kw: x[:, :2])
+    fn = Sampler(create_transport()).sample_ode(sampling_method="dopri5", num_steps=3)
+    with pytest.raises(NotImplementedError):
+        fn(torch.ones(2, 4, 8, 8), lambda x, t, **kw: -x)
+
+
+def test_bf16_state_rounds_t_like_torchdiffeq():
+    seen = []
+
+    def model(x, t, **kw):
+        seen.append(float(t[0]))
+        return torch.zeros_like(x)
+
+    fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=11)
+    fn(torch.ones(2, 4, 2, 2, dtype=torch.bfloat16), model)
+    assert abs(seen[3] - float(torch.tensor(0.3).bfloat16())) < 1e-9  # 0.30078125
+
+
+def test_paths_are_consistent():
+    x = torch.randn(3, 2, 4, 4)
+    t = torch.tensor([0.2, 0.5, 0.9])
+    for plan in (path.ICPlan(), path.GVPCPlan(), path.VPCPlan()):
+        v = torch.randn_like(x)
+        s = plan.get_score_from_velocity(v, x, t)
+        v2 = plan.get_velocity_from_score(s, x, t)
+        torch.testing.assert_close(v2, v, rtol=2e-4, atol=2e-4)
+        tt, xt, ut = plan.plan(t, torch.randn_like(x), x)
+        assert xt.shape == x.shape and ut.shape == x.shape
+
+
+def test_sde_sampler_shapes():
+    torch.manual_seed(0)
+    fn = Sampler(create_transport()).sample_sde(num_steps=6, last_step="Mean")
+    xs = fn(torch.randn(2, 4, 4, 4), lambda x, t, **kw: -x)
+    assert len(xs) == 6 and all(v.shape == (2, 4, 4, 4) for v in xs)

@@ -1,0 +1,122 @@
+"""CPU: pins the oracle (plain-torch restatement) against golden vectors produced by the UNMODIFIED reference
+(oracle/make_golden.py, run in the authoring container).  No GPU, no /root/reference needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nextdit_oracle as O
+from oracle import odeint_oracle as OD
+from oracle import synth
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _cfg(g):
+    return synth.NextDiTConfig(**json.loads(str(g["config"])))
+
+
+def test_kat_time_grid(golden_dir):
+    g = _load(golden_dir, "kat")
+    np.testing.assert_array_equal(OD.time_grid(30, 4).numpy(), g["tgrid_30_shift4"])
+    np.testing.assert_array_equal(OD.time_grid(5).numpy(), g["tgrid_5"])
+    # SURVEY.md A.7 spot values
+    assert abs(float(g["tgrid_30_shift4"][1]) - 0.00884956) < 1e-7
+    assert list(g["interval"]) == [0.0, 1.0]
+
+
+def test_kat_rope_table(golden_dir):
+    g = _load(golden_dir, "kat")
+    for key, kw in (("rope72_default", {}), ("rope72_ntk2", dict(scale_factor=2.0, scale_watershed=0.3, timestep=0.5)),
+                    ("rope72_lin2", dict(scale_factor=2.0, scale_watershed=0.3, timestep=0.1))):
+        mine = torch.view_as_real(O.rope_table(72, 16, **kw)).numpy()
+        np.testing.assert_array_equal(mine, g[key])
+    f = torch.view_as_complex(torch.from_numpy(g["rope72_default"]))
+    assert abs(f[3, 5, 0] - complex(-0.98999250, 0.14112000)) < 1e-6  # cis(row 3 * 1)
+    assert abs(f[3, 5, 18] - complex(0.99955004, 0.02999550)) < 1e-6  # cis(row 3 * 0.01)
+
+
+def test_kat_rotary_and_timestep(golden_dir):
+    g = _load(golden_dir, "kat")
+    x = torch.from_numpy(g["rotary_in"])
+    f = O.rope_table(8, 4)[:1, :2].flatten(0, 1).unsqueeze(0)
+    np.testing.assert_array_equal(O.apply_rotary(x, f).numpy(), g["rotary_out"])
+    np.testing.assert_array_equal(O.timestep_embedding(torch.tensor([0.5, 0.037, 1.0]), 256).numpy(), g["temb_half"])
+    widths = json.loads(str(g["ffn_widths"]))
+    for dim, w in widths.items():
+        assert synth.NextDiTConfig(dim=int(dim), n_heads=8).ffn_hidden == w
+    assert widths["2304"] == 6144 and widths["1536"] == 4096 and widths["3072"] == 8192
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_kat_sampler_wiring(golden_dir, method):
+    g = _load(golden_dir, "kat")
+    out = OD.sample_ode(lambda x, t, **kw: -x, torch.ones(2, 4, 8, 8), 5, method=method)
+    np.testing.assert_allclose(out.numpy(), g[f"wiring_{method}"], rtol=0, atol=1e-7)
+    if method == "euler":
+        assert abs(float(out[-1].flatten()[0]) - 0.75 ** 4) < 1e-7
+    # closed form for dy/dt = -y on a uniform grid (independent of the stub used to make the golden)
+    h = 0.25
+    factor = {"euler": 1 - h, "midpoint": 1 - h + h * h / 2, "rk4": 1 - h + h**2 / 2 - h**3 / 6 + h**4 / 24}[method]
+    assert abs(float(out[-1].flatten()[0]) - factor ** 4) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["nextdit_tiny", "nextdit_tiny_rect", "nextdit_tiny_gqa"])
+def test_oracle_matches_reference_model(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg = _cfg(g)
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    z, t, cap, mask = (torch.from_numpy(g[k]) for k in ("z", "t", "cap", "mask"))
+    tol = dict(rtol=0, atol=2e-5)
+    out, hidden = O.forward(sd, cfg, z, t, cap, mask, return_hidden=True)
+    np.testing.assert_allclose(out.numpy(), g["forward"], **tol)
+    np.testing.assert_allclose(torch.stack(hidden).numpy(), g["hidden"], **tol)
+    got = O.forward_with_cfg(sd, cfg, z, t, cap, mask, 4.0, base_seqlen=16, proportional_attn=True)
+    np.testing.assert_allclose(got.numpy(), g["cfg4_prop"], **tol)
+    got = O.forward_with_cfg(sd, cfg, z, torch.full((2,), 0.1), cap, mask, 4.0, scale_factor=2.0, scale_watershed=0.3,
+                             base_seqlen=16, proportional_attn=True)
+    np.testing.assert_allclose(got.numpy(), g["cfg4_lin2"], **tol)
+    got = O.forward_with_cfg(sd, cfg, z, torch.full((2,), 0.8), cap, mask, 4.0, scale_factor=2.0, scale_watershed=0.3,
+                             base_seqlen=16, proportional_attn=True)
+    np.testing.assert_allclose(got.numpy(), g["cfg4_ntk2"], **tol)
+    got = O.forward_with_cfg(sd, cfg, z, t, cap, mask, 1.0)
+    np.testing.assert_allclose(got.numpy(), g["cfg1_plain"], **tol)
+    # CFG quirk: guided channels identical across the pair, channel 3 is each row's own
+    ref = g["cfg4_prop"]
+    assert np.array_equal(ref[0, :3], ref[1, :3]) and not np.array_equal(ref[0, 3], ref[1, 3])
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint"])
+def test_oracle_trajectory_matches_reference_sampler(golden_dir, method):
+    g = _load(golden_dir, "nextdit_tiny")
+    cfg = _cfg(g)
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    z, cap, mask = (torch.from_numpy(g[k]) for k in ("z", "cap", "mask"))
+
+    def model_fn(x, tvec, **kw):
+        return O.forward_with_cfg(sd, cfg, x, tvec, **kw)
+
+    traj = OD.sample_ode(model_fn, z, 5, method=method, time_shifting_factor=4, cap_feats=cap, cap_mask=mask,
+                         cfg_scale=4.0, proportional_attn=True, base_seqlen=16)
+    np.testing.assert_allclose(traj.numpy(), g[f"traj_{method}"], rtol=0, atol=5e-5)
+
+
+def test_bf16_choreography_noise_floor(golden_dir):
+    """The bf16-emulating oracle mode stays within the reference's own bf16-vs-fp32 noise floor."""
+    g = _load(golden_dir, "nextdit_tiny")
+    cfg = _cfg(g)
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    z, t, cap, mask = (torch.from_numpy(g[k]) for k in ("z", "t", "cap", "mask"))
+    ref = torch.from_numpy(g["cfg4_prop"])
+    got = O.forward_with_cfg(sd, cfg, z, t, cap, mask, 4.0, base_seqlen=16, proportional_attn=True, bf16=True)
+    rel = float((got - ref).norm() / ref.norm())
+    assert 1e-4 < rel < 6e-2, rel
+
+
+def test_flop_count_matches_survey():
+    n = O.flops_per_nfe(synth.NEXT_2B, 4096, 128, 2)
+    assert 32.5e12 < n < 34.0e12  # 33.2 TFLOP per NFE at cfg 2
