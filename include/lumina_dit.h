@@ -84,6 +84,9 @@ const char* lt_last_error(void);
 /* library / build identification: returns e.g. "lumina_dit gfx950 r1" */
 const char* lt_version(void);
 
+/* process-wide kernel selection knobs (A/B measurements, tests): "attention_variant" 1|2, "gemm_variant" 0|1|2 */
+int lt_set_option(const char* name, int32_t value);
+
 /* ---- engine lifetime ------------------------------------------------------------------------- */
 int  lt_create(const lt_config* cfg, lt_engine** out);
 void lt_destroy(lt_engine* e);

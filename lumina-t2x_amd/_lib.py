@@ -58,6 +58,7 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGNATURES: Dict[str, tuple] = {
     "lt_last_error": (C.c_char_p, []),
     "lt_version": (C.c_char_p, []),
+    "lt_set_option": (_i32, [C.c_char_p, _i32]),
     "lt_create": (_i32, [C.POINTER(LtConfig), C.POINTER(_vp)]),
     "lt_destroy": (None, [_vp]),
     "lt_set_weight": (_i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32, _vp]),

@@ -20,6 +20,7 @@
 
 namespace {
 
+// ---- v1: straightforward online softmax (kept for A/B and as the fallback for head_dim % 32 == 0) -------
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     constexpr int KS = (HD + 15) / 16;   // QK^T k-steps
@@ -217,23 +218,258 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+// ---- v2: VALU diet ------------------------------------------------------------------------------------
+// The v1 loop is VALU-bound (MFMA pipe ~25 % busy): per 64-key tile a lane spends ~300 VALU ops on 22 MFMAs.
+// v2 removes most of them:
+//  * the softmax scale is folded into the exponent: p = exp2(fma(s, scale*log2e, -m));
+//  * the running max is only raised when the tile max exceeds it by more than THR (log2 units), so the
+//    O rescale is a rare wave-uniform branch (guide T13; P <= 2^THR stays exact enough in bf16);
+//  * the row sum l comes out of the PV MFMA for free: V^T gets one extra LDS row of ones in the padding of
+//    the last 32-row tile (hd 72 -> row 72, hd 48 -> row 48), so O^T[hd][q] = sum_k P[q][k];
+//  * s_setprio(1) around the MFMA clusters.
+// The key-bias path (text cross-attention, a few tiles only) keeps the explicit fma+bias form.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel_v2(AttnArgs p) {
+    constexpr int KS = (HD + 15) / 16;
+    constexpr int DT = (HD + 31) / 32;
+    constexpr int CPR = HD / 8;
+    constexpr int KTILE = 64 * HD * 2;
+    constexpr int VTILE = HD * 128 + 128;  // + the row of ones
+    constexpr float THR = 8.0f;
+    static_assert(HD % 32 != 0, "v2 needs a spare row in the last O^T tile");
+    constexpr int LI = HD % 32, L_DT = HD / 32, L_HI = (LI >> 2) & 1, L_REG = (LI & 3) + 4 * (LI >> 3);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int nqb = (p.N + 127) / 128;
+    const int BH = p.B * p.H;
+    int bh, qb;
+    if ((BH & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bh = xcd + 8 * (idx / nqb);
+        qb = idx % nqb;
+    } else {
+        bh = blockIdx.x / nqb;
+        qb = blockIdx.x % nqb;
+    }
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int bhk = b * p.Hkv + h / (p.H / p.Hkv);
+
+    // row of ones (bf16 1.0 = 0x3F80) behind each V^T buffer
+    if (tid < 64) {
+        const int buf = tid >> 5, w = tid & 31;
+        *(unsigned*)(smem + 2 * KTILE + buf * VTILE + HD * 128 + w * 4) = 0x3F803F80u;
+    }
+
+    int qrow = qb * 128 + wave * 32 + l31;
+    const bool q_ok = qrow < p.N;
+    if (!q_ok) qrow = p.N - 1;
+    const u16* qptr = p.q + ((size_t)bh * p.N + qrow) * HD;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int d0 = 16 * s + 8 * hi;
+        if (d0 < HD) qf[s] = *(const bf16x8*)(qptr + d0);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)0.0f;
+        }
+    }
+
+    const size_t kbytes = (size_t)p.Nk * HD * 2;
+    __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + (size_t)bhk * p.Nk * HD), 0, (int)kbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vt + (size_t)bhk * HD * p.Nkpad), 0, (int)((size_t)HD * p.Nkpad * 2), 0x00020000);
+    auto stage = [&](int buf, int k0) {
+        char* kb = smem + buf * KTILE;
+        char* vb = smem + 2 * KTILE + buf * VTILE;
+#pragma unroll
+        for (int i = 0; i < (CPR + 3) / 4; ++i) {
+            const int j = wave + 4 * i;
+            if (j < CPR) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, LDS_PTR(kb + j * 1024), 16, j * 1024 + lane * 16, k0 * HD * 2, 0, 0);
+                const int d = 8 * j + (lane >> 3);
+                const int sc = (lane & 7) ^ ((d >> 1) & 7);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(vb + j * 1024), 16, d * p.Nkpad * 2 + sc * 16, k0 * 2, 0, 0);
+            }
+        }
+    };
+
+    int koff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        int ch = 2 * s + hi;
+        if (ch > CPR - 1) ch = CPR - 1;
+        koff[s] = l31 * HD * 2 + ch * 16;
+    }
+    int voff[DT][4];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        int d = dt * 32 + l31;
+        if (d > HD) d = HD;  // row HD is the row of ones; rows past it are never stored
+#pragma unroll
+        for (int g = 0; g < 4; ++g) voff[dt][g] = d * 128 + (((2 * g + hi) ^ ((d >> 1) & 7)) << 4);
+    }
+
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -1.0e30f;
+
+    const int ntile = (p.Nk + 63) / 64;
+    const float* bias = p.bias ? p.bias + (size_t)b * p.Nkpad : nullptr;
+    stage(0, 0);
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntile) stage(cur ^ 1, (t + 1) * 64);
+        const char* kb = smem + cur * KTILE;
+        const char* vb = smem + 2 * KTILE + cur * VTILE;
+        const int k0 = t * 64;
+
+        f32x16 sc[2];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt2][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *(const bf16x8*)(kb + kt2 * 32 * HD * 2 + koff[s]);
+                sc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[kt2], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+
+        float mx = -INFINITY;
+        if (bias) {  // key-bias path: v = s * sl2 + bias, then plain max / exp2(v - m)
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 t4 = *(const f32x4*)(bias + k0 + 32 * kt2 + 8 * q4 + 4 * hi);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = __builtin_fmaf(sc[kt2][4 * q4 + j], sl2, t4[j]);
+                        sc[kt2][4 * q4 + j] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                }
+        } else {
+            if (k0 + 64 > p.Nk) {  // tail tile: keys past Nk
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + 32 * kt2 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (key >= p.Nk) sc[kt2][r] = -INFINITY;
+                    }
+            }
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt2][r]);
+            mx *= sl2;  // scale > 0
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const bool raise = mx > m_run + THR;
+        if (__any(raise)) {
+            const float m_new = raise ? mx : m_run;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        if (bias) {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[kt2][r] = __builtin_amdgcn_exp2f(sc[kt2][r] - m_run);
+        } else {
+            const float nm = -m_run;
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[kt2][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt2][r], sl2, nm));
+        }
+
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[g >> 1][8 * (g & 1) + e];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vf = *(const bf16x8*)(vb + voff[dt][g]);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    // l = O^T[HD][q] lives in register L_REG of tile L_DT on the hi == L_HI lane of this query row
+    const float l_tot = __shfl(o[L_DT][L_REG], l31 + 32 * L_HI, 64);
+    const float inv = 1.0f / l_tot;
+    float gate = 0.f;
+    if (p.accumulate) gate = bfr(tanhf(bf2f(p.gate[h])));
+    if (q_ok) {
+        u16* orow = p.out + ((size_t)b * p.N + qrow) * ((size_t)p.H * HD) + (size_t)h * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int d0 = 32 * dt + 8 * q4 + 4 * hi;
+                if (d0 < HD) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * q4 + j] * inv;
+                    u32x2* dst = (u32x2*)(orow + d0);
+                    if (p.accumulate) {
+                        const u32x2 prev = *dst;
+                        const float pv[4] = {bf_lo(prev[0]), bf_hi(prev[0]), bf_lo(prev[1]), bf_hi(prev[1])};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = pv[j] + bfr(bfr(v[j]) * gate);
+                    }
+                    u32x2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                    *dst = w;
+                }
+            }
+    }
+}
+
 }  // namespace
+
+static int g_attn_variant = 2;
+void lt_set_attention_variant(int v) { g_attn_variant = v; }
 
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.H % a.Hkv == 0, "attention: H=%d not a multiple of Hkv=%d", a.H, a.Hkv);
     LT_REQUIRE(a.Nkpad % 64 == 0 && a.Nkpad >= a.Nk && a.Nk > 0 && a.N > 0, "attention: bad key counts Nk=%d Nkpad=%d", a.Nk, a.Nkpad);
     LT_REQUIRE(!a.accumulate || a.gate != nullptr, "attention: accumulate mode needs a gate");
+    LT_REQUIRE(a.scale > 0.f, "attention: softmax scale must be positive");
     const int nqb = (a.N + 127) / 128;
     dim3 grid(a.B * a.H * nqb), block(256);
-#define LAUNCH_HD(HD_)                                                                                         \
-    hipLaunchKernelGGL(attn_fwd_kernel<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128), stream, a)
+#define LAUNCH_V1(HD_) hipLaunchKernelGGL(attn_fwd_kernel<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128), stream, a)
+#define LAUNCH_V2(HD_) hipLaunchKernelGGL(attn_fwd_kernel_v2<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128 + 128), stream, a)
+    const bool v2 = g_attn_variant == 2;
     switch (a.hd) {
-        case 48: LAUNCH_HD(48); break;
-        case 72: LAUNCH_HD(72); break;
-        case 96: LAUNCH_HD(96); break;
+        case 48: if (v2) LAUNCH_V2(48); else LAUNCH_V1(48); break;
+        case 72: if (v2) LAUNCH_V2(72); else LAUNCH_V1(72); break;
+        case 96: LAUNCH_V1(96); break;
         default: lt_set_error("attention: head_dim %d not built (48, 72, 96)", a.hd); return 2;
     }
-#undef LAUNCH_HD
+#undef LAUNCH_V1
+#undef LAUNCH_V2
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -627,6 +627,14 @@ extern "C" int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t*
     return 0;
 }
 
+extern "C" int lt_set_option(const char* name, int32_t value) {
+    LT_REQUIRE(name, "lt_set_option: null name");
+    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value == 1 || value == 2, "attention_variant must be 1 or 2"); lt_set_attention_variant(value); return 0; }
+    if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }
+    lt_set_error("lt_set_option: unknown option '%s'", name);
+    return 2;
+}
+
 // ---- operator-level entry points ---------------------------------------------------------------------------
 extern "C" int lt_op_gemm_bf16(const void* A, const void* W, const void* bias, int32_t bias_dtype, void* C, int32_t M,
                                int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* stream) {

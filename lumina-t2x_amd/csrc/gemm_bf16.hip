@@ -5,7 +5,8 @@
 //
 // Design (CDNA4-first, not a CUDA tiling):
 //  * 256x256x64 macro tile, 8 waves (2 along M x 4 along N), each wave owns 128x64 of C as
-//    4x2 tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator registers / lane).
+//    4x2 tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator registers / lane); or 256x288x64 with
+//    12 waves (4 x 3, 64x96 per wave) where that removes tile-count quantisation over the 256 CUs.
 //  * A and W tiles go HBM -> LDS with buffer_load ... lds (16 B / lane, no VGPR round trip),
 //    double-buffered (2 x 64 KiB of the CU's 160 KiB).  The LDS image is lane-linear, so the bank
 //    swizzle is applied to the per-lane SOURCE address and again on the ds_read_b128 (guide rule 21):
@@ -23,9 +24,7 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int STAGE_BYTES = 65536;  // A 32 KiB + W 32 KiB
-constexpr int W_OFF = 32768;
+constexpr int BK = 64;
 
 __device__ __forceinline__ void tile_coords(int bid, int nwg, int TM, int TN, int& tm, int& tn) {
     const int NX = 8;
@@ -46,13 +45,30 @@ __device__ __forceinline__ float load_bias(const void* bias, int dt, int n) {
     return dt == 0 ? ((const float*)bias)[n] : bf2f(((const u16*)bias)[n]);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs p) {
+}  // namespace
+
+// (named namespace: a __global__ template with internal linkage that is only instantiated from another
+//  template loses its host stub with hipcc 7.2)
+namespace lt_gemm {
+
+// WM x WN waves, each owning an (MT*32) x (NT*32) block of C.  Tile = (WM*MT*32) x (WN*NT*32) x 64.
+//   <2,4,4,2>: 256 x 256, 8 waves  (128 accumulators / lane)  - default and the SwiGLU epilogue
+//   <4,3,2,3>: 256 x 288, 12 waves ( 96 accumulators / lane)  - N = 2304 / 6912: 8192 x 2304 is exactly
+//              256 tiles = one round of the 256 CUs (256-wide tiles need 288 = 1.125 rounds -> 2 rounds)
+template <int WM, int WN, int MT, int NT, int EPI>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_tn(GemmArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int PA = BM / 8, PW = BN / 8;           // 1-KiB staging pieces (8 rows x 128 B)
+    constexpr int IA = (PA + NW - 1) / NW, IW = (PW + NW - 1) / NW;
+    constexpr int W_OFF = BM * 128;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(EPI == 0 || NT % 2 == 0, "SwiGLU epilogue pairs accumulator tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int hi = lane >> 5, l31 = lane & 31;
 
     const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
@@ -68,39 +84,42 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs p) {
     __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.W + (size_t)n0 * p.ldw), 0, (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left), 0x00020000);
 
-    // staging: wave w copies 1-KiB pieces j = w + 8 i (8 rows x 128 B each) of both tiles
+    // staging: wave w copies pieces w, w + NW, ... of the A tile and of the W tile.  Piece j holds rows
+    // 8j..8j+7; the lane's 16-byte chunk c of row r is fetched from source chunk c ^ ((r >> 1) & 7).
     const int srow = wave * 8 + (lane >> 3);
-    const int sswz = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16;
-    int a_voff[4], w_voff[4];
+    const int sswz = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16;  // NW is even: parity of j = parity of w
+    static_assert(IA <= 4 && IW <= 4, "staging pieces per wave");
+    int a_voff[4], w_voff[4];  // fixed size: a dependent bound here breaks host-side substitution (hipcc 7.2)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a_voff[i] = (srow + 64 * i) * p.lda * 2 + sswz;
-        w_voff[i] = (srow + 64 * i) * p.ldw * 2 + sswz;
-    }
+    for (int i = 0; i < IA; ++i) a_voff[i] = (srow + 8 * NW * i) * p.lda * 2 + sswz;
+#pragma unroll
+    for (int i = 0; i < IW; ++i) w_voff[i] = (srow + 8 * NW * i) * p.ldw * 2 + sswz;
     auto stage = [&](int buf, int kt) {
         const int soff = kt * BK * 2;
         char* base = smem + buf * STAGE_BYTES + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(base + i * 8192), 16, a_voff[i], soff, 0, 0);
+        for (int i = 0; i < IA; ++i)
+            if (wave + NW * i < PA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(base + i * NW * 1024), 16, a_voff[i], soff, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(base + W_OFF + i * 8192), 16, w_voff[i], soff, 0, 0);
+        for (int i = 0; i < IW; ++i)
+            if (wave + NW * i < PW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(base + W_OFF + i * NW * 1024), 16, w_voff[i], soff, 0, 0);
     };
 
     // fragment read offsets (row ≡ l31 mod 32 in every sub-tile, so the swizzle key is per lane)
     const int fswz = (l31 >> 1) & 7;
-    const int a_row_off = (wm * 128 + l31) * 128;
-    const int w_row_off = W_OFF + (wn * 64 + l31) * 128;
+    const int a_row_off = (wm * MT * 32 + l31) * 128;
+    const int w_row_off = W_OFF + (wn * NT * 32 + l31) * 128;
     int coff[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) coff[s] = ((2 * s + hi) ^ fswz) << 4;
 
-    f32x16 acc[4][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -115,15 +134,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs p) {
         const char* sb = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 wf[2], af[4];
+            bf16x8 wf[NT], af[MT];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) wf[nt] = *(const bf16x8*)(sb + w_row_off + nt * 4096 + coff[s]);
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(sb + w_row_off + nt * 4096 + coff[s]);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf16x8*)(sb + a_row_off + mt * 4096 + coff[s]);
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf16x8*)(sb + a_row_off + mt * 4096 + coff[s]);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -133,13 +152,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs p) {
     // ---- epilogue: lane holds, per 32x32 tile, row m = l31 and columns 8q + 4hi + j (reg 4q+j) ----
     const size_t ldc = p.ldc;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 128 + mt * 32 + l31;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * MT * 32 + mt * 32 + l31;
         u16* crow = p.C + (size_t)m * ldc;
         if (EPI == 0) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int nbase = n0 + wn * 64 + nt * 32;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nbase = n0 + wn * NT * 32 + nt * 32;
 #pragma unroll
                 for (int qp = 0; qp < 2; ++qp) {
                     float v[8];
@@ -165,30 +184,43 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs p) {
                 }
             }
         } else {
-            const int obase = (n0 + wn * 64) / 2;
 #pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {
-                float v[8];
+            for (int np = 0; np < NT / 2; ++np) {
+                const int obase = (n0 + wn * NT * 32 + np * 64) / 2;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
-                    const float a = bfr(acc[mt][0][8 * qp + j]);
-                    const float b = bfr(acc[mt][1][8 * qp + j]);
-                    v[j] = bfr(silu_f(a)) * b;
-                }
-                unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
-                unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
-                auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                const int col = obase + 16 * qp + 8 * hi;
-                if (m < p.M && col < p.N / 2) {
-                    u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                    *(u32x4*)(crow + col) = o;
+                for (int qp = 0; qp < 2; ++qp) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
+                        const float a = bfr(acc[mt][2 * np][8 * qp + j]);
+                        const float b = bfr(acc[mt][2 * np + 1][8 * qp + j]);
+                        v[j] = bfr(silu_f(a)) * b;
+                    }
+                    unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
+                    unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    const int col = obase + 16 * qp + 8 * hi;
+                    if (m < p.M && col < p.N / 2) {
+                        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        *(u32x4*)(crow + col) = o;
+                    }
                 }
             }
         }
     }
 }
+
+// explicit instantiations (hipcc 7.2 does not emit the kernel body for address-only uses inside another template)
+template __global__ void gemm_bf16_tn<2, 4, 4, 2, 0>(GemmArgs);
+template __global__ void gemm_bf16_tn<2, 4, 4, 2, 1>(GemmArgs);
+template __global__ void gemm_bf16_tn<4, 3, 2, 3, 0>(GemmArgs);
+
+}  // namespace lt_gemm
+
+namespace {
+using lt_gemm::gemm_bf16_tn;
 
 // w1/w3 -> 32-row interleaved packed weight (row P: block = P/64; P%64 < 32 -> w1 else w3)
 __global__ void pack_w13_kernel(const u16* __restrict__ w1, const u16* __restrict__ w3, u16* __restrict__ out,
@@ -206,26 +238,55 @@ __global__ void pack_w13_kernel(const u16* __restrict__ w1, const u16* __restric
 
 }  // namespace
 
+namespace {
+template <int WM, int WN, int MT, int NT, int EPI>
+int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32, SMEM = 2 * (BM + BN) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_done = true;
+    }
+    const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+}  // namespace
+
+static int g_gemm_variant = 0;
+void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
+
+// variant: 0 = pick the tile shape that minimises (rounds over the CUs) x (tile width); 1 = 256x256; 2 = 256x288
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream) {
     LT_REQUIRE(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    (void)variant;
-    static bool attr_done = false;
-    if (!attr_done) {
-        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-        attr_done = true;
+    LT_REQUIRE(variant >= 0 && variant <= 2, "gemm: unknown variant %d", variant);
+    if (epilogue == 1) return launch_cfg<2, 4, 4, 2, 1>(a, stream);
+    if (variant == 0) variant = g_gemm_variant;
+    if (variant == 0) {
+        const int cus = num_cus();
+        const long long tm = (a.M + 255) / 256;
+        const long long t256 = tm * ((a.N + 255) / 256), t288 = tm * ((a.N + 287) / 288);
+        const long long c256 = ((t256 + cus - 1) / cus) * 256, c288 = ((t288 + cus - 1) / cus) * 288;
+        variant = c288 < c256 ? 2 : 1;
     }
-    const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
-    dim3 grid(TM * TN), block(512);
-    if (epilogue == 0)
-        hipLaunchKernelGGL(gemm_bf16_tn_256<0>, grid, block, 2 * STAGE_BYTES, stream, a);
-    else
-        hipLaunchKernelGGL(gemm_bf16_tn_256<1>, grid, block, 2 * STAGE_BYTES, stream, a);
-    LT_CHECK_HIP(hipGetLastError());
-    return 0;
+    if (variant == 2) return launch_cfg<4, 3, 2, 3, 0>(a, stream);
+    return launch_cfg<2, 4, 4, 2, 0>(a, stream);
 }
 
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream) {

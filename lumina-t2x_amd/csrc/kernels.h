@@ -72,6 +72,8 @@ struct AttnArgs {
     float scale;
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
+void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
+void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
 
 // ---- small kernels (misc.hip) ------------------------------------------------------------------
 int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int M, int N, int K, int act_in,

@@ -39,3 +39,7 @@ def lib():
 
 def ok(rc, what=""):
     _lib.check(rc, what)
+
+
+def set_option(name, value):
+    ok(lib().lt_set_option(name.encode(), int(value)), f"lt_set_option({name})")

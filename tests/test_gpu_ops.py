@@ -10,16 +10,23 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import P, bf, lib, max_abs, ok, r16, rel_l2, stream
+from gpu_util import P, bf, lib, max_abs, ok, r16, rel_l2, set_option, stream
 
 pytestmark = pytest.mark.gpu
 
 
-def _gemm(A, W, bias=None, epilogue=0):
+@pytest.fixture(autouse=True)
+def _default_kernel_variants():
+    yield
+    set_option("attention_variant", 2)
+    set_option("gemm_variant", 0)
+
+
+def _gemm(A, W, bias=None, epilogue=0, variant=0):
     M, K = A.shape
     N = W.shape[0]
     out = torch.full((M, N // 2 if epilogue else N), float("nan"), device="cuda", dtype=torch.bfloat16)
-    ok(lib().lt_op_gemm_bf16(P(A), P(W), P(bias), 1, P(out), M, N, K, epilogue, 0, stream()), "gemm")
+    ok(lib().lt_op_gemm_bf16(P(A), P(W), P(bias), 1, P(out), M, N, K, epilogue, variant, stream()), "gemm")
     torch.cuda.synchronize()
     return out
 
@@ -37,12 +44,27 @@ def test_gemm_plain(M, N, K):
     assert max_abs(out, ref) < 0.04 * float(ref.abs().max())
 
 
-def test_gemm_identity_asymmetric():
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(8192, 2304, 2304), (300, 576, 128), (1024, 6912, 2304), (256, 288, 64), (257, 296, 192)])
+def test_gemm_tile_variants(variant, M, N, K):
+    """both tile shapes (256x256 / 8 waves, 256x288 / 12 waves) on tile-multiple and ragged problems"""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + variant)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = bf(torch.randn(N, generator=g))
+    out = _gemm(A, W, b, variant=variant)
+    ref = A.float() @ W.float().t() + b.float()
+    assert not torch.isnan(out.float()).any(), "unwritten outputs"
+    assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_identity_asymmetric(variant):
     """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
-    K = N = 256
-    A = bf(torch.eye(256, K))
+    K, N = 320, 576
+    A = bf(torch.eye(320, K))
     W = bf((torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 64.0)
-    out = _gemm(A, W)
+    out = _gemm(A, W, variant=variant)
     assert torch.equal(out.float().cpu(), W.float().t().cpu())
 
 
@@ -210,9 +232,11 @@ def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None):
     return out.view(B, N, H, hd).permute(0, 2, 1, 3)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("B,H,Hkv,N,hd", [(1, 8, 8, 128, 72), (2, 8, 2, 320, 72), (2, 4, 4, 200, 72), (1, 3, 3, 64, 72),
                                           (2, 32, 32, 4096, 72), (1, 8, 8, 256, 48), (1, 8, 8, 192, 96)])
-def test_attention_self(B, H, Hkv, N, hd):
+def test_attention_self(variant, B, H, Hkv, N, hd):
+    set_option("attention_variant", variant)
     g = torch.Generator().manual_seed(N + hd)
     q = bf(torch.randn(B, H, N, hd, generator=g))
     k = bf(torch.randn(B, Hkv, N, hd, generator=g))
@@ -224,8 +248,11 @@ def test_attention_self(B, H, Hkv, N, hd):
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
 
 
-def test_attention_softmax_outlier_keys():
-    """forces a large running-max jump mid-sequence (guide 5.4 rule 26)"""
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_softmax_outlier_keys(variant):
+    """forces large running-max jumps mid-sequence, above and below the deferred-rescale threshold (guide 5.4
+    rule 26); v1 (rescale every tile) and v2 (threshold 8 in log2 units) must both match the exact softmax"""
+    set_option("attention_variant", variant)
     B, H, N, hd = 1, 8, 256, 72
     g = torch.Generator().manual_seed(9)
     q = bf(torch.randn(B, H, N, hd, generator=g))
@@ -233,13 +260,16 @@ def test_attention_softmax_outlier_keys():
     v = bf(torch.randn(B, H, N, hd, generator=g))
     k[:, :, 131] = q[:, :, 7] * 4.0
     k[:, :, 3] = q[:, :, 200] * 2.0
+    k[:, :, 70] = q[:, :, 100] * 0.35   # raises the row max by less than the threshold: stays un-rescaled
     out = _run_attn(q, k, v, 1 / math.sqrt(hd))
     ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), 1 / math.sqrt(hd))
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("T,valid1", [(16, 8), (13, 5), (128, 8), (77, 77)])
-def test_attention_text_accumulate(T, valid1):
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("T,valid1", [(16, 8), (13, 5), (128, 8), (77, 77), (200, 130)])
+def test_attention_text_accumulate(variant, T, valid1):
+    set_option("attention_variant", variant)
     B, H, Hkv, N, hd = 2, 8, 2, 96, 72
     g = torch.Generator().manual_seed(T)
     q = bf(torch.randn(B, H, N, hd, generator=g))
