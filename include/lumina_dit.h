@@ -139,6 +139,11 @@ int lt_profile_reset(lt_engine* e);
 int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, int32_t bias_dtype,
                     void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
                     void* stream);
+/* diagnostics: the ping-pong GEMM (variant 3 | 4) built with s_memtime stamps; trace_dev receives, for every 64th
+ * workgroup and each of its waves, 8 x uint64: cycle totals of {fragment-read issue, vmcnt wait, lgkmcnt wait,
+ * pre-MFMA barrier, MFMA segment, post-MFMA barrier}, the slab count and the end stamp. */
+int lt_op_gemm_trace(const void* A_dev, const void* W_dev, void* C_dev, int32_t M, int32_t N, int32_t K,
+                     int32_t variant, void* trace_dev, void* stream);
 /* interleave w1[F,K], w3[F,K] into the packed [2F,K] layout epilogue 1 expects */
 int lt_op_pack_w13(const void* w1_dev, const void* w3_dev, void* out_dev, int32_t F, int32_t K,
                    void* stream);

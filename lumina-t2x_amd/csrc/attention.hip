@@ -447,6 +447,271 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel_v2(AttnArgs p) {
     }
 }
 
+
+// ---- v3: ping-pong wave groups for head_dim 72 (the Next-DiT 2B self-attention) ----------------------------------
+// At hd = 72 the softmax VALU work per score is as expensive as the MFMA work (the v2 loop keeps the matrix pipe
+// ~37 % busy), so v3 removes VALU work and makes the two waves of a SIMD alternate between a pure-MFMA phase and
+// a pure-VALU phase:
+//  * workgroup = 8 waves = 256 query rows (32 per wave), K / V^T tiles of 64 keys in 4-slot LDS rings shared by
+//    all 8 waves (half the staging traffic and DMA issue per query row of v2).
+//  * the waves form two groups (wave / 4); per tile a wave runs
+//        X(t): PV MFMAs of tile t-1 + QK^T MFMAs of tile t (22 MFMAs, fragment ds_reads in between)  | s_barrier
+//        Y(t): softmax of tile t (max3 tree, exp2, bf16 pack) + LDS-DMA issue for K(t+3), V(t+2)      | s_barrier
+//    and group 1 runs one barrier interval late: on every SIMD one wave feeds the matrix pipe while the other
+//    does exp2 - the two pipes overlap by construction instead of by luck.
+//  * the running max is folded INTO the QK^T MFMA: hd 72 is padded to 80 in the reduction, so two of the pad
+//    slots carry K-side 1.0 (a constant LDS chunk) x Q-side (-m_hi, -m_lo); Q is pre-scaled by scale*log2(e).
+//    The MFMA therefore yields s*scale*log2e - m directly and P = exp2(.) needs no fma.  m only moves when a tile
+//    max exceeds it by 2^THR (rare wave-uniform branch that rescales O, fixes this tile's scores and rewrites
+//    the two pad values); a bf16-split m is exact enough because numerator and row sum use the same P.
+//  * row sum l from the ones-row of V^T, as in v2.  DMA waits are counted (never vmcnt(0) in the loop).
+// Hazards (barrier-interval units; X(t) of group g in interval 2t+g, Y(t) in 2t+g+1):
+//   K(t+3) / V(t+2) are issued in Y(t), waited for at the end of X(t+2) (leaving Y(t+1)'s batch in flight) and
+//   first read in X(t+3) - a barrier all waves pass lies between wait and read for either group; they overwrite
+//   the slots of K(t-1) / V(t-2), last read in X(t-1) = interval 2t-2+g' < 2t+g+1.
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
+    static_assert(HD == 72, "v3 relies on hd % 16 == 8 (pad slots in the last QK^T k-step, spare row in O^T)");
+    constexpr int KS = 5, DT = 3, CPR = HD / 8;
+    constexpr int KTILE = 64 * HD * 2;      // 9216
+    constexpr int VTILE = HD * 128 + 128;   // 9344 incl. the row of ones
+    constexpr int V_BASE = 0, K_BASE = 4 * VTILE, CONST_OFF = K_BASE + 4 * KTILE;
+    constexpr float THR = 8.0f;
+    constexpr int LI = HD % 32, L_DT = HD / 32, L_HI = (LI >> 2) & 1, L_REG = (LI & 3) + 4 * (LI >> 3);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int nqb = (p.N + 255) / 256;
+    const int BH = p.B * p.H;
+    int bh, qb;
+    if ((BH & 7) == 0) {  // XCD-aware: head bh lives on XCD bh % 8, its q-blocks run back to back (K/V stay in that L2)
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bh = xcd + 8 * (idx / nqb);
+        qb = idx % nqb;
+    } else {
+        bh = blockIdx.x / nqb;
+        qb = blockIdx.x % nqb;
+    }
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int bhk = b * p.Hkv + h / (p.H / p.Hkv);
+
+    // constants in LDS: ones rows behind each V^T slot, and the K-side pad chunk (1, 1, 0, ...)
+    if (tid < 128) *(unsigned*)(smem + V_BASE + (tid >> 5) * VTILE + HD * 128 + (tid & 31) * 4) = 0x3F803F80u;
+    if (tid >= 128 && tid < 132) *(unsigned*)(smem + CONST_OFF + (tid - 128) * 4) = (tid == 128) ? 0x3F803F80u : 0u;
+
+    // ---- Q fragments, pre-scaled to the log2 domain -------------------------------------------------
+    int qrow = qb * 256 + wave * 32 + l31;
+    const bool q_ok = qrow < p.N;
+    if (!q_ok) qrow = p.N - 1;
+    const u16* qptr = p.q + ((size_t)bh * p.N + qrow) * HD;
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int d0 = 16 * s + 8 * hi;
+        if (d0 < HD) {
+            const bf8_t raw = *(const bf8_t*)(qptr + d0);
+            float f[8];
+            unpack8(raw, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)(f[e] * sl2);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)0.0f;  // pad: slots 0,1 become -m_hi, -m_lo
+        }
+    }
+
+    // ---- staging ------------------------------------------------------------------------------------
+    const size_t kbytes = (size_t)p.Nk * HD * 2;
+    __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + (size_t)bhk * p.Nk * HD), 0, (int)kbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vt + (size_t)bhk * HD * p.Nkpad), 0, (int)((size_t)HD * p.Nkpad * 2), 0x00020000);
+    // 18 one-KiB pieces per (K, V^T) tile pair: piece j < 9 = K bytes [1024 j, +1024), piece 9 + j = V^T rows 8j..8j+7.
+    // wave w owns pieces w, w + 8, w + 16 (< 18): waves 0,1 issue 3 per batch, the others 2.
+    const int vrow = lane >> 3;
+    auto stage_k = [&](int t, int slot, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, LDS_PTR(smem + K_BASE + slot * KTILE + j * 1024), 16,
+                                                 j * 1024 + lane * 16, t * KTILE, 0, 0);
+    };
+    auto stage_v = [&](int t, int slot, int j) {
+        const int d = 8 * j + vrow;
+        const int sc = (lane & 7) ^ ((d >> 1) & 7);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(smem + V_BASE + slot * VTILE + j * 1024), 16,
+                                                 d * p.Nkpad * 2 + sc * 16, t * 128, 0, 0);
+    };
+    auto stage_batch = [&](int tk, int tv) {  // K(tk) and V(tv) into their ring slots
+        // piece ids of this wave: wave (K piece), wave + 8 (K piece 8 for wave 0, else V piece wave - 1), wave + 16 (V 7, 8)
+        stage_k(tk, tk & 3, wave);                                  // pieces 0..7
+        if (wave == 0) stage_k(tk, tk & 3, 8);                      // piece 8
+        else stage_v(tv, tv & 3, wave - 1);                         // pieces 9..15 -> V rows of piece wave-1
+        if (wave < 2) stage_v(tv, tv & 3, 7 + wave);                // pieces 16, 17 -> V pieces 7, 8
+    };
+    const int ntile = (p.Nk + 63) / 64;
+    // prologue: K(0); K(1), V(0); K(2), V(1)  (what Y(-3), Y(-2), Y(-1) would have issued)
+    stage_k(0, 0, wave);
+    if (wave == 0) stage_k(0, 0, 8);
+    stage_batch(1, 0);
+    stage_batch(2, 1);
+
+    // ---- per-lane LDS read offsets ------------------------------------------------------------------
+    const int kb_lane = K_BASE + l31 * (HD * 2) + hi * 16;  // + slot * KTILE + kt2 * 32 * HD * 2 + s * 32 (s < 4)
+    int voff[DT][4];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        int d = dt * 32 + l31;
+        if (d > HD) d = HD;  // row HD is the row of ones; rows past it are never stored
+#pragma unroll
+        for (int g = 0; g < 4; ++g) voff[dt][g] = V_BASE + d * 128 + (((2 * g + hi) ^ ((d >> 1) & 7)) << 4);
+    }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    f32x16 sc[2];
+    bf16x8 pa[4];
+    float m_run = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // DMA landed, constant rows written
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // X phase: PV of the previous tile (P in pa, V^T slot vs) and QK^T of tile t (K slot ks)
+    auto phase_x = [&](int ks, int vs, bool do_pv, bool do_qk) {
+        __builtin_amdgcn_s_setprio(1);
+        if (do_qk) {
+            const char* kb = smem + ks * KTILE;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2) {
+                    bf16x8 kf;
+                    if (s < KS - 1) kf = *(const bf16x8*)(kb + kb_lane + kt2 * 32 * HD * 2 + s * 32);
+                    else kf = *(const bf16x8*)(hi ? (const char*)(smem + CONST_OFF) : (kb + kb_lane + kt2 * 32 * HD * 2 + s * 32));
+                    sc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? zero : sc[kt2], 0, 0, 0);
+                }
+            }
+        }
+        if (do_pv) {
+            const char* vb = smem + vs * VTILE;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vf = *(const bf16x8*)(vb + voff[dt][g]);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pa[g], o[dt], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // Y phase: softmax of the tile in sc -> pa
+    auto phase_y = [&](int t) {
+        if (t == ntile - 1 && (p.Nk & 63)) {  // partial last tile: keys past Nk get probability 0
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + 32 * kt2 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.Nk) sc[kt2][r] = -INFINITY;
+                }
+        }
+        float mx = fmaxf(sc[0][0], sc[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sc[0][r]), sc[1][r]);
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const bool first = (t == 0);
+        const bool raise = first || (mx > THR);
+        if (__builtin_expect(__any(raise), 0)) {
+            // new running max = m_run + mx (scores are relative to m_run already), rounded to the bf16 pair
+            // (hi + lo) the MFMA will actually subtract from now on; delta is the step between the two
+            // REPRESENTED values, so this tile's scores, O and all later tiles stay on one scale
+            const float nm = -(m_run + (raise ? mx : 0.f));
+            const float nm_hi = bfr(nm);
+            const float nm_lo = bfr(nm - nm_hi);
+            const float m_new = -(nm_hi + nm_lo);
+            const float delta = m_new - m_run;
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[kt2][r] -= delta;
+            if (hi) {  // pad slots 0 and 1 of the last k-step live on the hi half
+                qf[KS - 1][0] = (__bf16)nm_hi;
+                qf[KS - 1][1] = (__bf16)nm_lo;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pa[g][e] = (__bf16)__builtin_amdgcn_exp2f(sc[g >> 1][8 * (g & 1) + e]);
+        // keep the bf16 packing in THIS phase (hipcc otherwise sinks the cvt_pk next to the PV MFMAs of the X phase)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(pa[g]));
+    };
+
+    for (int t = 0; t < ntile; ++t) {
+        phase_x(t & 3, (t + 3) & 3, t > 0, true);
+        // K(t+1), V(t) must have landed before anybody's X(t+1); the batch issued in Y(t-1) may stay in flight
+        if (t + 1 < ntile) {
+            if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        bar();
+        phase_y(t);
+        if (t + 2 < ntile) stage_batch(t + 3, t + 2);
+        bar();
+    }
+    phase_x(0, (ntile + 3) & 3, true, false);  // PV of the last tile
+    if (grp == 0) bar();                       // the barrier group 1 still needs after its last Y phase
+
+    // l = O^T[HD][q] lives in register L_REG of tile L_DT on the hi == L_HI lane of this query row
+    const float l_tot = __shfl(o[L_DT][L_REG], l31 + 32 * L_HI, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        u16* orow = p.out + ((size_t)b * p.N + qrow) * ((size_t)p.H * HD) + (size_t)h * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int d0 = 32 * dt + 8 * q4 + 4 * hi;
+                if (d0 < HD) {
+                    u32x2 w = {pack2bf(o[dt][4 * q4] * inv, o[dt][4 * q4 + 1] * inv),
+                               pack2bf(o[dt][4 * q4 + 2] * inv, o[dt][4 * q4 + 3] * inv)};
+                    *(u32x2*)(orow + d0) = w;
+                }
+            }
+    }
+}
+
 }  // namespace
 
 static int g_attn_variant = 2;
@@ -461,7 +726,19 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     dim3 grid(a.B * a.H * nqb), block(256);
 #define LAUNCH_V1(HD_) hipLaunchKernelGGL(attn_fwd_kernel<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128), stream, a)
 #define LAUNCH_V2(HD_) hipLaunchKernelGGL(attn_fwd_kernel_v2<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128 + 128), stream, a)
-    const bool v2 = g_attn_variant == 2;
+    if (g_attn_variant == 3 && a.hd == 72 && a.bias == nullptr && !a.accumulate) {
+        constexpr int SMEM3 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16;
+        static bool attr_done = false;
+        if (!attr_done) {
+            LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<72>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3));
+            attr_done = true;
+        }
+        const int nqb3 = (a.N + 255) / 256;
+        hipLaunchKernelGGL(attn_fwd_kernel_v3<72>, dim3(a.B * a.H * nqb3), dim3(512), SMEM3, stream, a);
+        LT_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    const bool v2 = g_attn_variant >= 2;
     switch (a.hd) {
         case 48: if (v2) LAUNCH_V2(48); else LAUNCH_V1(48); break;
         case 72: if (v2) LAUNCH_V2(72); else LAUNCH_V1(72); break;

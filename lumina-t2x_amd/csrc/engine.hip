@@ -629,7 +629,8 @@ extern "C" int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t*
 
 extern "C" int lt_set_option(const char* name, int32_t value) {
     LT_REQUIRE(name, "lt_set_option: null name");
-    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value == 1 || value == 2, "attention_variant must be 1 or 2"); lt_set_attention_variant(value); return 0; }
+    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 3, "attention_variant must be 1, 2 or 3"); lt_set_attention_variant(value); return 0; }
+    if (strcmp(name, "gemm_pipeline") == 0) { LT_REQUIRE(value == 0 || value == 1, "gemm_pipeline must be 0 or 1"); lt_set_gemm_pipeline(value); return 0; }
     if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }
     lt_set_error("lt_set_option: unknown option '%s'", name);
     return 2;
@@ -643,6 +644,15 @@ extern "C" int lt_op_gemm_bf16(const void* A, const void* W, const void* bias, i
     g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = bias ? bias_dtype : -1;
     return launch_gemm_bf16(g, epilogue, variant, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_gemm_trace(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t variant,
+                                void* trace_dev, void* stream) {
+    LT_REQUIRE(A && W && C && trace_dev, "lt_op_gemm_trace: null pointer");
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = N; g.bias_dtype = -1; g.trace = (unsigned long long*)trace_dev;
+    return launch_gemm_bf16(g, 0, variant, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_pack_w13(const void* w1, const void* w3, void* out, int32_t F, int32_t K, void* stream) {

@@ -21,6 +21,7 @@
 //    grouped (4 tile-rows, column-major) order so neighbouring tiles share A/W panels in one L2.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -50,6 +51,72 @@ __device__ __forceinline__ float load_bias(const void* bias, int dt, int n) {
 // (named namespace: a __global__ template with internal linkage that is only instantiated from another
 //  template loses its host stub with hipcc 7.2)
 namespace lt_gemm {
+
+// ---- epilogue shared by both GEMM kernels: lane holds, per 32x32 tile, row m = l31 and columns 8q + 4hi + j (reg 4q+j) ----
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[MT][NT], const GemmArgs& p, int m0, int n0, int wm, int wn,
+                                           int hi, int l31) {
+    const size_t ldc = p.ldc;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * MT * 32 + mt * 32 + l31;
+        u16* crow = p.C + (size_t)m * ldc;
+        if (EPI == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nbase = n0 + wn * NT * 32 + nt * 32;
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = acc[mt][nt][8 * qp + j];
+                    if (p.bias_dtype >= 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            int n = nbase + 16 * qp + 8 * (j >> 2) + 4 * hi + (j & 3);
+                            n = n < p.N ? n : p.N - 1;  // clamped (branch-free); out-of-range columns are not stored
+                            v[j] += load_bias(p.bias, p.bias_dtype, n);
+                        }
+                    }
+                    unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
+                    unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    const int col = nbase + 16 * qp + 8 * hi;
+                    if (m < p.M && col < p.N) {
+                        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        *(u32x4*)(crow + col) = o;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int np = 0; np < NT / 2; ++np) {
+                const int obase = (n0 + wn * NT * 32 + np * 64) / 2;
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
+                        const float a = bfr(acc[mt][2 * np][8 * qp + j]);
+                        const float b = bfr(acc[mt][2 * np + 1][8 * qp + j]);
+                        v[j] = bfr(silu_f(a)) * b;
+                    }
+                    unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
+                    unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    const int col = obase + 16 * qp + 8 * hi;
+                    if (m < p.M && col < p.N / 2) {
+                        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        *(u32x4*)(crow + col) = o;
+                    }
+                }
+            }
+        }
+    }
+}
 
 // WM x WN waves, each owning an (MT*32) x (NT*32) block of C.  Tile = (WM*MT*32) x (WN*NT*32) x 64.
 //   <2,4,4,2>: 256 x 256, 8 waves  (128 accumulators / lane)  - default and the SwiGLU epilogue
@@ -149,78 +216,249 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_tn(G
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds, per 32x32 tile, row m = l31 and columns 8q + 4hi + j (reg 4q+j) ----
-    const size_t ldc = p.ldc;
+    store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
+}
+
+
+// ---- ping-pong kernel ---------------------------------------------------------------------------------
+// Same tile shapes and fragment/epilogue layout as gemm_bf16_tn, different time structure.  The workgroup's
+// waves form G = NW/4 groups (group = wave / 4, i.e. the G waves that share one SIMD belong to G different
+// groups).  K is consumed in 32-deep slabs held in a 4-slot LDS ring (64-byte rows, XOR swizzle on the two
+// chunk-index bits).  Per slab every wave runs
+//        READ  (fragment ds_reads of slab s, counted vmcnt for slab s+1, lgkmcnt(0))   | s_barrier
+//        MFMA  (all MFMAs of slab s, with the LDS-DMA of slab s+3 issued between them)   | s_barrier  [+ G-2 idle]
+// and group g starts g barrier intervals late, so on every SIMD exactly one wave is in its MFMA segment while
+// the others read / wait: the matrix pipe sees back-to-back MFMA segments and no wave ever drains vmcnt to 0
+// in the main loop (LDS-DMA stays in flight across barriers; guide T3/T4, "Pipelining across barriers").
+//
+// Hazards, in barrier-interval units (READ(s) of group g runs in interval G*s + g, MFMA(s) one later):
+//   RAW  slab s+1 is waited for (each wave: its own pieces) in READ(s), interval G*s+g, and first read in
+//        READ(s+1), interval G*s+G+g' > G*s+g for all g, g'  -> a barrier every wave has passed lies between.
+//   WAR  slab s+4 reuses the slot of slab s; it is issued in MFMA(s+1), interval G*s+G+g+1, while the last
+//        read of slab s completed (lgkmcnt(0) before the barrier) in interval G*s+g' <= G*s+G-1.
+#define LT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 8, "vmcnt literal table");
+    if constexpr (N == 0) LT_WAIT_VM(0);
+    else if constexpr (N == 1) LT_WAIT_VM(1);
+    else if constexpr (N == 2) LT_WAIT_VM(2);
+    else if constexpr (N == 3) LT_WAIT_VM(3);
+    else if constexpr (N == 4) LT_WAIT_VM(4);
+    else if constexpr (N == 5) LT_WAIT_VM(5);
+    else if constexpr (N == 6) LT_WAIT_VM(6);
+    else if constexpr (N == 7) LT_WAIT_VM(7);
+    else LT_WAIT_VM(8);
+}
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(GemmArgs p) {
+    constexpr int NW = WM * WN, G = NW / 4;
+    static_assert(NW % 4 == 0 && G >= 2 && G <= 3, "ping-pong needs 2 or 3 waves per SIMD");
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int PA = BM / 16, PW = BN / 16, NP = PA + PW;  // 1-KiB pieces (16 rows x 64 B) per slab
+    constexpr int IP = (NP + NW - 1) / NW;                   // pieces per wave per slab (same for every wave)
+    constexpr int SLAB = (BM + BN) * 64, W_OFF = BM * 64;
+    static_assert(EPI == 0 || NT % 2 == 0, "SwiGLU epilogue pairs accumulator tiles");
+    static_assert(IP <= 4, "staging pieces per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, TM, TN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const long long a_left = (long long)(p.M - m0) * p.lda * 2;
+    const long long w_left = (long long)(p.N - n0) * p.ldw * 2;
+    const int a_bytes = (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left);
+    const int w_bytes = (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left);
+    const u16* a_base = p.A + (size_t)m0 * p.lda;
+    const u16* w_base = p.W + (size_t)n0 * p.ldw;
+
+    // staging: wave w owns pieces w, w + NW, ... (a surplus slot re-loads the wave's previous piece: same bytes
+    // to the same place, so every wave issues exactly IP loads per slab and one vmcnt literal fits all).
+    // Piece q holds rows 16q..16q+15 of A (q < PA) or of W; lane -> row 16q + lane/4, 16-byte position lane%4,
+    // fetched from source chunk pos ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3).
+    const int sswz = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+    __amdgpu_buffer_rsrc_t rs[4];
+    int voff[4], ldsoff[4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wm * MT * 32 + mt * 32 + l31;
-        u16* crow = p.C + (size_t)m * ldc;
-        if (EPI == 0) {
+    for (int i = 0; i < IP; ++i) {
+        int q = wave + NW * i;
+        if (q >= NP) q -= NW;
+        const bool isA = q < PA;
+        const int r0 = 16 * (isA ? q : q - PA) + (lane >> 2);
+        rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(isA ? a_base : w_base), 0, isA ? a_bytes : w_bytes, 0x00020000);
+        voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + sswz;
+        ldsoff[i] = q * 1024;
+    }
+    auto stage = [&](int slab) {
+        char* base = smem + (slab & 3) * SLAB;
+        const int soff = slab * 64;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int nbase = n0 + wn * NT * 32 + nt * 32;
+        for (int i = 0; i < IP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i], LDS_PTR(base + ldsoff[i]), 16, voff[i], soff, 0, 0);
+    };
+
+    const int fswz = (l31 >> 2) & 3;
+    const int a_row_off = (wm * MT * 32 + l31) * 64;
+    const int w_row_off = W_OFF + (wn * NT * 32 + l31) * 64;
+    int coff[2];
 #pragma unroll
-                for (int qp = 0; qp < 2; ++qp) {
-                    float v[8];
+    for (int s = 0; s < 2; ++s) coff[s] = ((2 * s + hi) ^ fswz) << 4;
+
+    f32x16 acc[MT][NT];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = acc[mt][nt][8 * qp + j];
-                    if (p.bias_dtype >= 0) {
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            int n = nbase + 16 * qp + 8 * (j >> 2) + 4 * hi + (j & 3);
-                            n = n < p.N ? n : p.N - 1;  // clamped (branch-free); out-of-range columns are not stored
-                            v[j] += load_bias(p.bias, p.bias_dtype, n);
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ns = p.K / 32;
+    // prologue: slabs 0..2 in flight, slab 0 landed and visible
+    stage(0);
+    if (ns > 1) stage(1);
+    if (ns > 2) stage(2);
+    if (ns > 2) wait_vmcnt<2 * IP>();
+    else if (ns > 1) wait_vmcnt<IP>();
+    else wait_vmcnt<0>();
+    pp_barrier();
+    for (int g = 0; g < grp; ++g) pp_barrier();
+
+    bf16x8 wf[2][NT], af[2][MT];
+    // TRACE build only: per-wave cycle totals of the six sub-segments of a step (s_memtime stamps)
+    unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, ta = 0, tb = 0, tc = 0;
+    unsigned long long tstart = 0;
+    if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
+    auto read_seg = [&](int s) {
+        const char* sb = smem + (s & 3) * SLAB;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * 2048 + coff[k]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * 2048 + coff[k]);
+        }
+        if constexpr (TRACE) ta = __builtin_amdgcn_s_memtime();
+        if (s + 2 < ns) wait_vmcnt<IP>();  // slab s+1 landed (slab s+2 may still be in flight)
+        else wait_vmcnt<0>();
+        if constexpr (TRACE) tb = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (TRACE) {
+            tc = __builtin_amdgcn_s_memtime();
+            tr[0] += ta - tprev; tr[1] += tb - ta; tr[2] += tc - tb;
+        }
+        pp_barrier();
+        if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); }
+    };
+    auto mfma_seg = [&](int s, auto do_stage) {
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int NM = 2 * MT * NT;                 // MFMAs of this segment
+        constexpr int EVERY = NM / (IP + 1) > 0 ? NM / (IP + 1) : 1;
+        int issued = 0, cnt = 0;
+        char* base = smem + ((s + 3) & 3) * SLAB;
+        const int soff = (s + 3) * 64;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], af[k][mt], acc[mt][nt], 0, 0, 0);
+                    ++cnt;
+                    if constexpr (decltype(do_stage)::value) {
+                        if (cnt % EVERY == 0 && issued < IP) {
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[issued], LDS_PTR(base + ldsoff[issued]), 16,
+                                                                     voff[issued], soff, 0, 0);
+                            ++issued;
                         }
                     }
-                    unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
-                    unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
-                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                    const int col = nbase + 16 * qp + 8 * hi;
-                    if (m < p.M && col < p.N) {
-                        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                        *(u32x4*)(crow + col) = o;
-                    }
                 }
+        if constexpr (decltype(do_stage)::value) {
+            // pin the interleave: EVERY MFMAs, one LDS-DMA issue, ... (a clustered burst of DMA issues would
+            // starve the matrix pipe of this in-order wave for a few hundred cycles)
+#pragma unroll
+            for (int i = 0; i < IP; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, EVERY, 0);
+                __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
             }
-        } else {
+            __builtin_amdgcn_sched_group_barrier(0x8, NM - IP * EVERY, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (TRACE) {
+            __builtin_amdgcn_sched_barrier(0);
+            ta = __builtin_amdgcn_s_memtime();
+            tr[3] += tprev - tc; tr[4] += ta - tprev;
+            tprev = ta;
+        }
+    };
+    auto trace_gap = [&]() {  // after the post-MFMA barrier(s)
+        if constexpr (TRACE) {
+            ta = __builtin_amdgcn_s_memtime();
+            tr[5] += ta - tprev;
+            tprev = ta;
+        }
+    };
+
+    int s = 0;
+    for (; s + 3 < ns; ++s) {
+        read_seg(s);
+        mfma_seg(s, std::true_type{});
+        pp_barrier();
 #pragma unroll
-            for (int np = 0; np < NT / 2; ++np) {
-                const int obase = (n0 + wn * NT * 32 + np * 64) / 2;
+        for (int g = 0; g < G - 2; ++g) pp_barrier();
+        trace_gap();
+    }
+    for (; s < ns; ++s) {
+        read_seg(s);
+        mfma_seg(s, std::false_type{});
+        if (s + 1 < ns) {
+            pp_barrier();
 #pragma unroll
-                for (int qp = 0; qp < 2; ++qp) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
-                        const float a = bfr(acc[mt][2 * np][8 * qp + j]);
-                        const float b = bfr(acc[mt][2 * np + 1][8 * qp + j]);
-                        v[j] = bfr(silu_f(a)) * b;
-                    }
-                    unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
-                    unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
-                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                    const int col = obase + 16 * qp + 8 * hi;
-                    if (m < p.M && col < p.N / 2) {
-                        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                        *(u32x4*)(crow + col) = o;
-                    }
-                }
-            }
+            for (int g = 0; g < G - 2; ++g) pp_barrier();
         }
     }
+    for (int g = grp; g < G - 1; ++g) pp_barrier();  // equalise barrier counts before the (barrier-free) epilogue
+    if constexpr (TRACE) {
+        if (p.trace && lane == 0 && (blockIdx.x & 63) == 5) {
+            unsigned long long* o = p.trace + ((size_t)(blockIdx.x >> 6) * NW + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] = tr[i];
+            o[6] = (unsigned long long)ns;
+            o[7] = __builtin_amdgcn_s_memtime() - tstart;
+        }
+    }
+
+    store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
 }
 
 // explicit instantiations (hipcc 7.2 does not emit the kernel body for address-only uses inside another template)
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 1>(GemmArgs);
 template __global__ void gemm_bf16_tn<4, 3, 2, 3, 0>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1>(GemmArgs);
+template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true>(GemmArgs);
+template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0, true>(GemmArgs);
 
 }  // namespace lt_gemm
 
 namespace {
 using lt_gemm::gemm_bf16_tn;
+using lt_gemm::gemm_bf16_pp;
 
 // w1/w3 -> 32-row interleaved packed weight (row P: block = P/64; P%64 < 32 -> w1 else w3)
 __global__ void pack_w13_kernel(const u16* __restrict__ w1, const u16* __restrict__ w3, u16* __restrict__ out,
@@ -239,17 +477,19 @@ __global__ void pack_w13_kernel(const u16* __restrict__ w1, const u16* __restric
 }  // namespace
 
 namespace {
-template <int WM, int WN, int MT, int NT, int EPI>
+template <int WM, int WN, int MT, int NT, int EPI, bool PP>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
-    constexpr int BM = WM * MT * 32, BN = WN * NT * 32, SMEM = 2 * (BM + BN) * 128;
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int SMEM = PP ? 4 * (BM + BN) * 64 : 2 * (BM + BN) * 128;
+    const void* fn = PP ? (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI> : (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
-        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        LT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_done = true;
     }
     const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
+    if (PP) hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
+    else hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -266,17 +506,37 @@ int num_cus() {
 }
 }  // namespace
 
-static int g_gemm_variant = 0;
+static int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 256x256, 2 = 256x288
+static int g_gemm_pipeline = 0;  // time structure when the caller passes variant <= 2: 0 classic, 1 ping-pong
 void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
+void lt_set_gemm_pipeline(int v) { g_gemm_pipeline = v; }
 
-// variant: 0 = pick the tile shape that minimises (rounds over the CUs) x (tile width); 1 = 256x256; 2 = 256x288
+// variant: 0 = pick the tile shape that minimises (rounds over the CUs) x (tile width); 1 = 256x256; 2 = 256x288;
+//          3 / 4 = the same two shapes with the ping-pong kernel regardless of the process-wide pipeline option
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream) {
     LT_REQUIRE(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 2, "gemm: unknown variant %d", variant);
-    if (epilogue == 1) return launch_cfg<2, 4, 4, 2, 1>(a, stream);
+    LT_REQUIRE(variant >= 0 && variant <= 4, "gemm: unknown variant %d", variant);
+    bool pp = g_gemm_pipeline == 1;
+    if (variant >= 3) { pp = true; variant -= 2; }
+    if (a.trace) {  // diagnostic build of the ping-pong kernel with s_memtime stamps (scripts/gemm_trace.py)
+        LT_REQUIRE(epilogue == 0 && (variant == 1 || variant == 2), "gemm trace: plain epilogue, explicit tile shape");
+        constexpr int S1 = 4 * 512 * 64, S2 = 4 * 544 * 64;
+        static bool done = false;
+        if (!done) {
+            LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp<2, 4, 4, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, S1));
+            LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp<4, 3, 2, 3, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, S2));
+            done = true;
+        }
+        const int TMx = (a.M + 255) / 256;
+        if (variant == 1) hipLaunchKernelGGL((gemm_bf16_pp<2, 4, 4, 2, 0, true>), dim3(TMx * ((a.N + 255) / 256)), dim3(512), S1, stream, a);
+        else hipLaunchKernelGGL((gemm_bf16_pp<4, 3, 2, 3, 0, true>), dim3(TMx * ((a.N + 287) / 288)), dim3(768), S2, stream, a);
+        LT_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    if (epilogue == 1) return pp ? launch_cfg<2, 4, 4, 2, 1, true>(a, stream) : launch_cfg<2, 4, 4, 2, 1, false>(a, stream);
     if (variant == 0) variant = g_gemm_variant;
     if (variant == 0) {
         const int cus = num_cus();
@@ -285,8 +545,8 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
         const long long c256 = ((t256 + cus - 1) / cus) * 256, c288 = ((t288 + cus - 1) / cus) * 288;
         variant = c288 < c256 ? 2 : 1;
     }
-    if (variant == 2) return launch_cfg<4, 3, 2, 3, 0>(a, stream);
-    return launch_cfg<2, 4, 4, 2, 0>(a, stream);
+    if (variant == 2) return pp ? launch_cfg<4, 3, 2, 3, 0, true>(a, stream) : launch_cfg<4, 3, 2, 3, 0, false>(a, stream);
+    return pp ? launch_cfg<2, 4, 4, 2, 0, true>(a, stream) : launch_cfg<2, 4, 4, 2, 0, false>(a, stream);
 }
 
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream) {

@@ -12,6 +12,7 @@ struct GemmArgs {
     int M, N, K;
     int lda, ldw, ldc;
     int bias_dtype;    // -1 none, 0 f32, 1 bf16
+    unsigned long long* trace = nullptr;  // diagnostics only (lt_op_gemm_trace): per-wave cycle totals
 };
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream);
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream);
@@ -74,6 +75,7 @@ struct AttnArgs {
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
+void lt_set_gemm_pipeline(int v);      // 0 = classic double-buffered loop, 1 = ping-pong wave groups
 
 // ---- small kernels (misc.hip) ------------------------------------------------------------------
 int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int M, int N, int K, int act_in,

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Diagnostics (GPU box): per-wave cycle breakdown of the ping-pong GEMM from its s_memtime-instrumented build."""
+import math
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from gpu_util import P, lib, ok, stream  # noqa: E402
+
+L = lib()
+names = ["ds_issue", "vm_wait", "lgkm_wait", "bar1", "mfma", "bar2"]
+for (M, N, K, variant, nw) in [(8192, 6912, 2304, 3, 8), (8192, 2304, 6144, 4, 12), (8192, 6912, 2304, 4, 12)]:
+    A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(torch.bfloat16)
+    Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    tr = torch.zeros(64, nw, 8, device="cuda", dtype=torch.int64)
+    for _ in range(2):
+        ok(L.lt_op_gemm_trace(P(A), P(W), P(Cc), M, N, K, variant, P(tr), stream()))
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    walls = {}
+    for nm, fn in (("traced", lambda: L.lt_op_gemm_trace(P(A), P(W), P(Cc), M, N, K, variant, P(tr), stream())),
+                   ("untraced", lambda: L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(Cc), M, N, K, 0, variant, stream())),
+                   ("classic", lambda: L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(Cc), M, N, K, 0, variant - 2, stream()))):
+        for _ in range(3):
+            fn()
+        st.record()
+        for _ in range(10):
+            fn()
+        en.record()
+        torch.cuda.synchronize()
+        walls[nm] = st.elapsed_time(en) / 10 * 1e3
+    t = tr.cpu()
+    bm, bn = (256, 256) if variant == 3 else (256, 288)
+    tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+    rounds = (tiles + 255) // 256
+    blk_cyc = float(t[0, 0, 7])
+    print(f"== M{M} N{N} K{K} variant {variant}: slabs {int(t[0,0,6])} tiles {tiles} rounds {rounds}; wall us {walls}; "
+          f"main-loop cycles of one traced block {blk_cyc:.0f} -> implied clock >= {rounds * blk_cyc / walls['traced'] / 1e3:.2f} GHz")
+    for blk in range(0, min(4, t.shape[0])):
+        if int(t[blk, 0, 6]) == 0:
+            continue
+        for w in range(nw):
+            per = [float(t[blk, w, i]) / float(t[blk, w, 6]) for i in range(6)]
+            print(f"  blk {blk*64+5:4d} wave {w:2d} grp {w//4}: " + " ".join(f"{n} {v:6.0f}" for n, v in zip(names, per)) + f" | step {sum(per):6.0f} cyc")

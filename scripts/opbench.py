@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""Operator-level A/B bench on the GPU box (not part of the product): times each hot kernel through the C ABI at
+the cfg-2 shapes, variants interleaved in one process (guide 5.4 rule 24), random data (rule 25), median + min.
+
+    python scripts/opbench.py gemm attn elem [--rounds 7]
+"""
+import argparse
+import ctypes as C
+import math
+import os
+import statistics
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from gpu_util import P, bf, lib, ok, rel_l2, set_option, stream  # noqa: E402
+
+
+def timeit(fn, iters=5):
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters
+
+
+def ab(cases, rounds):
+    """cases: {name: fn}; interleaved rounds -> {name: (median_ms, min_ms)}"""
+    for fn in cases.values():
+        fn()
+    torch.cuda.synchronize()
+    res = {k: [] for k in cases}
+    for _ in range(rounds):
+        for k, fn in cases.items():
+            res[k].append(timeit(fn))
+    return {k: (statistics.median(v), min(v)) for k, v in res.items()}
+
+
+def bench_gemm(rounds, variants):
+    L = lib()
+    shapes = [("qkv", 8192, 6912, 2304, 0), ("wo", 8192, 2304, 2304, 0), ("w13", 8192, 12288, 2304, 1),
+              ("w2", 8192, 2304, 6144, 0)]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    tot = {v: 0.0 for v in variants}
+    for name, M, N, K, epi in shapes:
+        A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        outs = {}
+        cases = {}
+        for v in variants:
+            out = torch.empty(M, N // 2 if epi else N, device="cuda", dtype=torch.bfloat16)
+            outs[v] = out
+
+            def fn(v=v, out=out):
+                ok(L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(out), M, N, K, epi, v, stream()), "gemm")
+            cases[v] = fn
+        r = ab(cases, rounds)
+        ref = outs[variants[0]].float()
+        fl = 2.0 * M * N * K
+        for v in variants:
+            med, mn = r[v]
+            err = rel_l2(outs[v], ref) if v != variants[0] else 0.0
+            tot[v] += med
+            print(f"gemm {name:4s} M{M} N{N} K{K} epi{epi} variant {v}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s"
+                  f"  (best {fl/mn/1e9:7.1f})  rel-vs-v{variants[0]} {err:.2e}", flush=True)
+    fl_layer = 2.0 * 8192 * 2304 * (6912 + 2304 + 12288 + 6144)
+    for v in variants:
+        print(f"gemm per-layer total variant {v}: {tot[v]*1e3:8.1f} us  -> {fl_layer/tot[v]/1e9:7.1f} TF/s ; x24 = {tot[v]*24:.2f} ms/NFE")
+
+
+def bench_attn(rounds, variants):
+    L = lib()
+    B, H, N, hd = 2, 32, 4096, 72
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qkv = torch.randn(B * N, 3 * H * hd, device="cuda", generator=g).to(torch.bfloat16)
+    q = torch.empty(B, H, N, hd, device="cuda", dtype=torch.bfloat16)
+    k = torch.empty_like(q)
+    vt = torch.empty(B, H, hd, N, device="cuda", dtype=torch.bfloat16)
+    ok(L.lt_op_qk_norm_rope(P(qkv), 3 * H * hd, 0, P(None), P(None), C.c_float(1e-5), P(q), B, N, H, hd, 0, P(None), 64, stream()))
+    ok(L.lt_op_qk_norm_rope(P(qkv), 3 * H * hd, H * hd, P(None), P(None), C.c_float(1e-5), P(k), B, N, H, hd, 0, P(None), 64, stream()))
+    ok(L.lt_op_v_transpose(P(qkv), 3 * H * hd, 2 * H * hd, P(vt), B, N, N, H, hd, stream()))
+    scale = 1.0 / math.sqrt(hd)
+    outs, cases = {}, {}
+    for v in variants:
+        out = torch.empty(B, N, H * hd, device="cuda", dtype=torch.bfloat16)
+        outs[v] = out
+
+        def fn(v=v, out=out):
+            set_option("attention_variant", v)
+            ok(L.lt_op_attention(P(q), P(k), P(vt), None, P(out), P(None), 0, B, H, H, N, N, N, hd, C.c_float(scale), stream()))
+        cases[v] = fn
+    r = ab(cases, rounds)
+    fl = 4.0 * B * H * N * N * hd
+    # fp32 reference for one head
+    qh = q[0, 0].float()
+    kh = k[0, 0].float()
+    vh = qkv.view(B, N, 3, H, hd)[0, :, 2, 0].float()
+    ref = torch.softmax(qh @ kh.t() * scale, -1) @ vh
+    for v in variants:
+        med, mn = r[v]
+        err = rel_l2(outs[v].view(B, N, H, hd)[0, :, 0], ref)
+        print(f"attn B{B} H{H} N{N} hd{hd} variant {v}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s (best {fl/mn/1e9:7.1f})"
+              f"  rel-L2 head0 vs fp32 {err:.2e}", flush=True)
+    set_option("attention_variant", 2)
+
+
+def bench_elem(rounds):
+    L = lib()
+    B, N, d = 2, 4096, 2304
+    M = B * N
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(M, d, device="cuda", generator=g).to(torch.bfloat16)
+    y = torch.randn(M, d, device="cuda", generator=g).to(torch.bfloat16)
+    h = torch.empty_like(x)
+    w = torch.ones(d, device="cuda", dtype=torch.bfloat16)
+    mod = (0.1 * torch.randn(B, 4 * d, device="cuda", generator=g)).to(torch.bfloat16)
+    qkv = torch.randn(M, 3 * d, device="cuda", generator=g).to(torch.bfloat16)
+    q = torch.empty(B, 32, N, 72, device="cuda", dtype=torch.bfloat16)
+    vt = torch.empty(B, 32, 72, N, device="cuda", dtype=torch.bfloat16)
+    tab = torch.zeros(2, 384, 18, 2, device="cuda", dtype=torch.float32)
+    ok(L.lt_op_rope_table_2d(P(tab), 384, 72, C.c_float(10000.0), C.c_float(1.0), stream()))
+
+    def grn():
+        ok(L.lt_op_gated_residual_norm(P(x), P(y), P(w), P(mod), 1, 1, P(w), P(mod[:, d:]), P(None), 1, 4 * d, P(h), B, N, d,
+                                       C.c_float(1e-5), C.c_float(1e-6), stream()))
+
+    def qkn():
+        ok(L.lt_op_qk_norm_rope(P(qkv), 3 * d, 0, P(w), P(w), C.c_float(1e-5), P(q), B, N, 32, 72, 1, P(tab), 64, stream()))
+
+    def vtr():
+        ok(L.lt_op_v_transpose(P(qkv), 3 * d, 2 * d, P(vt), B, N, N, 32, 72, stream()))
+
+    r = ab({"gated_residual_norm": grn, "qk_norm_rope": qkn, "v_transpose": vtr}, rounds)
+    bytes_ = {"gated_residual_norm": 4 * M * d * 2, "qk_norm_rope": 2 * M * d * 2, "v_transpose": 2 * M * d * 2}
+    for kname, (med, mn) in r.items():
+        print(f"elem {kname:22s}: median {med*1e3:7.1f} us  {bytes_[kname]/med/1e9:6.2f} TB/s algorithmic", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["gemm", "attn", "elem"])
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--gemm-variants", type=str, default="1,2,3,4")
+    ap.add_argument("--attn-variants", type=str, default="1,2")
+    a = ap.parse_args()
+    print("device:", torch.cuda.get_device_name(0), flush=True)
+    if "gemm" in a.what:
+        bench_gemm(a.rounds, [int(v) for v in a.gemm_variants.split(",")])
+    if "attn" in a.what:
+        bench_attn(a.rounds, [int(v) for v in a.attn_variants.split(",")])
+    if "elem" in a.what:
+        bench_elem(a.rounds)

@@ -44,10 +44,12 @@ def test_gemm_plain(M, N, K):
     assert max_abs(out, ref) < 0.04 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-@pytest.mark.parametrize("M,N,K", [(8192, 2304, 2304), (300, 576, 128), (1024, 6912, 2304), (256, 288, 64), (257, 296, 192)])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(8192, 2304, 2304), (300, 576, 128), (1024, 6912, 2304), (256, 288, 64), (257, 296, 192),
+                                   (512, 512, 6144)])
 def test_gemm_tile_variants(variant, M, N, K):
-    """both tile shapes (256x256 / 8 waves, 256x288 / 12 waves) on tile-multiple and ragged problems"""
+    """both tile shapes (256x256 / 8 waves, 256x288 / 12 waves) x both pipelines (classic double buffer, ping-pong wave
+    groups = variants 3 / 4) on tile-multiple and ragged problems; K = 64 ... 6144 covers 2 ... 192 ring slabs"""
     g = torch.Generator(device="cpu").manual_seed(M + N + K + variant)
     A = bf(torch.randn(M, K, generator=g))
     W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
@@ -58,7 +60,7 @@ def test_gemm_tile_variants(variant, M, N, K):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_gemm_identity_asymmetric(variant):
     """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
     K, N = 320, 576
@@ -83,15 +85,16 @@ def test_gemm_bias_and_edges():
     assert torch.all(big[200:] == 7.0)
 
 
+@pytest.mark.parametrize("variant", [1, 3])
 @pytest.mark.parametrize("M,F_,K", [(256, 128, 64), (300, 1536, 576), (4096, 6144, 2304)])
-def test_gemm_swiglu(M, F_, K):
+def test_gemm_swiglu(M, F_, K, variant):
     g = torch.Generator().manual_seed(F_ + K)
     A = bf(torch.randn(M, K, generator=g))
     w1 = bf(torch.randn(F_, K, generator=g) / math.sqrt(K))
     w3 = bf(torch.randn(F_, K, generator=g) / math.sqrt(K))
     packed = torch.empty(2 * F_, K, device="cuda", dtype=torch.bfloat16)
     ok(lib().lt_op_pack_w13(P(w1), P(w3), P(packed), F_, K, stream()))
-    out = _gemm(A, packed, None, 1)
+    out = _gemm(A, packed, None, 1, variant=variant)
     a = r16(A.float() @ w1.float().t())
     b = r16(A.float() @ w3.float().t())
     ref = r16(r16(F.silu(a)) * b)
@@ -232,9 +235,10 @@ def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None):
     return out.view(B, N, H, hd).permute(0, 2, 1, 3)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("B,H,Hkv,N,hd", [(1, 8, 8, 128, 72), (2, 8, 2, 320, 72), (2, 4, 4, 200, 72), (1, 3, 3, 64, 72),
-                                          (2, 32, 32, 4096, 72), (1, 8, 8, 256, 48), (1, 8, 8, 192, 96)])
+                                          (2, 32, 32, 4096, 72), (1, 8, 8, 256, 48), (1, 8, 8, 192, 96),
+                                          (1, 8, 8, 1000, 72), (1, 2, 2, 40, 72)])
 def test_attention_self(variant, B, H, Hkv, N, hd):
     set_option("attention_variant", variant)
     g = torch.Generator().manual_seed(N + hd)
@@ -248,10 +252,11 @@ def test_attention_self(variant, B, H, Hkv, N, hd):
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_attention_softmax_outlier_keys(variant):
     """forces large running-max jumps mid-sequence, above and below the deferred-rescale threshold (guide 5.4
-    rule 26); v1 (rescale every tile) and v2 (threshold 8 in log2 units) must both match the exact softmax"""
+    rule 26); v1 (rescale every tile), v2 (threshold 8 in log2 units) and v3 (same threshold, max folded into the
+    QK^T MFMA as a bf16 pair) must all match the exact softmax"""
     set_option("attention_variant", variant)
     B, H, N, hd = 1, 8, 256, 72
     g = torch.Generator().manual_seed(9)
@@ -261,6 +266,7 @@ def test_attention_softmax_outlier_keys(variant):
     k[:, :, 131] = q[:, :, 7] * 4.0
     k[:, :, 3] = q[:, :, 200] * 2.0
     k[:, :, 70] = q[:, :, 100] * 0.35   # raises the row max by less than the threshold: stays un-rescaled
+    k[:, :, :64] -= q[:, :, 50:51] * 3.0  # first tile far BELOW later ones for row 50 (and shifted for all rows)
     out = _run_attn(q, k, v, 1 / math.sqrt(hd))
     ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), 1 / math.sqrt(hd))
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
