@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gqa", action="store_true", help="NextDiT_2B_GQA_patch2 instead of the MHA model")
-    ap.add_argument("--attn-variant", type=int, default=None, help="A/B knob: 1 baseline, 2 VALU-diet (default)")
+    ap.add_argument("--attn-variant", type=int, default=None, help="A/B knob: 1 baseline, 2 VALU-diet, 3 ping-pong (default)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B knob: 0 auto (default), 1 256x256, 2 256x288")
     args = ap.parse_args()
     from lumina_t2x_amd import _lib
@@ -199,7 +199,7 @@ def main():
             "kernel_time_ms_per_step": {"gemm": gemm_ms / args.steps, "attention": attn_ms / args.steps,
                                         "other": oth_ms / args.steps},
             "attention_tflops_per_s": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0,
-            "kernel_variants": {"attention": args.attn_variant or 2, "gemm": args.gemm_variant or 0},
+            "kernel_variants": {"attention": args.attn_variant or 3, "gemm": args.gemm_variant or 0},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -164,22 +164,30 @@ int lt_op_gated_residual_norm(void* x_dev, const void* y_dev, const void* post_w
 /* q/k post-processing (model.py:361-371): affine LayerNorm over the full width (optional), 2-D or
  * 1-D RoPE, cast bf16, write head-major [B,heads,N,hd].  src bf16 [B*N, ld_src] at column col0.
  * rope_mode 0 none, 1 2-D interleaved (Next-DiT, model.py:959-961), 2 1-D (Flag-DiT).
- * cs_table_dev float2 [pos][hd/4 or hd/2] (cos,sin); grid_w = latent tokens per row. */
+ * cs_table_dev float2 [pos][hd/4 or hd/2] (cos,sin); grid_w = latent tokens per row.  out_scale multiplies the
+ * result before that one rounding (1.0 = reference layout; the engine folds softmax_scale * log2(e) into K). */
 int lt_op_qk_norm_rope(const void* src_dev, int32_t ld_src, int32_t col0, const void* ln_w_dev,
                        const void* ln_b_dev, float ln_eps, void* dst_dev, int32_t B, int32_t N,
                        int32_t heads, int32_t hd, int32_t rope_mode, const void* cs_table_dev,
-                       int32_t grid_w, void* stream);
+                       int32_t grid_w, float out_scale, void* stream);
 /* V -> transposed, key-permuted layout the attention kernel consumes: [B,kvh,hd,Npad] */
 int lt_op_v_transpose(const void* src_dev, int32_t ld_src, int32_t col0, void* dst_dev, int32_t B,
                       int32_t N, int32_t Npad, int32_t kv_heads, int32_t hd, void* stream);
 /* non-causal softmax(q k^T * scale + bias) v  (model.py:392-405 / 427-432).
  * q [B,H,N,hd], k [B,Hkv,Nk,hd], vt [B,Hkv,hd,Nkpad] (lt_op_v_transpose layout), bias float
  * [B,Nkpad] or NULL (0 / -inf per key), out bf16 [B,N,H*hd].
- * accumulate != 0: out = out + tanh(gate[h]) * result (model.py:433-434), gate bf16 [H]. */
+ * accumulate != 0: out = out + tanh(gate[h]) * result (model.py:433-434), gate bf16 [H].
+ * k_prescaled != 0: k already carries scale * log2(e) (lt_op_qk_norm_rope out_scale) and `scale` is not applied again. */
 int lt_op_attention(const void* q_dev, const void* k_dev, const void* vt_dev, const float* bias_dev,
                     void* out_dev, const void* gate_dev, int32_t accumulate, int32_t B, int32_t H,
                     int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t hd, float scale,
-                    void* stream);
+                    int32_t k_prescaled, void* stream);
+/* diagnostics: the hd-72 self-attention kernel (variant 3) built with s_memtime stamps; trace_dev receives, for every
+ * 64th workgroup and each of its 8 waves, 8 x uint64: cycle totals of {X phase (MFMA), DMA wait, barrier, Y phase
+ * (softmax + DMA issue), barrier}, the tile count. */
+int lt_op_attention_trace(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int32_t B,
+                          int32_t H, int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t hd, float scale,
+                          void* trace_dev, void* stream);
 /* y[m,n] = sum_k act(a[m,k]) w[n,k] + b[n], m < M <= 8 (GEMV-style; adaLN / embedders).
  * act_in 0 none, 1 SiLU.  a bf16 [M,K], w bf16 [N,K], b bf16 [N] or NULL, y bf16 [M,N]. */
 int lt_op_linear_small_m(const void* a_dev, const void* w_dev, const void* b_dev, void* y_dev,

@@ -17,6 +17,7 @@
 //  * workgroup -> (head, q-block) map keeps all q-blocks of a head on one XCD (private L2) in order.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int g = 0; g < 4; ++g) voff[dt][g] = d * 128 + (((2 * g + hi) ^ ((d >> 1) & 7)) << 4);
     }
 
-    const float sl2 = p.scale * 1.44269504088896340736f;  // work in the log2 domain
+    const float sl2 = p.k_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;  // work in the log2 domain
     f32x16 o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel_v2(AttnArgs p) {
         for (int g = 0; g < 4; ++g) voff[dt][g] = d * 128 + (((2 * g + hi) ^ ((d >> 1) & 7)) << 4);
     }
 
-    const float sl2 = p.scale * 1.44269504088896340736f;
+    const float sl2 = p.k_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
     f32x16 o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel_v2(AttnArgs p) {
 //   K(t+3) / V(t+2) are issued in Y(t), waited for at the end of X(t+2) (leaving Y(t+1)'s batch in flight) and
 //   first read in X(t+3) - a barrier all waves pass lies between wait and read for either group; they overwrite
 //   the slots of K(t-1) / V(t-2), last read in X(t-1) = interval 2t-2+g' < 2t+g+1.
-template <int HD>
+template <int HD, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     static_assert(HD == 72, "v3 relies on hd % 16 == 8 (pad slots in the last QK^T k-step, spare row in O^T)");
     constexpr int KS = 5, DT = 3, CPR = HD / 8;
@@ -509,7 +510,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     const bool q_ok = qrow < p.N;
     if (!q_ok) qrow = p.N - 1;
     const u16* qptr = p.q + ((size_t)bh * p.N + qrow) * HD;
-    const float sl2 = p.scale * 1.44269504088896340736f;
+    // scores must come out of the MFMA in the log2 domain: either K already carries scale * log2(e) (engine path: folded
+    // into K's single bf16 rounding by qk_norm_rope, no extra rounding anywhere) or Q is pre-scaled here (one extra
+    // bf16 rounding of Q; operator-level calls with plain K)
+    const float sl2 = p.k_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -527,35 +531,44 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     }
 
     // ---- staging ------------------------------------------------------------------------------------
-    const size_t kbytes = (size_t)p.Nk * HD * 2;
-    __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + (size_t)bhk * p.Nk * HD), 0, (int)kbytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vt + (size_t)bhk * HD * p.Nkpad), 0, (int)((size_t)HD * p.Nkpad * 2), 0x00020000);
-    // 18 one-KiB pieces per (K, V^T) tile pair: piece j < 9 = K bytes [1024 j, +1024), piece 9 + j = V^T rows 8j..8j+7.
-    // wave w owns pieces w, w + 8, w + 16 (< 18): waves 0,1 issue 3 per batch, the others 2.
-    const int vrow = lane >> 3;
-    auto stage_k = [&](int t, int slot, int j) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, LDS_PTR(smem + K_BASE + slot * KTILE + j * 1024), 16,
-                                                 j * 1024 + lane * 16, t * KTILE, 0, 0);
+    // 18 one-KiB pieces per (K, V^T) tile pair: K piece j = K-tile bytes [1024 j, +1024) (j < 9), V piece j = V^T rows
+    // 8j..8j+7 (j < 9).  Every wave issues exactly three LDS-DMA loads per batch, branch-free, so one vmcnt literal
+    // fits all waves:  A = K piece w;  B = K piece 8 (wave 0) or V piece w-1;  C = V piece 7 (wave 0), 8 (wave 1) or
+    // V piece w-1 again (waves 2..7: same bytes to the same place, harmless).
+    const u16* k_head = p.k + (size_t)bhk * p.Nk * HD;
+    const u16* v_head = p.vt + (size_t)bhk * HD * p.Nkpad;
+    const int kbytes = (int)((size_t)p.Nk * HD * 2), vbytes = (int)((size_t)HD * p.Nkpad * 2);
+    const bool b_is_k = (wave == 0);
+    const int jb = b_is_k ? 8 : wave - 1;
+    const int jc = (wave == 0) ? 7 : (wave == 1 ? 8 : wave - 1);
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)k_head, 0, kbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)(b_is_k ? k_head : v_head), 0, b_is_k ? kbytes : vbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)v_head, 0, vbytes, 0x00020000);
+    auto v_voff = [&](int j) __attribute__((always_inline)) {
+        const int d = 8 * j + (lane >> 3);
+        return d * p.Nkpad * 2 + (((lane & 7) ^ ((d >> 1) & 7)) << 4);
     };
-    auto stage_v = [&](int t, int slot, int j) {
-        const int d = 8 * j + vrow;
-        const int sc = (lane & 7) ^ ((d >> 1) & 7);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(smem + V_BASE + slot * VTILE + j * 1024), 16,
-                                                 d * p.Nkpad * 2 + sc * 16, t * 128, 0, 0);
+    const int voffA = wave * 1024 + lane * 16;
+    const int voffB = b_is_k ? 8 * 1024 + lane * 16 : v_voff(jb);
+    const int voffC = v_voff(jc);
+    // batch = {K(tk), V(tv)}
+    auto dma_a = [&](int tk) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(smem + K_BASE + (tk & 3) * KTILE + wave * 1024), 16, voffA, tk * KTILE, 0, 0);
     };
-    auto stage_batch = [&](int tk, int tv) {  // K(tk) and V(tv) into their ring slots
-        // piece ids of this wave: wave (K piece), wave + 8 (K piece 8 for wave 0, else V piece wave - 1), wave + 16 (V 7, 8)
-        stage_k(tk, tk & 3, wave);                                  // pieces 0..7
-        if (wave == 0) stage_k(tk, tk & 3, 8);                      // piece 8
-        else stage_v(tv, tv & 3, wave - 1);                         // pieces 9..15 -> V rows of piece wave-1
-        if (wave < 2) stage_v(tv, tv & 3, 7 + wave);                // pieces 16, 17 -> V pieces 7, 8
+    auto dma_b = [&](int tk, int tv) __attribute__((always_inline)) {
+        const int lds = b_is_k ? K_BASE + (tk & 3) * KTILE + 8 * 1024 : V_BASE + (tv & 3) * VTILE + jb * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_PTR(smem + lds), 16, voffB, b_is_k ? tk * KTILE : tv * 128, 0, 0);
+    };
+    auto dma_c = [&](int tv) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rC, LDS_PTR(smem + V_BASE + (tv & 3) * VTILE + jc * 1024), 16, voffC, tv * 128, 0, 0);
     };
     const int ntile = (p.Nk + 63) / 64;
-    // prologue: K(0); K(1), V(0); K(2), V(1)  (what Y(-3), Y(-2), Y(-1) would have issued)
-    stage_k(0, 0, wave);
-    if (wave == 0) stage_k(0, 0, 8);
-    stage_batch(1, 0);
-    stage_batch(2, 1);
+    // prologue: K(0); K(1), V(0); K(2), V(1)  (the batches X(-3), X(-2), X(-1) would have issued; tile indices past
+    // the end read zeros through the descriptor bounds and are never consumed)
+    dma_a(0);
+    if (wave == 0) dma_b(0, 0);
+    dma_a(1); dma_b(1, 0); dma_c(0);
+    dma_a(2); dma_b(2, 1); dma_c(1);
 
     // ---- per-lane LDS read offsets ------------------------------------------------------------------
     const int kb_lane = K_BASE + l31 * (HD * 2) + hi * 16;  // + slot * KTILE + kt2 * 32 * HD * 2 + s * 32 (s < 4)
@@ -586,45 +599,92 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    auto bar = [&]() {
+    auto bar = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // X phase: PV of the previous tile (P in pa, V^T slot vs) and QK^T of tile t (K slot ks)
-    auto phase_x = [&](int ks, int vs, bool do_pv, bool do_qk) {
+    // X phase: PV of the previous tile (P in pa, V^T slot (t+3)&3) and QK^T of tile t (K slot t&3); with DMA it also
+    // issues the batch {K(t+3), V(t+2)} between the MFMAs.  All 22 fragment reads are written first and the order is
+    // pinned with sched_group_barrier: six reads ahead of the first MFMA, then one read per MFMA, so the in-order
+    // wave never sits on LDS latency (the compiler's own just-in-time placement kept the matrix pipe ~60 % busy).
+    bf16x8 fpre[6];  // first six V^T fragments of the next X phase, read at the end of the Y phase before it
+    auto pre_reads = [&](int t_next) __attribute__((always_inline)) {  // V(t_next - 1) lives in slot (t_next + 3) & 3
+        const char* vb = smem + ((t_next + 3) & 3) * VTILE;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) fpre[i] = *(const bf16x8*)(vb + voff[i % 3][i / 3]);
+    };
+    auto phase_x = [&](int t, auto pv_c, auto qk_c, auto dma_c_) __attribute__((always_inline)) {
+        constexpr bool PV = decltype(pv_c)::value, QK = decltype(qk_c)::value, DMA = decltype(dma_c_)::value;
         __builtin_amdgcn_s_setprio(1);
-        if (do_qk) {
-            const char* kb = smem + ks * KTILE;
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-#pragma unroll
-                for (int kt2 = 0; kt2 < 2; ++kt2) {
-                    bf16x8 kf;
-                    if (s < KS - 1) kf = *(const bf16x8*)(kb + kb_lane + kt2 * 32 * HD * 2 + s * 32);
-                    else kf = *(const bf16x8*)(hi ? (const char*)(smem + CONST_OFF) : (kb + kb_lane + kt2 * 32 * HD * 2 + s * 32));
-                    sc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? zero : sc[kt2], 0, 0, 0);
-                }
+        const char* kb = smem + (t & 3) * KTILE + kb_lane;
+        const char* vb = smem + ((t + 3) & 3) * VTILE;
+        const char* kpad = hi ? (const char*)(smem + CONST_OFF) : kb + (KS - 1) * 32;
+        bf16x8 fr[22];
+        int n = 0;
+        // LDS-DMA writes cannot be scheduled across LDS reads they might alias, so their place among the reads is
+        // fixed here in source order (beside MFMAs 2 / 6 / 10 of the pinned pipeline)
+        auto dma_at = [&](int k) __attribute__((always_inline)) {
+            if constexpr (DMA) {
+                constexpr int P0 = PV ? 9 : 3, P1 = PV ? 13 : 6, P2 = PV ? 17 : 9;
+                if (k == P0) dma_a(t + 3);
+                if (k == P1) dma_b(t + 3, t + 2);
+                if (k == P2) dma_c(t + 2);
             }
-        }
-        if (do_pv) {
-            const char* vb = smem + vs * VTILE;
+        };
+        if constexpr (PV) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 vf = *(const bf16x8*)(vb + voff[dt][g]);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pa[g], o[dt], 0, 0, 0);
+                    dma_at(n);
+                    if (n < 6) fr[n] = fpre[n];
+                    else fr[n] = *(const bf16x8*)(vb + voff[dt][g]);
+                    ++n;
                 }
+        }
+        if constexpr (QK) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2) {
+                    dma_at(n);
+                    fr[n++] = (s < KS - 1) ? *(const bf16x8*)(kb + kt2 * 32 * HD * 2 + s * 32)
+                                           : *(const bf16x8*)(kpad + (hi ? 0 : kt2 * 32 * HD * 2));
+                }
+        }
+        n = 0;
+        if constexpr (PV) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n++], pa[g], o[dt], 0, 0, 0);
+        }
+        if constexpr (QK) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2)
+                    sc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n++], qf[s], s == 0 ? zero : sc[kt2], 0, 0, 0);
+        }
+        if constexpr (PV && QK) {  // the first six fragments are already in flight (pre_reads): one read per MFMA
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (DMA && (i == 2 || i == 6 || i == 10)) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);
         }
         __builtin_amdgcn_s_setprio(0);
     };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
 
     // Y phase: softmax of the tile in sc -> pa
-    auto phase_y = [&](int t) {
+    auto phase_y = [&](int t) __attribute__((always_inline)) {
         if (t == ntile - 1 && (p.Nk & 63)) {  // partial last tile: keys past Nk get probability 0
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2)
@@ -676,21 +736,56 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
         for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(pa[g]));
     };
 
-    for (int t = 0; t < ntile; ++t) {
-        phase_x(t & 3, (t + 3) & 3, t > 0, true);
-        // K(t+1), V(t) must have landed before anybody's X(t+1); the batch issued in Y(t-1) may stay in flight
-        if (t + 1 < ntile) {
-            if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long tr[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    if constexpr (TRACE) t0 = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        if constexpr (TRACE) {
+            __builtin_amdgcn_sched_barrier(0);
+            t1 = __builtin_amdgcn_s_memtime();
+            tr[i] += t1 - t0;
+            t0 = t1;
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    // after X(t): K(t+2), V(t+1) (the batch issued in X(t-1)) must have landed - V(t+1)'s first fragments are read by
+    // the other group as early as the end of its Y(t+1), one interval before its X(t+2); only the batch issued in
+    // X(t) itself (three loads) may stay in flight
+    auto rest = [&](int t) __attribute__((always_inline)) {
+        stamp(0);
+        if (t + 2 < ntile) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(1);
         bar();
+        stamp(2);
         phase_y(t);
-        if (t + 2 < ntile) stage_batch(t + 3, t + 2);
+        pre_reads(t + 1);
+        stamp(3);
         bar();
+        stamp(4);
+    };
+    {
+        if (2 < ntile) phase_x(0, F_{}, T_{}, T_{});
+        else phase_x(0, F_{}, T_{}, F_{});
+        rest(0);
     }
-    phase_x(0, (ntile + 3) & 3, true, false);  // PV of the last tile
+    int t = 1;
+    for (; t + 2 < ntile; ++t) {
+        phase_x(t, T_{}, T_{}, T_{});
+        rest(t);
+    }
+    for (; t < ntile; ++t) {
+        phase_x(t, T_{}, T_{}, F_{});
+        rest(t);
+    }
+    if constexpr (TRACE) {
+        if (p.trace && lane == 0 && (blockIdx.x & 63) == 5) {
+            unsigned long long* o = p.trace + ((size_t)(blockIdx.x >> 6) * 8 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) o[i] = tr[i];
+            o[5] = (unsigned long long)ntile;
+        }
+    }
+    phase_x(ntile, T_{}, F_{}, F_{});  // PV of the last tile (V slot (ntile + 3) & 3 = (ntile - 1) & 3)
     if (grp == 0) bar();                       // the barrier group 1 still needs after its last Y phase
 
     // l = O^T[HD][q] lives in register L_REG of tile L_DT on the hi == L_HI lane of this query row
@@ -714,7 +809,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
 
 }  // namespace
 
-static int g_attn_variant = 2;
+static int g_attn_variant = 3;  // 3: ping-pong kernel where it applies (hd 72 self-attention), v2 elsewhere
 void lt_set_attention_variant(int v) { g_attn_variant = v; }
 
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
@@ -734,11 +829,20 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
             attr_done = true;
         }
         const int nqb3 = (a.N + 255) / 256;
+        if (a.trace) {
+            static bool tdone = false;
+            if (!tdone) {
+                LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<72, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3));
+                tdone = true;
+            }
+            hipLaunchKernelGGL((attn_fwd_kernel_v3<72, true>), dim3(a.B * a.H * nqb3), dim3(512), SMEM3, stream, a);
+        } else
         hipLaunchKernelGGL(attn_fwd_kernel_v3<72>, dim3(a.B * a.H * nqb3), dim3(512), SMEM3, stream, a);
         LT_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    const bool v2 = g_attn_variant >= 2;
+    LT_REQUIRE(a.trace == nullptr, "attention trace: only the hd 72 self-attention kernel (variant 3) is instrumented");
+    const bool v2 = g_attn_variant >= 2;  // (variant 3 falls back to v2 for text attention and other head dims)
     switch (a.hd) {
         case 48: if (v2) LAUNCH_V2(48); else LAUNCH_V1(48); break;
         case 72: if (v2) LAUNCH_V2(72); else LAUNCH_V1(72); break;

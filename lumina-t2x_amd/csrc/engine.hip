@@ -32,6 +32,8 @@ extern "C" const char* lt_version(void) { return "lumina_dit gfx950 r1"; }
 
 namespace {
 
+constexpr float LOG2E = 1.44269504088896340736f;
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -283,12 +285,14 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             if (launch_qk_norm_rope(qa, s)) return 1;
             qa.col0 = d; qa.heads = Hkv; qa.dst = e->k;
             qa.ln_w = c.qk_norm ? w.k_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.k_norm_b : nullptr;
+            qa.out_scale = sm_scale * LOG2E;  // softmax scale folded into K's one bf16 rounding (scores in log2 units)
             if (launch_qk_norm_rope(qa, s)) return 1;
             if (launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
         }
         AttnArgs at;
         at.q = e->q; at.k = e->k; at.vt = e->vt; at.bias = nullptr; at.out = e->attn; at.gate = nullptr; at.accumulate = 0;
         at.B = B; at.H = H; at.Hkv = Hkv; at.N = N; at.Nk = N; at.Nkpad = Npad; at.hd = hd; at.scale = sm_scale;
+        at.k_prescaled = 1;
         if (attention(e, at, s)) return 1;
         if (e->cap > 0) {  // zero-init gated text cross-attention (model.py:420-434)
             at.k = w.ky; at.vt = w.vty; at.bias = e->txt_bias; at.gate = w.gate; at.accumulate = 1;
@@ -484,6 +488,7 @@ extern "C" int lt_prepare_prompt(lt_engine* e, const void* cap_feats_dev, int32_
         qa.src = e->kvy; qa.ld_src = 2 * dkv; qa.col0 = 0; qa.B = B; qa.N = T; qa.heads = e->Hkv; qa.hd = e->hd;
         qa.rope_mode = 0; qa.cs = nullptr; qa.t = nullptr; qa.grid_w = 1; qa.cs_len = 0; qa.ln_eps = 1e-5f; qa.watershed = 0.f;
         qa.ln_w = c.qk_norm ? w.ky_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.ky_norm_b : nullptr; qa.dst = w.ky;
+        qa.out_scale = (float)(1.0 / std::sqrt((double)e->hd)) * LOG2E;  // SDPA default scale (model.py:427-432), folded like the self-attention K
         if (launch_qk_norm_rope(qa, s)) return 1;
         if (launch_v_transpose(e->kvy, 2 * dkv, dkv, w.vty, B, T, Tpad, e->Hkv, e->hd, s)) return 1;
     }
@@ -630,7 +635,7 @@ extern "C" int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t*
 extern "C" int lt_set_option(const char* name, int32_t value) {
     LT_REQUIRE(name, "lt_set_option: null name");
     if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 3, "attention_variant must be 1, 2 or 3"); lt_set_attention_variant(value); return 0; }
-    if (strcmp(name, "gemm_pipeline") == 0) { LT_REQUIRE(value == 0 || value == 1, "gemm_pipeline must be 0 or 1"); lt_set_gemm_pipeline(value); return 0; }
+    if (strcmp(name, "gemm_pipeline") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_pipeline must be 0, 1 or 2"); lt_set_gemm_pipeline(value); return 0; }
     if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }
     lt_set_error("lt_set_option: unknown option '%s'", name);
     return 2;
@@ -684,12 +689,13 @@ extern "C" int lt_op_gated_residual_norm(void* x, const void* y, const void* pos
 
 extern "C" int lt_op_qk_norm_rope(const void* src, int32_t ld_src, int32_t col0, const void* ln_w, const void* ln_b,
                                   float ln_eps, void* dst, int32_t B, int32_t N, int32_t heads, int32_t hd,
-                                  int32_t rope_mode, const void* cs_table, int32_t grid_w, void* stream) {
+                                  int32_t rope_mode, const void* cs_table, int32_t grid_w, float out_scale, void* stream) {
     LT_REQUIRE(src && dst, "lt_op_qk_norm_rope: null pointer");
     QkPostArgs q;
     q.src = (const u16*)src; q.ld_src = ld_src; q.col0 = col0; q.ln_w = (const u16*)ln_w; q.ln_b = (const u16*)ln_b;
     q.ln_eps = ln_eps; q.dst = (u16*)dst; q.B = B; q.N = N; q.heads = heads; q.hd = hd; q.rope_mode = rope_mode;
     q.cs = (const float*)cs_table; q.t = nullptr; q.grid_w = grid_w > 0 ? grid_w : 1; q.watershed = 0.f;
+    q.out_scale = out_scale;
     q.cs_len = 0;  // op level: the caller hands over the single branch table it wants (no branch offset)
     return launch_qk_norm_rope(q, (hipStream_t)stream);
 }
@@ -702,12 +708,23 @@ extern "C" int lt_op_v_transpose(const void* src, int32_t ld_src, int32_t col0, 
 
 extern "C" int lt_op_attention(const void* q, const void* k, const void* vt, const float* bias, void* out, const void* gate,
                                int32_t accumulate, int32_t B, int32_t H, int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad,
-                               int32_t hd, float scale, void* stream) {
+                               int32_t hd, float scale, int32_t k_prescaled, void* stream) {
     LT_REQUIRE(q && k && vt && out, "lt_op_attention: null pointer");
     AttnArgs a;
     a.q = (const u16*)q; a.k = (const u16*)k; a.vt = (const u16*)vt; a.bias = bias; a.out = (u16*)out;
     a.gate = (const u16*)gate; a.accumulate = accumulate; a.B = B; a.H = H; a.Hkv = Hkv; a.N = N; a.Nk = Nk;
-    a.Nkpad = Nkpad; a.hd = hd; a.scale = scale;
+    a.Nkpad = Nkpad; a.hd = hd; a.scale = scale; a.k_prescaled = k_prescaled;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_attention_trace(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H, int32_t Hkv,
+                                     int32_t N, int32_t Nk, int32_t Nkpad, int32_t hd, float scale, void* trace_dev,
+                                     void* stream) {
+    LT_REQUIRE(q && k && vt && out && trace_dev, "lt_op_attention_trace: null pointer");
+    AttnArgs a;
+    a.q = (const u16*)q; a.k = (const u16*)k; a.vt = (const u16*)vt; a.bias = nullptr; a.out = (u16*)out;
+    a.gate = nullptr; a.accumulate = 0; a.B = B; a.H = H; a.Hkv = Hkv; a.N = N; a.Nk = Nk;
+    a.Nkpad = Nkpad; a.hd = hd; a.scale = scale; a.trace = (unsigned long long*)trace_dev;
     return launch_attention(a, (hipStream_t)stream);
 }
 

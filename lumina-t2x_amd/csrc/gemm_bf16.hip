@@ -507,7 +507,7 @@ int num_cus() {
 }  // namespace
 
 static int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 256x256, 2 = 256x288
-static int g_gemm_pipeline = 0;  // time structure when the caller passes variant <= 2: 0 classic, 1 ping-pong
+static int g_gemm_pipeline = 0;  // variant <= 2: 0 auto (ping-pong for the SwiGLU GEMM, classic elsewhere), 1 ping-pong, 2 classic
 void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
 void lt_set_gemm_pipeline(int v) { g_gemm_pipeline = v; }
 
@@ -536,7 +536,9 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
         LT_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    if (epilogue == 1) return pp ? launch_cfg<2, 4, 4, 2, 1, true>(a, stream) : launch_cfg<2, 4, 4, 2, 1, false>(a, stream);
+    // SwiGLU GEMM (N = 2F = 12288 at cfg 2: whole rounds of 256x256 tiles): the ping-pong kernel measured +5 % over the classic
+    // loop (opbench r01), so it is the default there; g_gemm_pipeline == 2 forces the classic loop everywhere (A/B).
+    if (epilogue == 1) return (pp || g_gemm_pipeline == 0) ? launch_cfg<2, 4, 4, 2, 1, true>(a, stream) : launch_cfg<2, 4, 4, 2, 1, false>(a, stream);
     if (variant == 0) variant = g_gemm_variant;
     if (variant == 0) {
         const int cus = num_cus();

@@ -55,6 +55,7 @@ struct QkPostArgs {
     int ld_src, col0, B, N, heads, hd;
     int rope_mode, grid_w, cs_len;  // cs_len: positions per branch table
     float ln_eps, watershed;
+    float out_scale = 1.0f;  // multiplies the result before its single bf16 rounding (folds softmax scale * log2 e into K)
 };
 int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream);
 int launch_v_transpose(const u16* src, int ld_src, int col0, u16* dst, int B, int N, int Npad, int kv_heads,
@@ -71,6 +72,8 @@ struct AttnArgs {
     int accumulate;
     int B, H, Hkv, N, Nk, Nkpad, hd;
     float scale;
+    int k_prescaled = 0;  // 1: K already carries scale * log2(e) (qk_norm_rope out_scale): scores are in the log2 domain
+    unsigned long long* trace = nullptr;  // diagnostics only (lt_op_attention_trace)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)

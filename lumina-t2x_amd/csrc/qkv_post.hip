@@ -100,6 +100,10 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkPostArgs p) {
                     o[2 * j + 1] = y[2 * j] * t.y + y[2 * j + 1] * t.x;
                 }
             }
+            if (p.out_scale != 1.0f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] *= p.out_scale;
+            }
             u16* dst = p.dst + (((size_t)b * p.heads + head) * p.N + n) * p.hd + ci * 8;
             *(bf8_t*)dst = pack8(o);
         }

@@ -81,8 +81,8 @@ def bench_attn(rounds, variants):
     q = torch.empty(B, H, N, hd, device="cuda", dtype=torch.bfloat16)
     k = torch.empty_like(q)
     vt = torch.empty(B, H, hd, N, device="cuda", dtype=torch.bfloat16)
-    ok(L.lt_op_qk_norm_rope(P(qkv), 3 * H * hd, 0, P(None), P(None), C.c_float(1e-5), P(q), B, N, H, hd, 0, P(None), 64, stream()))
-    ok(L.lt_op_qk_norm_rope(P(qkv), 3 * H * hd, H * hd, P(None), P(None), C.c_float(1e-5), P(k), B, N, H, hd, 0, P(None), 64, stream()))
+    ok(L.lt_op_qk_norm_rope(P(qkv), 3 * H * hd, 0, P(None), P(None), C.c_float(1e-5), P(q), B, N, H, hd, 0, P(None), 64, 1.0, stream()))
+    ok(L.lt_op_qk_norm_rope(P(qkv), 3 * H * hd, H * hd, P(None), P(None), C.c_float(1e-5), P(k), B, N, H, hd, 0, P(None), 64, 1.0, stream()))
     ok(L.lt_op_v_transpose(P(qkv), 3 * H * hd, 2 * H * hd, P(vt), B, N, N, H, hd, stream()))
     scale = 1.0 / math.sqrt(hd)
     outs, cases = {}, {}
@@ -92,7 +92,7 @@ def bench_attn(rounds, variants):
 
         def fn(v=v, out=out):
             set_option("attention_variant", v)
-            ok(L.lt_op_attention(P(q), P(k), P(vt), None, P(out), P(None), 0, B, H, H, N, N, N, hd, C.c_float(scale), stream()))
+            ok(L.lt_op_attention(P(q), P(k), P(vt), None, P(out), P(None), 0, B, H, H, N, N, N, hd, C.c_float(scale), 0, stream()))
         cases[v] = fn
     r = ab(cases, rounds)
     fl = 4.0 * B * H * N * N * hd
@@ -106,7 +106,7 @@ def bench_attn(rounds, variants):
         err = rel_l2(outs[v].view(B, N, H, hd)[0, :, 0], ref)
         print(f"attn B{B} H{H} N{N} hd{hd} variant {v}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s (best {fl/mn/1e9:7.1f})"
               f"  rel-L2 head0 vs fp32 {err:.2e}", flush=True)
-    set_option("attention_variant", 2)
+    set_option("attention_variant", 3)
 
 
 def bench_elem(rounds):
@@ -130,7 +130,7 @@ def bench_elem(rounds):
                                        C.c_float(1e-5), C.c_float(1e-6), stream()))
 
     def qkn():
-        ok(L.lt_op_qk_norm_rope(P(qkv), 3 * d, 0, P(w), P(w), C.c_float(1e-5), P(q), B, N, 32, 72, 1, P(tab), 64, stream()))
+        ok(L.lt_op_qk_norm_rope(P(qkv), 3 * d, 0, P(w), P(w), C.c_float(1e-5), P(q), B, N, 32, 72, 1, P(tab), 64, 1.0, stream()))
 
     def vtr():
         ok(L.lt_op_v_transpose(P(qkv), 3 * d, 2 * d, P(vt), B, N, N, 32, 72, stream()))

@@ -18,8 +18,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _default_kernel_variants():
     yield
-    set_option("attention_variant", 2)
+    set_option("attention_variant", 3)
     set_option("gemm_variant", 0)
+    set_option("gemm_pipeline", 0)
 
 
 def _gemm(A, W, bias=None, epilogue=0, variant=0):
@@ -85,16 +86,17 @@ def test_gemm_bias_and_edges():
     assert torch.all(big[200:] == 7.0)
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("pipeline", [1, 2])  # 1 = ping-pong wave groups (the default for this epilogue), 2 = classic loop
 @pytest.mark.parametrize("M,F_,K", [(256, 128, 64), (300, 1536, 576), (4096, 6144, 2304)])
-def test_gemm_swiglu(M, F_, K, variant):
+def test_gemm_swiglu(M, F_, K, pipeline):
+    set_option("gemm_pipeline", pipeline)
     g = torch.Generator().manual_seed(F_ + K)
     A = bf(torch.randn(M, K, generator=g))
     w1 = bf(torch.randn(F_, K, generator=g) / math.sqrt(K))
     w3 = bf(torch.randn(F_, K, generator=g) / math.sqrt(K))
     packed = torch.empty(2 * F_, K, device="cuda", dtype=torch.bfloat16)
     ok(lib().lt_op_pack_w13(P(w1), P(w3), P(packed), F_, K, stream()))
-    out = _gemm(A, packed, None, 1, variant=variant)
+    out = _gemm(A, packed, None, 1)
     a = r16(A.float() @ w1.float().t())
     b = r16(A.float() @ w3.float().t())
     ref = r16(r16(F.silu(a)) * b)
@@ -167,7 +169,11 @@ def test_qk_norm_rope(heads, hd, qk_norm):
     ok(lib().lt_op_rope_table_2d(P(table), 384, hd, 10000.0, 2.0, stream()))
     dst = torch.empty(B, heads, N, hd, device="cuda", dtype=torch.bfloat16)
     ok(lib().lt_op_qk_norm_rope(P(src), ld, 64, P(w) if qk_norm else None, P(b) if qk_norm else None, 1e-5, P(dst), B, N,
-                                heads, hd, 1, P(table[1]), Wp, stream()))
+                                heads, hd, 1, P(table[1]), Wp, 1.0, stream()))
+    # out_scale: applied in fp32 before the single bf16 rounding (how the engine folds softmax_scale * log2 e into K)
+    dst_s = torch.empty_like(dst)
+    ok(lib().lt_op_qk_norm_rope(P(src), ld, 64, P(w) if qk_norm else None, P(b) if qk_norm else None, 1e-5, P(dst_s), B, N,
+                                heads, hd, 1, P(table[1]), Wp, 0.1875, stream()))
     torch.cuda.synchronize()
     xs = src.float().cpu()[:, 64:]
     if qk_norm:
@@ -175,6 +181,8 @@ def test_qk_norm_rope(heads, hd, qk_norm):
     freqs = O.rope_table(hd, 384, scale_factor=2.0, scale_watershed=0.3, timestep=0.9)[:Hp, :Wp].flatten(0, 1).unsqueeze(0)
     ref = r16(O.apply_rotary(xs.view(B, N, heads, hd), freqs)).permute(0, 2, 1, 3)
     assert rel_l2(dst, ref) < 3e-3, rel_l2(dst, ref)
+    ref_s = r16(O.apply_rotary(xs.view(B, N, heads, hd), freqs) * 0.1875).permute(0, 2, 1, 3)
+    assert rel_l2(dst_s, ref_s) < 3e-3, rel_l2(dst_s, ref_s)
     # table itself: branch 0 = linear interpolation, branch 1 = NTK (model.py:944-952)
     lin = O.rope_table(hd, 384, scale_factor=2.0, scale_watershed=0.3, timestep=0.1)
     tb = table.cpu()
@@ -217,8 +225,11 @@ def _attn_ref(q, k, v, scale, bias=None):
     return out.cpu()
 
 
-def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None):
+def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None, fold_scale=False):
+    """fold_scale: hand the kernel K * scale * log2(e) (rounded once to bf16) with k_prescaled = 1 - the engine's path"""
     B, H, N, hd = q.shape
+    if fold_scale:
+        k = (k.float() * (scale * 1.4426950408889634)).to(torch.bfloat16)
     Hkv, Nk = k.shape[1], k.shape[2]
     Nkpad = (Nk + 63) // 64 * 64
     vsrc = v.permute(0, 2, 1, 3).reshape(B * Nk, Hkv * hd).contiguous()
@@ -230,7 +241,7 @@ def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None):
         bias_dev = torch.full((B, Nkpad), float("-inf"), device="cuda", dtype=torch.float32)
         bias_dev[:, :Nk] = bias.cuda()
     ok(lib().lt_op_attention(P(q), P(k), P(vt), P(bias_dev), P(out), P(gate), 1 if gate is not None else 0, B, H, Hkv, N,
-                             Nk, Nkpad, hd, scale, stream()), "attention")
+                             Nk, Nkpad, hd, scale, 1 if fold_scale else 0, stream()), "attention")
     torch.cuda.synchronize()
     return out.view(B, N, H, hd).permute(0, 2, 1, 3)
 
@@ -239,14 +250,15 @@ def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None):
 @pytest.mark.parametrize("B,H,Hkv,N,hd", [(1, 8, 8, 128, 72), (2, 8, 2, 320, 72), (2, 4, 4, 200, 72), (1, 3, 3, 64, 72),
                                           (2, 32, 32, 4096, 72), (1, 8, 8, 256, 48), (1, 8, 8, 192, 96),
                                           (1, 8, 8, 1000, 72), (1, 2, 2, 40, 72)])
-def test_attention_self(variant, B, H, Hkv, N, hd):
+@pytest.mark.parametrize("fold", [False, True])
+def test_attention_self(variant, B, H, Hkv, N, hd, fold):
     set_option("attention_variant", variant)
     g = torch.Generator().manual_seed(N + hd)
     q = bf(torch.randn(B, H, N, hd, generator=g))
     k = bf(torch.randn(B, Hkv, N, hd, generator=g))
     v = bf(torch.randn(B, Hkv, N, hd, generator=g))
     scale = math.sqrt(math.log(N, 64) / hd) if N > 64 else 1 / math.sqrt(hd)
-    out = _run_attn(q, k, v, scale)
+    out = _run_attn(q, k, v, scale, fold_scale=fold)
     ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), scale)
     assert not torch.isnan(out.float()).any()
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
@@ -274,7 +286,8 @@ def test_attention_softmax_outlier_keys(variant):
 
 @pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("T,valid1", [(16, 8), (13, 5), (128, 8), (77, 77), (200, 130)])
-def test_attention_text_accumulate(variant, T, valid1):
+@pytest.mark.parametrize("fold", [False, True])
+def test_attention_text_accumulate(variant, T, valid1, fold):
     set_option("attention_variant", variant)
     B, H, Hkv, N, hd = 2, 8, 2, 96, 72
     g = torch.Generator().manual_seed(T)
@@ -286,7 +299,7 @@ def test_attention_text_accumulate(variant, T, valid1):
     mask = torch.ones(B, T)
     mask[1, valid1:] = 0
     bias = torch.where(mask > 0, 0.0, float("-inf"))
-    out = _run_attn(q, k, v, 1 / math.sqrt(hd), bias=bias, gate=gate, prev=prev)
+    out = _run_attn(q, k, v, 1 / math.sqrt(hd), bias=bias, gate=gate, prev=prev, fold_scale=fold)
     oy = r16(_attn_ref(q.cpu(), k.cpu(), v.cpu(), 1 / math.sqrt(hd), bias))
     gt = r16(torch.tanh(gate.float().cpu())).view(1, H, 1, 1)
     ref = r16(prev.float().cpu().view(B, N, H, hd).permute(0, 2, 1, 3) + r16(oy * gt))
