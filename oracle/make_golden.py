@@ -101,6 +101,67 @@ def model_case(name, cfg, pkg, latent_hw, text_len, uncond_len, seed_w, seed_x):
     print(f"{name}.npz: N={N} T={text_len}", {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 0})
 
 
+def _fresh_import(pkg, module):
+    """import <pkg>/<module> of the reference with a clean `models` namespace (every sub-project calls its package `models`)"""
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
+        del sys.modules[m]
+    root = os.path.join(R.REFERENCE_ROOT, pkg)
+    sys.path = [q for q in sys.path if not q.startswith(R.REFERENCE_ROOT)]
+    sys.path.insert(0, root)
+    return importlib.import_module(module)
+
+
+def family_case(name, cfg, latent_hw, seed_w, seed_x, text_len=16, uncond_len=8):
+    """imagenet / moe / flag_t2i fixtures from the unmodified reference modules (fp32, CPU, eager)."""
+    os.environ["TORCHDYNAMO_DISABLE"] = "1"  # models.py:463 decorates the SwiGLU with torch.compile; eager is the same maths
+    sd = synth.synth_state_dict(cfg, seed=seed_w)
+    ins = synth.synth_inputs(cfg, latent_hw=latent_hw, text_len=text_len, uncond_len=uncond_len, seed=seed_x)
+    pkg, module = {"imagenet": ("Next-DiT-ImageNet", "models.models"), "moe": ("Next-DiT-MoE", "models.models2"),
+                   "flag_t2i": ("lumina_t2i", "models.model")}[cfg.family]
+    mod = _fresh_import(pkg, module)
+    kw = cfg.ctor_kwargs()
+    model = mod.DiT_Llama(**kw).eval()
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    out = {"config": np.array(json.dumps(cfg.to_dict())), "seed_w": seed_w, "seed_x": seed_x, "package": np.array(pkg),
+           "text_len": text_len, "uncond_len": uncond_len, "latent_hw": np.array(latent_hw)}
+    hidden = []
+    hooks = [l.register_forward_hook(lambda m, i, o: hidden.append(_np(o))) for l in model.layers]
+    with torch.no_grad():
+        if cfg.has_text:
+            z, t, cap, mask = ins
+            out.update(z=_np(z), t=_np(t), cap=_np(cap), mask=_np(mask))
+            out["forward"] = _np(model(z, t, cap, mask))
+            out["hidden"] = np.stack(hidden)
+            for h in hooks:
+                h.remove()
+            out["cfg4_prop"] = _np(model.forward_with_cfg(z, t, cap, mask, 4.0, base_seqlen=16, proportional_attn=True))
+            out["cfg4_rope"] = _np(model.forward_with_cfg(z, t, cap, mask, 4.0, rope_scaling_factor=2.0, ntk_factor=1.5,
+                                                          base_seqlen=16, proportional_attn=True))
+            model.forward_with_cfg(z, t, cap, mask, 1.0, rope_scaling_factor=1.0, ntk_factor=1.0)  # restore the table
+            out["cfg1_plain"] = _np(model.forward_with_cfg(z, t, cap, mask, 1.0))
+        else:
+            z, t, y = ins
+            out.update(z=_np(z), t=_np(t), y=_np(y))
+            out["forward"] = _np(model(z, t, y))
+            out["hidden"] = np.stack(hidden)
+            for h in hooks:
+                h.remove()
+            out["cfg4"] = _np(model.forward_with_cfg(z, t, y, 4.0))
+            out["cfg4_rope"] = _np(model.forward_with_cfg(z, t, y, 4.0, rope_scaling_factor=2.0, ntk_factor=1.5))
+            model.forward_with_cfg(z, t, y, 1.0, rope_scaling_factor=1.0, ntk_factor=1.0)
+            out["cfg1_plain"] = _np(model.forward_with_cfg(z, t, y, 1.0))
+            # BASELINE configs[0]: 4-step Euler ODE driven through the reference's own transport package
+            tmod = _fresh_import("Next-DiT-ImageNet", "transport")
+            tr = tmod.create_transport("Linear", "velocity", None, None, None)
+            fn = tmod.Sampler(tr).sample_ode(sampling_method="euler", num_steps=5)
+            if cfg.family == "imagenet":
+                traj = fn(z, model.forward_with_cfg, y=y, cfg_scale=4.0)
+                out["traj_euler"] = _np(traj)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}.npz:", {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 0})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -109,6 +170,9 @@ def main():
     model_case("nextdit_tiny", synth.TINY, "lumina_next_t2i", (16, 16), 16, 8, 0, 1)
     model_case("nextdit_tiny_rect", synth.TINY, "lumina_next_t2i", (12, 20), 13, 5, 3, 4)
     model_case("nextdit_tiny_gqa", synth.TINY_GQA, "lumina_next_t2i_mini", (16, 16), 16, 8, 5, 6)
+    family_case("imagenet_tiny", synth.TINY_IMAGENET, (16, 16), 7, 8)
+    family_case("moe_tiny", synth.TINY_MOE, (16, 16), 9, 10)
+    family_case("flag_tiny", synth.TINY_FLAG, (16, 24), 11, 12)
 
 
 if __name__ == "__main__":

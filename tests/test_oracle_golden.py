@@ -120,3 +120,62 @@ def test_bf16_choreography_noise_floor(golden_dir):
 def test_flop_count_matches_survey():
     n = O.flops_per_nfe(synth.NEXT_2B, 4096, 128, 2)
     assert 32.5e12 < n < 34.0e12  # 33.2 TFLOP per NFE at cfg 2
+
+
+# ---- the other model families (oracle/variants_oracle.py) against the unmodified reference modules ----------------------
+
+def test_imagenet_oracle_matches_reference_model(golden_dir):
+    """class-conditional Next-DiT (Next-DiT-ImageNet/models/models.py), BASELINE configs[0] architecture"""
+    from oracle import variants_oracle as V
+    g = _load(golden_dir, "imagenet_tiny")
+    cfg = _cfg(g)
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    z, t, y = (torch.from_numpy(g[k]) for k in ("z", "t", "y"))
+    tol = dict(rtol=0, atol=2e-5)
+    out, hidden = V.imagenet_forward(sd, cfg, z, t, y, return_hidden=True)
+    np.testing.assert_allclose(out.numpy(), g["forward"], **tol)
+    np.testing.assert_allclose(torch.stack(hidden).numpy(), g["hidden"], **tol)
+    np.testing.assert_allclose(V.imagenet_forward_with_cfg(sd, cfg, z, t, y, 4.0).numpy(), g["cfg4"], **tol)
+    np.testing.assert_allclose(V.imagenet_forward_with_cfg(sd, cfg, z, t, y, 4.0, rope_scaling_factor=2.0, ntk_factor=1.5).numpy(),
+                               g["cfg4_rope"], **tol)
+    np.testing.assert_allclose(V.imagenet_forward_with_cfg(sd, cfg, z, t, y, 1.0).numpy(), g["cfg1_plain"], **tol)
+    assert np.array_equal(g["cfg4"][0, :3], g["cfg4"][1, :3]) and not np.array_equal(g["cfg4"][0, 3], g["cfg4"][1, 3])
+    # BASELINE configs[0]: 4-step Euler ODE through the reference's transport package
+    traj = OD.sample_ode(lambda x, tv, **kw: V.imagenet_forward_with_cfg(sd, cfg, x, tv, **kw), z, 5, method="euler", y=y, cfg_scale=4.0)
+    np.testing.assert_allclose(traj.numpy(), g["traj_euler"], rtol=0, atol=5e-5)
+
+
+def test_moe_oracle_matches_reference_model(golden_dir):
+    """time + space MoE Next-DiT (Next-DiT-MoE/models/models2.py): routers, top-2, fp32 softmax, in-order scatter-add"""
+    from oracle import variants_oracle as V
+    g = _load(golden_dir, "moe_tiny")
+    cfg = _cfg(g)
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    z, t, y = (torch.from_numpy(g[k]) for k in ("z", "t", "y"))
+    tol = dict(rtol=0, atol=2e-5)
+    out, hidden = V.imagenet_forward(sd, cfg, z, t, y, return_hidden=True)
+    np.testing.assert_allclose(out.numpy(), g["forward"], **tol)
+    np.testing.assert_allclose(torch.stack(hidden).numpy(), g["hidden"], **tol)
+    np.testing.assert_allclose(V.imagenet_forward_with_cfg(sd, cfg, z, t, y, 4.0).numpy(), g["cfg4"], **tol)
+    np.testing.assert_allclose(V.imagenet_forward_with_cfg(sd, cfg, z, t, y, 4.0, rope_scaling_factor=2.0, ntk_factor=1.5).numpy(),
+                               g["cfg4_rope"], **tol)
+
+
+def test_flag_oracle_matches_reference_model(golden_dir):
+    """Flag-DiT (lumina_t2i/models/model.py): 1-D RoPE over rows with eol tokens, shift/scale/gate, text cross-attention"""
+    from oracle import variants_oracle as V
+    g = _load(golden_dir, "flag_tiny")
+    cfg = _cfg(g)
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    z, t, cap, mask = (torch.from_numpy(g[k]) for k in ("z", "t", "cap", "mask"))
+    tol = dict(rtol=0, atol=3e-5)
+    out, hidden = V.flag_forward(sd, cfg, z, t, cap, mask, return_hidden=True)
+    assert hidden[0].shape[1] == 8 * (12 + 1)  # 16x24 latent -> 8 rows of 12 patches + one eol token each
+    np.testing.assert_allclose(out.numpy(), g["forward"], **tol)
+    np.testing.assert_allclose(torch.stack(hidden).numpy(), g["hidden"], **tol)
+    got = V.flag_forward_with_cfg(sd, cfg, z, t, cap, mask, 4.0, base_seqlen=16, proportional_attn=True)
+    np.testing.assert_allclose(got.numpy(), g["cfg4_prop"], **tol)
+    got = V.flag_forward_with_cfg(sd, cfg, z, t, cap, mask, 4.0, rope_scaling_factor=2.0, ntk_factor=1.5, base_seqlen=16,
+                                  proportional_attn=True)
+    np.testing.assert_allclose(got.numpy(), g["cfg4_rope"], **tol)
+    np.testing.assert_allclose(V.flag_forward_with_cfg(sd, cfg, z, t, cap, mask, 1.0).numpy(), g["cfg1_plain"], **tol)
