@@ -69,7 +69,7 @@ typedef struct lt_config {
 /* kwargs of NextDiT.forward_with_cfg (model.py:866-877) that are not tensors */
 typedef struct lt_step_args {
     float   cfg_scale;         /* model.py:872                                                    */
-    float   scale_factor;      /* model.py:873   RoPE extrapolation factor                         */
+    float   scale_factor;      /* model.py:873   RoPE extrapolation factor (rope_scaling_factor elsewhere) */
     float   scale_watershed;   /* model.py:874   t < watershed -> linear interp, else NTK          */
     int32_t base_seqlen;       /* model.py:875   0 = None                                          */
     int32_t proportional_attn; /* model.py:876                                                     */
@@ -78,6 +78,9 @@ typedef struct lt_step_args {
     int32_t batch;             /* B (cond+uncond rows), even for forward_with_cfg                  */
     int32_t io_dtype;          /* LT_BF16 or LT_F32: dtype of x and out                            */
     int32_t cfg_channels;      /* 3 = reference quirk (model.py:908); in_channels = standard CFG   */
+    float   ntk_factor;        /* ImageNet / Flag-DiT forward_with_cfg(ntk_factor=...) (models.py:946,  */
+                               /* lumina_t2i model.py:866-875); there scale_factor = rope_scaling_factor; */
+                               /* <= 0 means 1.0.  Ignored by LT_VARIANT_NEXT_T2I.                       */
 } lt_step_args;
 
 const char* lt_last_error(void);

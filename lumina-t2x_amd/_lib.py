@@ -37,6 +37,7 @@ class LtStepArgs(C.Structure):
         ("cfg_scale", C.c_float), ("scale_factor", C.c_float), ("scale_watershed", C.c_float),
         ("base_seqlen", C.c_int32), ("proportional_attn", C.c_int32), ("latent_h", C.c_int32),
         ("latent_w", C.c_int32), ("batch", C.c_int32), ("io_dtype", C.c_int32), ("cfg_channels", C.c_int32),
+        ("ntk_factor", C.c_float),
     ]
 
 

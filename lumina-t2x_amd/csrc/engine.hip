@@ -56,8 +56,37 @@ struct ProfClass {
 
 }  // namespace
 
+// What differs between the reference's model families on this path (everything else is shared code):
+//                    NEXT_T2I (model.py:573-662)   NEXT_IMAGENET (models.py:759-833)   FLAG_T2I (lumina_t2i model.py:572-658)
+//  adaLN chunks      scale,gate | scale,gate       scale,gate | scale,gate             shift,scale,gate | shift,scale,gate
+//  pre-norm weight   attention_norm1 / ffn_norm1   none (PFRMSNorm)                    attention_norm / ffn_norm
+//  post-norm         attention_norm2 / ffn_norm2   attention_norm / ffn_norm           none
+//  gate              tanh                          tanh                                plain
+//  conditioning      text (cross-attn + pooled)    class label embedding               text (cross-attn + pooled)
+//  RoPE              2-D, watershed branches       2-D, (rope_scaling, ntk) at once    1-D over the flattened rows, eol tokens
+//  final layer       scale                         shift, scale                        shift, scale
+struct VariantDesc {
+    int chunks;                  // adaLN chunks per layer
+    int i_shift[2], i_scale[2], i_gate[2];  // chunk index of {attention, ffn} branch; -1 = absent
+    bool pre_w, post, gate_tanh, text, labels, rope_1d, eol;
+    int final_chunks;            // 1: scale;  2: shift, scale
+};
+
+static VariantDesc variant_desc(int variant) {
+    VariantDesc v{};
+    if (variant == LT_VARIANT_NEXT_T2I) {
+        v = {4, {-1, -1}, {0, 2}, {1, 3}, true, true, true, true, false, false, false, 1};
+    } else if (variant == LT_VARIANT_NEXT_IMAGENET) {
+        v = {4, {-1, -1}, {0, 2}, {1, 3}, false, true, true, false, true, false, false, 2};
+    } else {  // LT_VARIANT_FLAG_T2I
+        v = {6, {0, 3}, {1, 4}, {2, 5}, true, false, false, true, false, true, true, 2};
+    }
+    return v;
+}
+
 struct lt_engine {
     lt_config cfg;
+    VariantDesc v;
     int d, L, H, Hkv, hd, F, dkv, qkvn, A, cap, nfinal, kpad, chunks, ld_mod;
     std::vector<DevBuf> allocs;
     std::vector<LayerW> lw;
@@ -66,7 +95,8 @@ struct lt_engine {
     u16 *capln_w = nullptr, *capln_b = nullptr, *cape_w = nullptr, *cape_b = nullptr, *pad_token = nullptr;
     u16 *adaln_w = nullptr, *adaln_b = nullptr;  // [L*chunks*d + d, A], [L*chunks*d + d]
     u16 *final_w = nullptr, *final_b = nullptr;
-    u16 *label_table = nullptr;
+    u16 *label_table = nullptr, *eol_token = nullptr;
+    int label_rows = 0;
     std::map<std::string, bool> need;
     bool weights_ok = false;
     // workspace
@@ -76,7 +106,8 @@ struct lt_engine {
     u16 *capb = nullptr, *capn = nullptr, *kvy = nullptr;
     float* txt_bias = nullptr;
     float* rope = nullptr;
-    float rope_scale = -1.f;
+    float rope_scale = -1.f, rope_ntk = -1.f;
+    int rope_len = 0;
     int prompt_B = 0, prompt_T = 0, prompt_Tpad = 0;
     // ode
     void *ys[2] = {nullptr, nullptr}, *ymid = nullptr, *kbuf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -182,10 +213,18 @@ int find_slot(lt_engine* e, const std::string& key, Slot* s) {
         if (r == "feed_forward.w1.weight") return set(w.w13, F, d, d, 0, 1);
         if (r == "feed_forward.w3.weight") return set(w.w13, F, d, d, 0, 2);
         if (r == "feed_forward.w2.weight") return set(w.w2, d, F, F);
-        if (r == "attention_norm1.weight") return set(w.attn_norm1, 1, d, d);
-        if (r == "attention_norm2.weight") return set(w.attn_norm2, 1, d, d);
-        if (r == "ffn_norm1.weight") return set(w.ffn_norm1, 1, d, d);
-        if (r == "ffn_norm2.weight") return set(w.ffn_norm2, 1, d, d);
+        if (e->cfg.variant == LT_VARIANT_NEXT_T2I) {
+            if (r == "attention_norm1.weight") return set(w.attn_norm1, 1, d, d);
+            if (r == "attention_norm2.weight") return set(w.attn_norm2, 1, d, d);
+            if (r == "ffn_norm1.weight") return set(w.ffn_norm1, 1, d, d);
+            if (r == "ffn_norm2.weight") return set(w.ffn_norm2, 1, d, d);
+        } else if (e->cfg.variant == LT_VARIANT_NEXT_IMAGENET) {  // post-norms carry the weight (models.py:735-738)
+            if (r == "attention_norm.weight") return set(w.attn_norm2, 1, d, d);
+            if (r == "ffn_norm.weight") return set(w.ffn_norm2, 1, d, d);
+        } else {  // Flag-DiT: pre-norms only (lumina_t2i model.py:556-557)
+            if (r == "attention_norm.weight") return set(w.attn_norm1, 1, d, d);
+            if (r == "ffn_norm.weight") return set(w.ffn_norm1, 1, d, d);
+        }
         if (r == "attention_y_norm.weight") return set(w.y_norm, 1, cap, cap);
         if (r == "adaLN_modulation.1.weight") return set(e->adaln_w, cd, A, A, l * cd);
         if (r == "adaLN_modulation.1.bias") return set(e->adaln_b + (size_t)l * cd, 1, cd, cd);
@@ -202,58 +241,82 @@ int find_slot(lt_engine* e, const std::string& key, Slot* s) {
         if (key == "cap_embedder.1.weight") return set(e->cape_w, A, cap, cap);
         if (key == "cap_embedder.1.bias") return set(e->cape_b, 1, A, A);
         if (key == "pad_token") return set(e->pad_token, 1, d, d);
+        if (key == "eol_token" && e->v.eol) return set(e->eol_token, 1, d, d);
+        if (key == "y_embedder.embedding_table.weight" && e->v.labels) return set(e->label_table, e->label_rows, A, A);
+        const int fd = e->v.final_chunks * d;
         if (key == "final_layer.linear.weight") return set(e->final_w, e->nfinal, d, d);
         if (key == "final_layer.linear.bias") return set(e->final_b, 1, e->nfinal, e->nfinal);
-        if (key == "final_layer.adaLN_modulation.1.weight") return set(e->adaln_w, d, A, A, e->L * cd);
-        if (key == "final_layer.adaLN_modulation.1.bias") return set(e->adaln_b + (size_t)e->L * cd, 1, d, d);
+        if (key == "final_layer.adaLN_modulation.1.weight") return set(e->adaln_w, fd, A, A, e->L * cd);
+        if (key == "final_layer.adaLN_modulation.1.bias") return set(e->adaln_b + (size_t)e->L * cd, 1, fd, fd);
     }
     lt_set_error("unknown weight key '%s' for this variant", key.c_str());
     return 2;
 }
 
-int ensure_rope(lt_engine* e, float scale_factor, hipStream_t s) {
-    if (e->rope_scale == scale_factor) return 0;
-    if (launch_rope_table_2d(e->rope, e->cfg.rope_table_len, e->hd, 10000.0f, scale_factor, s)) return 1;
-    e->rope_scale = scale_factor;
+// (cos,sin) factor table(s) for this call's RoPE arguments; rebuilt only when they change
+int ensure_rope(lt_engine* e, const lt_step_args* a, hipStream_t s) {
+    const float ntk = a->ntk_factor > 0.f ? a->ntk_factor : 1.0f;
+    const float sf = a->scale_factor > 0.f ? a->scale_factor : 1.0f;
+    if (e->rope_scale == sf && e->rope_ntk == ntk) return 0;
+    if (e->cfg.variant == LT_VARIANT_NEXT_T2I) {
+        if (launch_rope_table_2d(e->rope, e->rope_len, e->hd, 10000.0f, sf, s)) return 1;
+    } else {
+        // both branches identical: theta * ntk_factor, positions / rope_scaling_factor (models.py:1001-1005, model.py:948-955)
+        const int step = e->v.rope_1d ? 2 : 4;
+        if (launch_rope_table(e->rope, e->rope_len, e->hd, step, 10000.0f * ntk, sf, 10000.0f * ntk, sf, 1, s)) return 1;
+    }
+    e->rope_scale = sf;
+    e->rope_ntk = ntk;
     return 0;
 }
 
-// one NextDiT.forward (model.py:836-864) [+ CFG combine model.py:901-913]
+// one forward pass of the configured family [+ CFG combine]:
+//   NextDiT.forward / forward_with_cfg   lumina_next_t2i/models/model.py:836-913
+//   DiT_Llama (ImageNet)                 Next-DiT-ImageNet/models/models.py:920-974
+//   DiT_Llama (Flag-DiT)                 lumina_t2i/models/model.py:829-922
 int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, const lt_step_args* a, int use_cfg,
                 hipStream_t s) {
     const lt_config& c = e->cfg;
+    const VariantDesc& v = e->v;
     const int B = a->batch, p = c.patch_size;
     LT_REQUIRE(B >= 1 && B <= c.max_batch, "batch %d exceeds max_batch %d", B, c.max_batch);
     LT_REQUIRE(!use_cfg || B % 2 == 0, "forward_with_cfg needs an even batch (cond+uncond)");
     LT_REQUIRE(a->latent_h % p == 0 && a->latent_w % p == 0, "latent %dx%d not divisible by patch", a->latent_h, a->latent_w);
-    const int Hp = a->latent_h / p, Wp = a->latent_w / p, N = Hp * Wp, M = B * N;
+    const int Hp = a->latent_h / p, Wp = a->latent_w / p;
+    const int Wrow = v.eol ? Wp + 1 : Wp;  // tokens per latent row (Flag-DiT appends one eol token, model.py:779-786)
+    const int N = Hp * Wrow, M = B * N;
     LT_REQUIRE(N <= c.max_tokens, "%d latent tokens exceed max_tokens %d", N, c.max_tokens);
-    LT_REQUIRE(Hp <= c.rope_table_len && Wp <= c.rope_table_len, "latent grid exceeds the RoPE table (%d)", c.rope_table_len);
+    if (v.rope_1d) LT_REQUIRE(N <= e->rope_len, "sequence of %d tokens exceeds the 1-D RoPE table (%d)", N, e->rope_len);
+    else LT_REQUIRE(Hp <= e->rope_len && Wp <= e->rope_len, "latent grid exceeds the RoPE table (%d)", e->rope_len);
     LT_REQUIRE(a->io_dtype == LT_BF16 || a->io_dtype == LT_F32, "io_dtype must be bf16 or f32");
-    LT_REQUIRE(e->prompt_B == B, "lt_prepare_prompt was called for batch %d, step has batch %d", e->prompt_B, B);
+    LT_REQUIRE(e->prompt_B == B, "%s was called for batch %d, step has batch %d", v.labels ? "lt_prepare_labels" : "lt_prepare_prompt",
+               e->prompt_B, B);
     if (!e->weights_ok && lt_weights_ready(e)) return 2;
     const int d = e->d, L = e->L, H = e->H, Hkv = e->Hkv, hd = e->hd, F = e->F, dkv = e->dkv, A = e->A;
     const int Npad = round_up(N, 64);
     const int cd = e->chunks * d;
 
-    if (ensure_rope(e, a->scale_factor, s)) return 1;
+    if (ensure_rope(e, a, s)) return 1;
     float sm_scale;
-    if (a->proportional_attn) {
+    if (a->proportional_attn && !v.labels) {
         LT_REQUIRE(a->base_seqlen > 1, "proportional_attn needs base_seqlen");
-        // math.sqrt(math.log(seqlen, base_seqlen) / head_dim)  (model.py:374)
+        // math.sqrt(math.log(seqlen, base_seqlen) / head_dim)  (model.py:374; seqlen counts the eol tokens for Flag-DiT)
         sm_scale = (float)std::sqrt(std::log((double)N) / std::log((double)a->base_seqlen) / (double)hd);
     } else {
-        sm_scale = (float)std::sqrt(1.0 / (double)hd);  // model.py:376
+        sm_scale = (float)std::sqrt(1.0 / (double)hd);  // model.py:376; flash_attn_func default (models.py:389)
     }
-    const float txt_scale = (float)(1.0 / std::sqrt((double)hd));  // SDPA default (model.py:427-432)
 
-    // patchify + x_embedder (model.py:777-779)
+    // patchify + x_embedder (model.py:777-779) [+ eol token per row]
     {
         ProfScope ps(e, 2, 0, s);
-        if (launch_patchify(x_in, a->io_dtype, e->patches, B, c.in_channels, a->latent_h, a->latent_w, p, e->kpad, use_cfg, s)) return 1;
+        if (launch_patchify(x_in, a->io_dtype, e->patches, B, c.in_channels, a->latent_h, a->latent_w, p, e->kpad, use_cfg, Wrow, s)) return 1;
     }
     if (gemm(e, e->patches, e->kpad, e->xemb_w, e->kpad, e->x, d, M, d, e->kpad, e->xemb_b, 0, s)) return 1;
-    // conditioning: t_embedder (model.py:84-87) + cap_emb (hoisted) -> adaLN vectors of every layer + final
+    if (v.eol) {
+        ProfScope ps(e, 2, 0, s);
+        if (launch_eol_fill(e->x, e->eol_token, B * Hp, Wp, d, s)) return 1;
+    }
+    // conditioning: t_embedder (model.py:84-87) + caption / label embedding (hoisted) -> adaLN vectors of every layer + final
     {
         ProfScope ps(e, 2, 0, s);
         if (launch_timestep_features(t_dev, 0, e->tfeat, B, 256, s)) return 1;
@@ -262,24 +325,25 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         if (launch_add_bf16(e->temb, e->cap_emb, e->adaln_in, (long long)B * A, s)) return 1;
         if (launch_linear_small_m(e->adaln_in, e->adaln_w, e->adaln_b, e->mod, B, e->ld_mod, A, 1, s)) return 1;
     }
-    // first pre-norm: modulate(attention_norm1(x), scale_msa) (model.py:599)
+    auto chunk = [&](int layer, int idx) -> const u16* { return idx < 0 ? nullptr : e->mod + (size_t)layer * cd + (size_t)idx * d; };
+    // first pre-norm: modulate(attention_norm(x), [shift,] scale) (model.py:599 / models.py:785 / lumina_t2i model.py:600)
     {
         ProfScope ps(e, 2, 0, s);
         NormModArgs n;
-        n.x = e->x; n.w = e->lw[0].attn_norm1; n.scale = e->mod + 0; n.shift = nullptr; n.out = e->h;
-        n.rows = M; n.rows_per_batch = N; n.d = d; n.ld_mod = e->ld_mod; n.eps = c.norm_eps;
+        n.x = e->x; n.w = v.pre_w ? e->lw[0].attn_norm1 : nullptr; n.scale = chunk(0, v.i_scale[0]); n.shift = chunk(0, v.i_shift[0]);
+        n.out = e->h; n.rows = M; n.rows_per_batch = N; n.d = d; n.ld_mod = e->ld_mod; n.eps = c.norm_eps;
         if (launch_rmsnorm_mod(n, s)) return 1;
     }
+    const int post_mode = v.post ? 1 : 0, gate_mode = v.gate_tanh ? 1 : 0;
     for (int l = 0; l < L; ++l) {
         LayerW& w = e->lw[l];
-        const u16* modl = e->mod + (size_t)l * cd;  // chunks: scale_msa, gate_msa, scale_mlp, gate_mlp (model.py:595)
         if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, nullptr, 0, s)) return 1;
         {
             ProfScope ps(e, 2, 0, s);
             QkPostArgs qa;
-            qa.src = e->qkv; qa.ld_src = e->qkvn; qa.B = B; qa.N = N; qa.hd = hd; qa.rope_mode = 1;
-            qa.cs = e->rope; qa.t = t_dev; qa.grid_w = Wp; qa.cs_len = c.rope_table_len; qa.ln_eps = 1e-5f;
-            qa.watershed = a->scale_watershed;
+            qa.src = e->qkv; qa.ld_src = e->qkvn; qa.B = B; qa.N = N; qa.hd = hd; qa.rope_mode = v.rope_1d ? 2 : 1;
+            qa.cs = e->rope; qa.t = t_dev; qa.grid_w = Wp; qa.cs_len = e->rope_len; qa.ln_eps = 1e-5f;
+            qa.watershed = c.variant == LT_VARIANT_NEXT_T2I ? a->scale_watershed : 0.f;  // other families: one table (branch 1)
             qa.col0 = 0; qa.heads = H; qa.dst = e->q;
             qa.ln_w = c.qk_norm ? w.q_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.q_norm_b : nullptr;
             if (launch_qk_norm_rope(qa, s)) return 1;
@@ -294,32 +358,38 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         at.B = B; at.H = H; at.Hkv = Hkv; at.N = N; at.Nk = N; at.Nkpad = Npad; at.hd = hd; at.scale = sm_scale;
         at.k_prescaled = 1;
         if (attention(e, at, s)) return 1;
-        if (e->cap > 0) {  // zero-init gated text cross-attention (model.py:420-434)
+        if (v.text) {  // zero-init gated text cross-attention (model.py:420-434)
             at.k = w.ky; at.vt = w.vty; at.bias = e->txt_bias; at.gate = w.gate; at.accumulate = 1;
-            at.Nk = e->prompt_T; at.Nkpad = e->prompt_Tpad; at.scale = txt_scale;
+            at.Nk = e->prompt_T; at.Nkpad = e->prompt_Tpad; at.scale = (float)(1.0 / std::sqrt((double)hd));
             if (attention(e, at, s)) return 1;
         }
         if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s)) return 1;
-        {
+        {   // x += gate' * post(attn) ; h = pre_ffn(x) * (1 + scale) [+ shift]
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
-            g.x = e->x; g.y = e->o; g.post_w = w.attn_norm2; g.gate = modl + d; g.post_mode = 1; g.gate_mode = 1;
-            g.next_w = w.ffn_norm1; g.next_scale = modl + 2 * d; g.next_shift = nullptr; g.next_mode = 1; g.h = e->h;
+            g.x = e->x; g.y = e->o; g.post_w = v.post ? w.attn_norm2 : nullptr; g.gate = chunk(l, v.i_gate[0]);
+            g.post_mode = post_mode; g.gate_mode = gate_mode;
+            g.next_w = v.pre_w ? w.ffn_norm1 : nullptr; g.next_scale = chunk(l, v.i_scale[1]); g.next_shift = chunk(l, v.i_shift[1]);
+            g.next_mode = 1; g.h = e->h;
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
             if (launch_gated_residual_norm(g, s)) return 1;
         }
         if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s)) return 1;
         if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s)) return 1;
-        {
+        {   // x += gate' * post(ffn) ; h = next layer's pre-norm + modulate, or the final layer's LayerNorm + modulate
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
-            g.x = e->x; g.y = e->o; g.post_w = w.ffn_norm2; g.gate = modl + 3 * d; g.post_mode = 1; g.gate_mode = 1;
-            g.next_shift = nullptr; g.h = e->h;
+            g.x = e->x; g.y = e->o; g.post_w = v.post ? w.ffn_norm2 : nullptr; g.gate = chunk(l, v.i_gate[1]);
+            g.post_mode = post_mode; g.gate_mode = gate_mode; g.h = e->h;
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
             if (l + 1 < L) {
-                g.next_w = e->lw[l + 1].attn_norm1; g.next_scale = e->mod + (size_t)(l + 1) * cd; g.next_mode = 1;
-            } else {  // final layer: LayerNorm(no affine, 1e-6) * (1 + scale) (model.py:657-661)
-                g.next_w = nullptr; g.next_scale = e->mod + (size_t)L * cd; g.next_mode = 2;
+                g.next_w = v.pre_w ? e->lw[l + 1].attn_norm1 : nullptr; g.next_scale = chunk(l + 1, v.i_scale[0]);
+                g.next_shift = chunk(l + 1, v.i_shift[0]); g.next_mode = 1;
+            } else {  // final layer: LayerNorm(no affine, 1e-6) * (1 + scale) [+ shift] (model.py:657-661 / models.py:829-832)
+                const u16* fin = e->mod + (size_t)L * cd;
+                g.next_w = nullptr; g.next_mode = 2;
+                g.next_shift = v.final_chunks == 2 ? fin : nullptr;
+                g.next_scale = v.final_chunks == 2 ? fin + d : fin;
             }
             if (launch_gated_residual_norm(g, s)) return 1;
         }
@@ -329,7 +399,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         ProfScope ps(e, 2, 0, s);
         const int cfg_ch = a->cfg_channels > 0 ? a->cfg_channels : 3;
         if (launch_unpatchify_cfg(e->frows, e->nfinal, out, a->io_dtype, B, c.in_channels, c.out_channels, a->latent_h,
-                                  a->latent_w, p, use_cfg, a->cfg_scale, cfg_ch, s)) return 1;
+                                  a->latent_w, p, use_cfg, a->cfg_scale, cfg_ch, Wrow, s)) return 1;
     }
     return 0;
 }
@@ -348,22 +418,29 @@ float bf16_round_host(float f) {
 // =====================================================================================================
 extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     LT_REQUIRE(cfg && out, "lt_create: null argument");
-    LT_REQUIRE(cfg->variant == LT_VARIANT_NEXT_T2I, "lt_create: variant %d not built in this round (next_t2i only)", cfg->variant);
+    LT_REQUIRE(cfg->variant == LT_VARIANT_NEXT_T2I || cfg->variant == LT_VARIANT_NEXT_IMAGENET || cfg->variant == LT_VARIANT_FLAG_T2I,
+               "lt_create: unknown variant %d", cfg->variant);
+    const VariantDesc vd = variant_desc(cfg->variant);
     LT_REQUIRE(cfg->dim % cfg->n_heads == 0, "dim %% n_heads != 0");
     LT_REQUIRE(cfg->n_heads % cfg->n_kv_heads == 0, "n_heads %% n_kv_heads != 0");
     const int hd = cfg->dim / cfg->n_heads;
     LT_REQUIRE(hd == 48 || hd == 72 || hd == 96, "head_dim %d not built (48, 72, 96)", hd);
     LT_REQUIRE(cfg->dim % 64 == 0 && cfg->ffn_hidden % 64 == 0, "dim and ffn_hidden must be multiples of 64");
-    LT_REQUIRE(cfg->cap_feat_dim % 64 == 0 && cfg->cap_feat_dim > 0, "cap_feat_dim must be a positive multiple of 64");
+    LT_REQUIRE(!vd.text || (cfg->cap_feat_dim % 64 == 0 && cfg->cap_feat_dim > 0), "cap_feat_dim must be a positive multiple of 64");
+    LT_REQUIRE(!vd.labels || cfg->num_classes > 0, "class-conditional variant needs num_classes > 0");
     LT_REQUIRE(cfg->dim <= 4096 && cfg->cap_feat_dim <= 4096, "dim / cap_feat_dim above 4096 not supported by the row kernels");
     LT_REQUIRE(cfg->adaln_dim % 8 == 0 && cfg->max_batch >= 1 && cfg->max_batch <= 8, "adaln_dim %% 8 and 1 <= max_batch <= 8 required");
     LT_REQUIRE(cfg->in_channels * cfg->patch_size * cfg->patch_size <= 64, "patch vector longer than 64");
     lt_engine* e = new lt_engine();
     e->cfg = *cfg;
+    e->v = vd;
     e->d = cfg->dim; e->L = cfg->n_layers; e->H = cfg->n_heads; e->Hkv = cfg->n_kv_heads; e->hd = hd;
     e->F = cfg->ffn_hidden; e->dkv = e->Hkv * hd; e->qkvn = e->d + 2 * e->dkv; e->A = cfg->adaln_dim;
-    e->cap = cfg->cap_feat_dim; e->nfinal = cfg->patch_size * cfg->patch_size * cfg->out_channels;
-    e->kpad = 64; e->chunks = 4; e->ld_mod = e->L * e->chunks * e->d + e->d;
+    e->cap = vd.text ? cfg->cap_feat_dim : 0; e->nfinal = cfg->patch_size * cfg->patch_size * cfg->out_channels;
+    e->kpad = 64; e->chunks = vd.chunks; e->ld_mod = e->L * e->chunks * e->d + vd.final_chunks * e->d;
+    e->label_rows = vd.labels ? cfg->num_classes + 1 : 0;
+    // 2-D RoPE: positions per axis (384, model.py:734); 1-D: one position per token of the longest sequence
+    e->rope_len = vd.rope_1d ? round_up(cfg->max_tokens, 64) : (cfg->rope_table_len > 0 ? cfg->rope_table_len : 384);
     const int d = e->d, L = e->L, F = e->F, dkv = e->dkv, A = e->A, cap = e->cap, H = e->H, Hkv = e->Hkv;
     e->lw.resize(L);
     auto fail = [&]() { lt_destroy(e); return 1; };
@@ -372,48 +449,55 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     for (int l = 0; l < L; ++l) {
         LayerW& w = e->lw[l];
         A16(w.wqkv, (size_t)e->qkvn * d); A16(w.wo, (size_t)d * d); A16(w.w13, (size_t)2 * F * d); A16(w.w2, (size_t)d * F);
-        A16(w.wkvy, (size_t)2 * dkv * cap);
         A16(w.q_norm_w, d); A16(w.q_norm_b, d); A16(w.k_norm_w, dkv); A16(w.k_norm_b, dkv);
-        A16(w.ky_norm_w, dkv); A16(w.ky_norm_b, dkv); A16(w.gate, H);
-        A16(w.attn_norm1, d); A16(w.attn_norm2, d); A16(w.ffn_norm1, d); A16(w.ffn_norm2, d); A16(w.y_norm, cap);
-        A16(w.ky, (size_t)cfg->max_batch * Hkv * Tmax * hd); A16(w.vty, (size_t)cfg->max_batch * Hkv * hd * Tmax);
-        char key[128];
-        const char* names[] = {"attention.wq.weight", "attention.wk.weight", "attention.wv.weight", "attention.wo.weight",
-                               "attention.wk_y.weight", "attention.wv_y.weight", "attention.gate", "feed_forward.w1.weight",
-                               "feed_forward.w2.weight", "feed_forward.w3.weight", "attention_norm1.weight",
-                               "attention_norm2.weight", "ffn_norm1.weight", "ffn_norm2.weight", "attention_y_norm.weight",
-                               "adaLN_modulation.1.weight", "adaLN_modulation.1.bias"};
-        for (const char* nm : names) { snprintf(key, sizeof(key), "layers.%d.%s", l, nm); e->need[key] = false; }
-        if (cfg->qk_norm) {
-            const char* qn[] = {"attention.q_norm.weight", "attention.q_norm.bias", "attention.k_norm.weight",
-                                "attention.k_norm.bias", "attention.ky_norm.weight", "attention.ky_norm.bias"};
-            for (const char* nm : qn) { snprintf(key, sizeof(key), "layers.%d.%s", l, nm); e->need[key] = false; }
+        A16(w.attn_norm1, d); A16(w.attn_norm2, d); A16(w.ffn_norm1, d); A16(w.ffn_norm2, d);
+        if (vd.text) {
+            A16(w.wkvy, (size_t)2 * dkv * cap); A16(w.ky_norm_w, dkv); A16(w.ky_norm_b, dkv); A16(w.gate, H); A16(w.y_norm, cap);
+            A16(w.ky, (size_t)cfg->max_batch * Hkv * Tmax * hd); A16(w.vty, (size_t)cfg->max_batch * Hkv * hd * Tmax);
         }
+        char key[128];
+        std::vector<const char*> names = {"attention.wq.weight", "attention.wk.weight", "attention.wv.weight", "attention.wo.weight",
+                                          "feed_forward.w1.weight", "feed_forward.w2.weight", "feed_forward.w3.weight",
+                                          "adaLN_modulation.1.weight", "adaLN_modulation.1.bias"};
+        if (vd.text) for (const char* nm : {"attention.wk_y.weight", "attention.wv_y.weight", "attention.gate", "attention_y_norm.weight"}) names.push_back(nm);
+        if (cfg->variant == LT_VARIANT_NEXT_T2I)
+            for (const char* nm : {"attention_norm1.weight", "attention_norm2.weight", "ffn_norm1.weight", "ffn_norm2.weight"}) names.push_back(nm);
+        else
+            for (const char* nm : {"attention_norm.weight", "ffn_norm.weight"}) names.push_back(nm);
+        if (cfg->qk_norm) {
+            for (const char* nm : {"attention.q_norm.weight", "attention.q_norm.bias", "attention.k_norm.weight", "attention.k_norm.bias"}) names.push_back(nm);
+            if (vd.text) for (const char* nm : {"attention.ky_norm.weight", "attention.ky_norm.bias"}) names.push_back(nm);
+        }
+        for (const char* nm : names) { snprintf(key, sizeof(key), "layers.%d.%s", l, nm); e->need[key] = false; }
     }
     A16(e->xemb_w, (size_t)d * e->kpad); A16(e->xemb_b, d); A16(e->t0_w, (size_t)A * 256); A16(e->t0_b, A);
-    A16(e->t2_w, (size_t)A * A); A16(e->t2_b, A); A16(e->capln_w, cap); A16(e->capln_b, cap);
-    A16(e->cape_w, (size_t)A * cap); A16(e->cape_b, A); A16(e->pad_token, d);
+    A16(e->t2_w, (size_t)A * A); A16(e->t2_b, A); A16(e->pad_token, d);
+    if (vd.text) { A16(e->capln_w, cap); A16(e->capln_b, cap); A16(e->cape_w, (size_t)A * cap); A16(e->cape_b, A); }
+    if (vd.labels) A16(e->label_table, (size_t)e->label_rows * A);
+    if (vd.eol) A16(e->eol_token, d);
     A16(e->adaln_w, (size_t)e->ld_mod * A); A16(e->adaln_b, e->ld_mod);
     A16(e->final_w, (size_t)e->nfinal * d); A16(e->final_b, e->nfinal);
     for (const char* nm : {"x_embedder.weight", "x_embedder.bias", "t_embedder.mlp.0.weight", "t_embedder.mlp.0.bias",
-                           "t_embedder.mlp.2.weight", "t_embedder.mlp.2.bias", "cap_embedder.0.weight", "cap_embedder.0.bias",
-                           "cap_embedder.1.weight", "cap_embedder.1.bias", "final_layer.linear.weight", "final_layer.linear.bias",
+                           "t_embedder.mlp.2.weight", "t_embedder.mlp.2.bias", "final_layer.linear.weight", "final_layer.linear.bias",
                            "final_layer.adaLN_modulation.1.weight", "final_layer.adaLN_modulation.1.bias"})
         e->need[nm] = false;
+    if (vd.text) for (const char* nm : {"cap_embedder.0.weight", "cap_embedder.0.bias", "cap_embedder.1.weight", "cap_embedder.1.bias"}) e->need[nm] = false;
+    if (vd.labels) e->need["y_embedder.embedding_table.weight"] = false;
+    if (vd.eol) e->need["eol_token"] = false;
     // workspace
     const size_t Bm = cfg->max_batch, Nm = cfg->max_tokens, M = Bm * Nm;
     const size_t Npad = round_up((int)Nm, 64);
     A16(e->x, M * d); A16(e->h, M * d); A16(e->qkv, M * e->qkvn); A16(e->q, M * d); A16(e->k, M * dkv);
     A16(e->vt, Bm * Hkv * hd * Npad); A16(e->attn, M * d); A16(e->o, M * d); A16(e->u, M * F);
     A16(e->patches, M * e->kpad); A16(e->frows, M * e->nfinal); A16(e->mod, Bm * e->ld_mod);
-    A16(e->tfeat, Bm * 256); A16(e->t1, Bm * A); A16(e->temb, Bm * A); A16(e->cap_ln, Bm * cap);
+    A16(e->tfeat, Bm * 256); A16(e->t1, Bm * A); A16(e->temb, Bm * A);
     A16(e->cap_emb, Bm * A); A16(e->adaln_in, Bm * A);
-    A16(e->capb, Bm * Tmax * cap); A16(e->capn, Bm * Tmax * cap); A16(e->kvy, Bm * Tmax * 2 * dkv);
+    if (vd.text) { A16(e->cap_ln, Bm * cap); A16(e->capb, Bm * Tmax * cap); A16(e->capn, Bm * Tmax * cap); A16(e->kvy, Bm * Tmax * 2 * dkv); }
     {
         void* p;
         if (dev_alloc(e, &p, Bm * Tmax * sizeof(float))) return fail();
         e->txt_bias = (float*)p;
-        if (dev_alloc(e, &p, (size_t)2 * cfg->rope_table_len * (hd / 2) * 2 * sizeof(float))) return fail();
+        if (dev_alloc(e, &p, (size_t)2 * e->rope_len * (hd / 2) * 2 * sizeof(float))) return fail();
         e->rope = (float*)p;
         const size_t state = Bm * cfg->in_channels * Nm * cfg->patch_size * cfg->patch_size * sizeof(float);
         for (int i = 0; i < 2; ++i) { if (dev_alloc(e, &e->ys[i], state)) return fail(); }
@@ -460,6 +544,7 @@ extern "C" int lt_weights_ready(lt_engine* e) {
 extern "C" int lt_prepare_prompt(lt_engine* e, const void* cap_feats_dev, int32_t cap_dtype, const int32_t* cap_mask_dev,
                                  int32_t B, int32_t T, void* stream) {
     LT_REQUIRE(e && cap_feats_dev && cap_mask_dev, "lt_prepare_prompt: null argument");
+    LT_REQUIRE(e->v.text, "lt_prepare_prompt: this variant is class-conditional (use lt_prepare_labels)");
     hipStream_t s = (hipStream_t)stream;
     const lt_config& c = e->cfg;
     const int Tmax = round_up(c.max_text > 0 ? c.max_text : 64, 64);
@@ -497,9 +582,15 @@ extern "C" int lt_prepare_prompt(lt_engine* e, const void* cap_feats_dev, int32_
 }
 
 extern "C" int lt_prepare_labels(lt_engine* e, const int32_t* labels_dev, int32_t B, void* stream) {
-    (void)e; (void)labels_dev; (void)B; (void)stream;
-    lt_set_error("lt_prepare_labels: class-conditional variant not built in this round");
-    return 2;
+    LT_REQUIRE(e && labels_dev, "lt_prepare_labels: null argument");
+    LT_REQUIRE(e->v.labels, "lt_prepare_labels: this variant is text-conditional (use lt_prepare_prompt)");
+    LT_REQUIRE(B >= 1 && B <= e->cfg.max_batch, "label batch %d exceeds max_batch %d", B, e->cfg.max_batch);
+    if (lt_weights_ready(e)) return 2;
+    ProfScope ps(e, 2, 0, (hipStream_t)stream);
+    // y_embedder(y) in eval mode (models.py:216-221) -> the label half of adaln_input (models.py:937-939)
+    if (launch_label_gather(e->label_table, labels_dev, e->cap_emb, B, e->label_rows, e->A, (hipStream_t)stream)) return 1;
+    e->prompt_B = B; e->prompt_T = 0; e->prompt_Tpad = 0;
+    return 0;
 }
 
 extern "C" int lt_forward(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev, const lt_step_args* a, void* stream) {

@@ -86,9 +86,13 @@ int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int 
 // weights upload: cast src (f32/bf16/f16) to bf16 rows at dst (+ row offset handled by caller)
 int launch_cast_to_bf16(const void* src, int dtype, u16* dst, long long n, hipStream_t stream);
 // x [B,C,H,W] (bf16/f32) -> patch rows [B*N, kpad] bf16, (c,ph,pw) order, zero padded (model.py:777)
+// wp_stride: tokens per latent row in `out` (0 = W / patch; W / patch + 1 leaves one eol slot per row untouched)
 int launch_patchify(const void* x, int x_dtype, u16* out, int B, int C, int H, int W, int patch, int kpad,
-                    int dup_first_half, hipStream_t stream);
-// Flag-DiT eol variant handled by engine with the same kernel + a row fill (later round)
+                    int dup_first_half, int wp_stride, hipStream_t stream);
+// Flag-DiT: the last token of each latent row is the learned eol_token (lumina_t2i/models/model.py:779-786)
+int launch_eol_fill(u16* x, const u16* eol, int rows_total, int Wp, int d, hipStream_t stream);
+// class-conditional variants: out[b] = table[labels[b]] (bf16 [rows, d] table)
+int launch_label_gather(const u16* table, const int32_t* labels, u16* out, int B, int rows, int d, hipStream_t stream);
 // sinusoidal timestep features (model.py:63-82): t [B] f32 -> [B, dim] bf16 (cos block then sin block)
 int launch_timestep_features(const float* t, int t_index, u16* out, int B, int dim, hipStream_t stream);
 // masked mean pool + affine LayerNorm (model.py:847-849, cap_embedder.0): -> [B, C] bf16
@@ -101,7 +105,7 @@ int launch_mask_to_bias(const int32_t* mask, float* bias, int B, int T, int Tpad
 // final projection rows [B*N, ld] bf16 -> unpatchify (model.py:749-755), keep first C channels,
 // optional CFG combine on cfg_channels (model.py:908-913); out [B,C,H,W] bf16/f32
 int launch_unpatchify_cfg(const u16* rows, int ld, void* out, int out_dtype, int B, int C, int out_ch, int H, int W,
-                          int patch, int use_cfg, float cfg_scale, int cfg_channels, hipStream_t stream);
+                          int patch, int use_cfg, float cfg_scale, int cfg_channels, int wp_stride, hipStream_t stream);
 // torchdiffeq fixed-grid state arithmetic (modes documented in misc.hip)
 int launch_ode_combine(int mode, const void* y0, const void* k1, const void* k2, const void* k3, const void* k4,
                        void* out, int dtype, float dt, long long n, hipStream_t stream);
@@ -110,4 +114,7 @@ int launch_ode_combine(int mode, const void* y0, const void* k1, const void* k2,
 int launch_upload_rows(const void* src, int dtype, u16* dst, int rows, int cols, int dst_ld, int r0, int row_map,
                        hipStream_t stream);
 int launch_rope_table_2d(float* out, int len, int hd, float theta, float scale_factor, hipStream_t stream);
+// general (cos,sin) factor table, two branches: out[b][pos][fi], fi < hd / step (step 4 = 2-D RoPE axis table, 2 = 1-D)
+int launch_rope_table(float* out, int len, int hd, int step, float theta0, float lin0, float theta1, float lin1,
+                      int lin_on_pos, hipStream_t stream);
 int launch_fill_rows_bf16(u16* dst, const u16* row, long long rows, int d, hipStream_t stream);

@@ -58,8 +58,10 @@ __global__ void cast_to_bf16_kernel(const void* __restrict__ src, int dtype, u16
 }
 
 // patchify (model.py:776-777): rows (b, i, j), columns (c, ph, pw); zero padded to kpad
+// wp_stride = tokens per latent row in the output (Wp, or Wp + 1 when every row carries an eol token: Flag-DiT,
+// lumina_t2i/models/model.py:779-786 - the eol rows are left untouched here and filled by eol_fill_kernel)
 __global__ void patchify_kernel(const void* __restrict__ x, int x_dtype, u16* __restrict__ out, int B, int C, int H,
-                                int W, int patch, int kpad, int dup_first_half) {
+                                int W, int patch, int kpad, int dup_first_half, int wp_stride) {
     const int Hp = H / patch, Wp = W / patch;
     const long long total = (long long)B * Hp * Wp * kpad;
     const int kreal = C * patch * patch;
@@ -76,8 +78,32 @@ __global__ void patchify_kernel(const void* __restrict__ x, int x_dtype, u16* __
             const size_t idx = (((size_t)b * C + c) * H + (ii * patch + ph)) * W + (j * patch + pw);
             v = x_dtype == 0 ? f2bf(((const float*)x)[idx]) : ((const u16*)x)[idx];
         }
-        out[i] = v;
+        const long long orow = (row / Wp) * wp_stride + (row % Wp);
+        out[orow * kpad + k] = v;
     }
+}
+
+// rows[(b * Hp + r) * (Wp + 1) + Wp][:] = eol_token  (lumina_t2i/models/model.py:779-786)
+__global__ void eol_fill_kernel(u16* __restrict__ x, const u16* __restrict__ eol, int rows_total, int Wp, int d) {
+    const int chunks = d >> 3;
+    const long long total = (long long)rows_total * chunks;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const long long r = i / chunks;
+        *(bf8_t*)(x + ((r * (Wp + 1) + Wp) * (long long)d) + c * 8) = *(const bf8_t*)(eol + c * 8);
+    }
+}
+
+// class-conditional embedding lookup: out[b][:] = table[labels[b]][:]  (ParallelLabelEmbedder.forward in eval,
+// Next-DiT-ImageNet/models/models.py:216-221; the null class is row num_classes)
+__global__ void label_gather_kernel(const u16* __restrict__ table, const int32_t* __restrict__ labels, u16* __restrict__ out,
+                                    int B, int rows, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d) return;
+    const int b = i / d, c = i % d;
+    int l = labels[b];
+    l = l < 0 ? 0 : (l >= rows ? rows - 1 : l);
+    out[i] = table[(size_t)l * d + c];
 }
 
 // timestep_embedding (model.py:63-82): [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / half), cast bf16 (:86)
@@ -150,17 +176,17 @@ __global__ void mask_to_bias_kernel(const int32_t* mask, float* bias, int B, int
 // CFG on the first cfg_channels channels only (model.py:908-913) with the bf16 rounding of each step.
 __global__ void unpatchify_cfg_kernel(const u16* __restrict__ rows, int ld, void* __restrict__ out, int out_dtype, int B,
                                       int C, int out_ch, int H, int W, int patch, int use_cfg, float cfg_scale,
-                                      int cfg_channels) {
+                                      int cfg_channels, int wp_stride) {
     const long long total = (long long)B * C * H * W;
-    const int Wp = W / patch, Hp = H / patch;
+    const int Hp = H / patch;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int w = (int)(i % W);
         const int hh = (int)((i / W) % H);
         const int c = (int)((i / ((long long)W * H)) % C);
         const int b = (int)(i / ((long long)W * H * C));
         const int e = ((hh % patch) * patch + (w % patch)) * out_ch + c;
-        const long long tok = (long long)(hh / patch) * Wp + (w / patch);
-        auto rd = [&](int bb) { return bf2f(rows[((long long)bb * Hp * Wp + tok) * ld + e]); };
+        const long long tok = (long long)(hh / patch) * wp_stride + (w / patch);  // eol column (if any) is skipped
+        auto rd = [&](int bb) { return bf2f(rows[((long long)bb * Hp * wp_stride + tok) * ld + e]); };
         float v;
         if (use_cfg && c < cfg_channels) {
             const int half = B / 2;
@@ -201,17 +227,20 @@ __global__ void ode_combine_kernel(int mode, const void* y0, const void* k1, con
     else ((float*)out)[i] = r;
 }
 
-// precompute_freqs_cis (model.py:915-963) reduced to its two 1-D factors: out[branch][pos][fi] = cis(pos f_fi)
-__global__ void rope_table_2d_kernel(float* out, int len, int hd, float theta, float scale_factor) {
-    const int nf = hd / 4;
+// precompute_freqs_cis of every sub-project reduced to 1-D factor tables: out[branch][pos][fi] = cis(angle), with
+//   f_fi = theta_b^(-step fi / hd), step = 4 (2-D RoPE: hd/4 frequencies per axis; lumina_next_t2i/models/model.py:915-963,
+//   Next-DiT-ImageNet/models/models.py:977-1012) or 2 (1-D: hd/2 frequencies; lumina_t2i/models/model.py:924-960);
+//   angle = pos * (f / lin_b)   (Next-DiT T2I: the frequency is divided, model.py:952-953)  or
+//           (pos / lin_b) * f   (ImageNet / Flag-DiT: the position is divided, models.py:1003-1005)
+__global__ void rope_table_kernel(float* out, int len, int nf, int step, int hd, float theta0, float lin0, float theta1,
+                                  float lin1, int lin_on_pos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * len * nf) return;
     const int fi = i % nf, pos = (i / nf) % len, branch = i / (nf * len);
-    const float lin = branch == 0 ? scale_factor : 1.0f;
-    const float ntk = branch == 0 ? 1.0f : scale_factor;
-    const float th = theta * ntk;
-    const float freq = 1.0f / powf(th, (float)(4 * fi) / (float)hd) / lin;
-    const float ang = (float)pos * freq;
+    const float lin = branch == 0 ? lin0 : lin1;
+    const float th = branch == 0 ? theta0 : theta1;
+    const float freq = 1.0f / powf(th, (float)(step * fi) / (float)hd);
+    const float ang = lin_on_pos ? ((float)pos / lin) * freq : (float)pos * (freq / lin);
     out[2 * (size_t)i] = cosf(ang);
     out[2 * (size_t)i + 1] = sinf(ang);
 }
@@ -246,7 +275,7 @@ int launch_cast_to_bf16(const void* src, int dtype, u16* dst, long long n, hipSt
 }
 
 int launch_patchify(const void* x, int x_dtype, u16* out, int B, int C, int H, int W, int patch, int kpad,
-                    int dup_first_half, hipStream_t stream) {
+                    int dup_first_half, int wp_stride, hipStream_t stream) {
     LT_REQUIRE(H % patch == 0 && W % patch == 0, "patchify: %dx%d not divisible by patch %d", H, W, patch);
     LT_REQUIRE(C * patch * patch <= kpad, "patchify: kpad too small");
     LT_REQUIRE(!dup_first_half || B % 2 == 0, "patchify: CFG needs an even batch");
@@ -254,7 +283,7 @@ int launch_patchify(const void* x, int x_dtype, u16* out, int B, int C, int H, i
     int g = nblk(total, 256);
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(patchify_kernel, dim3(g), dim3(256), 0, stream, x, x_dtype, out, B, C, H, W, patch, kpad,
-                       dup_first_half);
+                       dup_first_half, wp_stride > 0 ? wp_stride : W / patch);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -289,13 +318,13 @@ int launch_mask_to_bias(const int32_t* mask, float* bias, int B, int T, int Tpad
 }
 
 int launch_unpatchify_cfg(const u16* rows, int ld, void* out, int out_dtype, int B, int C, int out_ch, int H, int W,
-                          int patch, int use_cfg, float cfg_scale, int cfg_channels, hipStream_t stream) {
+                          int patch, int use_cfg, float cfg_scale, int cfg_channels, int wp_stride, hipStream_t stream) {
     LT_REQUIRE(!use_cfg || B % 2 == 0, "unpatchify_cfg: CFG needs an even batch");
     const long long total = (long long)B * C * H * W;
     int g = nblk(total, 256);
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(unpatchify_cfg_kernel, dim3(g), dim3(256), 0, stream, rows, ld, out, out_dtype, B, C, out_ch, H,
-                       W, patch, use_cfg, cfg_scale, cfg_channels);
+                       W, patch, use_cfg, cfg_scale, cfg_channels, wp_stride > 0 ? wp_stride : W / patch);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -313,9 +342,33 @@ int launch_ode_combine(int mode, const void* y0, const void* k1, const void* k2,
 }
 
 int launch_rope_table_2d(float* out, int len, int hd, float theta, float scale_factor, hipStream_t stream) {
-    LT_REQUIRE(hd % 4 == 0, "rope_table_2d: hd %% 4 != 0");
-    hipLaunchKernelGGL(rope_table_2d_kernel, dim3(nblk(2LL * len * (hd / 4), 256)), dim3(256), 0, stream, out, len, hd,
-                       theta, scale_factor);
+    // Next-DiT T2I: branch 0 = linear interpolation (t < watershed), branch 1 = NTK (model.py:944-949)
+    return launch_rope_table(out, len, hd, 4, theta, scale_factor, theta * scale_factor, 1.0f, 0, stream);
+}
+
+int launch_rope_table(float* out, int len, int hd, int step, float theta0, float lin0, float theta1, float lin1,
+                      int lin_on_pos, hipStream_t stream) {
+    LT_REQUIRE(step == 2 || step == 4, "rope_table: step must be 2 (1-D) or 4 (2-D)");
+    LT_REQUIRE(hd % step == 0 && len > 0, "rope_table: hd %% %d != 0", step);
+    LT_REQUIRE(lin0 > 0.f && lin1 > 0.f && theta0 > 0.f && theta1 > 0.f, "rope_table: factors must be positive");
+    const int nf = hd / step;
+    hipLaunchKernelGGL(rope_table_kernel, dim3(nblk(2LL * len * nf, 256)), dim3(256), 0, stream, out, len, nf, step, hd,
+                       theta0, lin0, theta1, lin1, lin_on_pos);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_eol_fill(u16* x, const u16* eol, int rows_total, int Wp, int d, hipStream_t stream) {
+    LT_REQUIRE(d % 8 == 0, "eol_fill: d %% 8 != 0");
+    int g = nblk((long long)rows_total * (d / 8), 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(eol_fill_kernel, dim3(g), dim3(256), 0, stream, x, eol, rows_total, Wp, d);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_label_gather(const u16* table, const int32_t* labels, u16* out, int B, int rows, int d, hipStream_t stream) {
+    hipLaunchKernelGGL(label_gather_kernel, dim3(nblk((long long)B * d, 256)), dim3(256), 0, stream, table, labels, out, B, rows, d);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -65,6 +65,7 @@ class DiTEngine:
             _lib.check(self.lib.lt_create(C.byref(cfg), C.byref(handle)), "lt_create")
         self.handle = handle
         self._prompt_key = None
+        self.num_classes = num_classes
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -113,25 +114,39 @@ class DiTEngine:
         self._keep = (feats, mask)  # keep the temporaries alive until the stream has consumed them
         self._prompt_key = key
 
+    def prepare_labels(self, y: torch.Tensor) -> None:
+        """class-conditional variants: y int [B] (null class = num_classes, Next-DiT-ImageNet/sample.py:181)"""
+        _require_gpu(y, "y")
+        key = ("labels", y.data_ptr(), y._version, tuple(y.shape))
+        if key == self._prompt_key:
+            return
+        lab = y.to(dtype=torch.int32).contiguous()
+        with torch.cuda.device(self.device):
+            rc = self.lib.lt_prepare_labels(self.handle, C.c_void_p(lab.data_ptr()), lab.numel(), C.c_void_p(_stream_ptr(self.device)))
+        _lib.check(rc, "lt_prepare_labels")
+        self._keep = (lab,)
+        self._prompt_key = key
+
     # ---- one model evaluation --------------------------------------------------------------------
     def _step_args(self, x: torch.Tensor, cfg_scale: float, scale_factor: float, scale_watershed: float,
-                   base_seqlen: Optional[int], proportional_attn: bool, cfg_channels: int = 3) -> LtStepArgs:
+                   base_seqlen: Optional[int], proportional_attn: bool, cfg_channels: int = 3,
+                   ntk_factor: float = 1.0) -> LtStepArgs:
         B, Cc, H, W = x.shape
         if x.dtype not in (torch.float32, torch.bfloat16):
             raise LuminaLibError(f"state dtype {x.dtype} unsupported (bf16 or fp32)")
         return LtStepArgs(cfg_scale=float(cfg_scale), scale_factor=float(scale_factor),
                           scale_watershed=float(scale_watershed), base_seqlen=int(base_seqlen or 0),
                           proportional_attn=int(bool(proportional_attn)), latent_h=H, latent_w=W, batch=B,
-                          io_dtype=_DT[x.dtype], cfg_channels=cfg_channels)
+                          io_dtype=_DT[x.dtype], cfg_channels=cfg_channels, ntk_factor=float(ntk_factor))
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, *, use_cfg: bool, cfg_scale: float = 1.0,
                 scale_factor: float = 1.0, scale_watershed: float = 1.0, base_seqlen: Optional[int] = None,
-                proportional_attn: bool = False) -> torch.Tensor:
+                proportional_attn: bool = False, ntk_factor: float = 1.0) -> torch.Tensor:
         _require_gpu(x, "x")
         x = x.contiguous()
         t32 = t.to(device=x.device, dtype=torch.float32).contiguous()
         out = torch.empty_like(x)
-        a = self._step_args(x, cfg_scale, scale_factor, scale_watershed, base_seqlen, proportional_attn)
+        a = self._step_args(x, cfg_scale, scale_factor, scale_watershed, base_seqlen, proportional_attn, ntk_factor=ntk_factor)
         fn = self.lib.lt_forward_cfg if use_cfg else self.lib.lt_forward
         with torch.cuda.device(self.device):
             rc = fn(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(t32.data_ptr()), C.c_void_p(out.data_ptr()),
@@ -143,7 +158,7 @@ class DiTEngine:
     def sample_ode(self, z: torch.Tensor, tgrid: torch.Tensor, method: str, *, use_cfg: bool, cfg_scale: float = 1.0,
                    scale_factor: float = 1.0, scale_watershed: float = 1.0, base_seqlen: Optional[int] = None,
                    proportional_attn: bool = False, t_round_to_state_dtype: bool = True,
-                   return_trajectory: bool = True) -> torch.Tensor:
+                   return_trajectory: bool = True, ntk_factor: float = 1.0) -> torch.Tensor:
         _require_gpu(z, "z")
         if method not in _lib.ODE_METHODS:
             raise LuminaLibError(f"fixed-grid method '{method}' not in {sorted(_lib.ODE_METHODS)}")
@@ -151,7 +166,7 @@ class DiTEngine:
         grid = [float(v) for v in tgrid.detach().to("cpu", torch.float32).tolist()]
         n = len(grid)
         garr = (C.c_float * n)(*grid)
-        a = self._step_args(z, cfg_scale, scale_factor, scale_watershed, base_seqlen, proportional_attn)
+        a = self._step_args(z, cfg_scale, scale_factor, scale_watershed, base_seqlen, proportional_attn, ntk_factor=ntk_factor)
         if return_trajectory:
             out = torch.empty((n,) + tuple(z.shape), dtype=z.dtype, device=z.device)
             traj_ptr, fin_ptr = C.c_void_p(out.data_ptr()), C.c_void_p(0)

@@ -206,6 +206,21 @@ class NextDiT(nn.Module):
         return self._call(x, t, cap_feats, cap_mask, True, cfg_scale=cfg_scale, scale_factor=scale_factor,
                           scale_watershed=scale_watershed, base_seqlen=base_seqlen, proportional_attn=proportional_attn)
 
+    def _engine_sample_ode(self, x, tgrid, method, use_cfg, t_round, kw):
+        """transport fast path (integrators.ode.sample): kwargs of forward_with_cfg / forward -> lt_sample_ode"""
+        cap_feats, cap_mask = kw.pop("cap_feats"), kw.pop("cap_mask")
+        if use_cfg:
+            args = dict(cfg_scale=kw.pop("cfg_scale"), scale_factor=kw.pop("scale_factor", 1.0),
+                        scale_watershed=kw.pop("scale_watershed", 1.0), base_seqlen=kw.pop("base_seqlen", None),
+                        proportional_attn=kw.pop("proportional_attn", False))
+        else:
+            args = dict(scale_factor=self.scale_factor, scale_watershed=0.0)
+        if kw:
+            raise TypeError(f"unexpected model kwargs for the engine path: {sorted(kw)}")
+        eng = self.engine(x, cap_feats.shape[1])
+        eng.prepare_prompt(cap_feats, cap_mask)
+        return eng.sample_ode(x, tgrid, method, use_cfg=use_cfg, t_round_to_state_dtype=t_round, **args)
+
     def parameter_count(self) -> int:
         return sum(p.numel() for p in self.parameters())
 

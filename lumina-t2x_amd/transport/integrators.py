@@ -59,7 +59,7 @@ def _engine_target(model):
     """(NextDiT instance, use_cfg) when ``model`` is one of our engine-backed bound methods, else None."""
     owner = getattr(model, "__self__", None)
     name = getattr(model, "__name__", "")
-    if owner is None or not hasattr(owner, "engine") or not hasattr(owner, "engine_limits"):
+    if owner is None or not hasattr(owner, "_engine_sample_ode"):
         return None
     if name == "forward_with_cfg":
         return owner, True
@@ -100,21 +100,10 @@ class ode:
         return fixed_grid_odeint(_fn, x, self.t.to(device), method=self.sampler_type)
 
     def _sample_on_engine(self, x, target, kw):
+        """whole trajectory in one C-ABI call (lt_sample_ode): the model class maps its own forward / forward_with_cfg
+        kwargs onto the engine (each reference sub-project has a different kwarg set)"""
         owner, use_cfg = target
-        kw = dict(kw)
-        cap_feats, cap_mask = kw.pop("cap_feats"), kw.pop("cap_mask")
-        if use_cfg:
-            args = dict(cfg_scale=kw.pop("cfg_scale"), scale_factor=kw.pop("scale_factor", 1.0),
-                        scale_watershed=kw.pop("scale_watershed", 1.0), base_seqlen=kw.pop("base_seqlen", None),
-                        proportional_attn=kw.pop("proportional_attn", False))
-        else:
-            args = dict(scale_factor=owner.scale_factor, scale_watershed=0.0)
-        if kw:
-            raise TypeError(f"unexpected model kwargs for the engine path: {sorted(kw)}")
-        eng = owner.engine(x, cap_feats.shape[1])
-        eng.prepare_prompt(cap_feats, cap_mask)
-        return eng.sample_ode(x, self.t, self.sampler_type, use_cfg=use_cfg,
-                              t_round_to_state_dtype=self.t_round_to_state_dtype, **args)
+        return owner._engine_sample_ode(x, self.t, self.sampler_type, use_cfg, self.t_round_to_state_dtype, dict(kw))
 
 
 class sde:
