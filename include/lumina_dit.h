@@ -37,6 +37,7 @@ extern "C" {
 #define LT_VARIANT_NEXT_T2I 0      /* lumina_next_t2i/models/model.py:665 NextDiT              */
 #define LT_VARIANT_NEXT_IMAGENET 1 /* Next-DiT-ImageNet/models/models.py:836 DiT_Llama         */
 #define LT_VARIANT_FLAG_T2I 2      /* lumina_t2i/models/model.py:661 DiT_Llama (Flag-DiT)      */
+#define LT_VARIANT_NEXT_MOE 3      /* Next-DiT-MoE/models/models2.py:850 DiT_Llama (time+space MoE) */
 
 /* fixed-grid ODE methods, torchdiffeq names (lumina_next_t2i/transport/integrators.py:115) */
 #define LT_ODE_EULER 0
@@ -64,6 +65,7 @@ typedef struct lt_config {
     int32_t max_tokens;    /* max latent tokens per sample (N)                                    */
     int32_t max_text;      /* max text tokens per sample (T)                                      */
     int32_t rope_table_len;/* 384 (model.py:734); positions per axis in the 2-D RoPE table        */
+    int32_t num_experts;   /* LT_VARIANT_NEXT_MOE: experts per MoE layer (4, models2.py:696); top-2 routing */
 } lt_config;
 
 /* kwargs of NextDiT.forward_with_cfg (model.py:866-877) that are not tensors */

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liblumina_dit.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lumina_dit.h")
 
 LT_F32, LT_BF16, LT_F16 = 0, 1, 2
-LT_VARIANT_NEXT_T2I, LT_VARIANT_NEXT_IMAGENET, LT_VARIANT_FLAG_T2I = 0, 1, 2
+LT_VARIANT_NEXT_T2I, LT_VARIANT_NEXT_IMAGENET, LT_VARIANT_FLAG_T2I, LT_VARIANT_NEXT_MOE = 0, 1, 2, 3
 LT_ODE_EULER, LT_ODE_MIDPOINT, LT_ODE_RK4 = 0, 1, 2
 ODE_METHODS = {"euler": LT_ODE_EULER, "midpoint": LT_ODE_MIDPOINT, "rk4": LT_ODE_RK4}
 
@@ -28,7 +28,7 @@ class LtConfig(C.Structure):
         ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("cap_feat_dim", C.c_int32),
         ("adaln_dim", C.c_int32), ("qk_norm", C.c_int32), ("num_classes", C.c_int32),
         ("norm_eps", C.c_float), ("max_batch", C.c_int32), ("max_tokens", C.c_int32),
-        ("max_text", C.c_int32), ("rope_table_len", C.c_int32),
+        ("max_text", C.c_int32), ("rope_table_len", C.c_int32), ("num_experts", C.c_int32),
     ]
 
 

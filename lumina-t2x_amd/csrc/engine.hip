@@ -45,6 +45,9 @@ struct LayerW {
     u16 *ky_norm_w = nullptr, *ky_norm_b = nullptr, *gate = nullptr;
     u16 *attn_norm1 = nullptr, *attn_norm2 = nullptr, *ffn_norm1 = nullptr, *ffn_norm2 = nullptr, *y_norm = nullptr;
     u16 *ky = nullptr, *vty = nullptr;  // hoisted text K / V^T of the current prompt
+    // MoE family (models2.py:731-745): E experts per branch, w13 packed per expert [E][2F, d], w2 [E][d, F]
+    u16 *w13_t = nullptr, *w2_t = nullptr, *w13_s = nullptr, *w2_s = nullptr, *gate_t = nullptr, *gate_s = nullptr;
+    u16 *norm_time = nullptr, *norm_space = nullptr;
 };
 
 struct ProfClass {
@@ -78,6 +81,10 @@ static VariantDesc variant_desc(int variant) {
         v = {4, {-1, -1}, {0, 2}, {1, 3}, true, true, true, true, false, false, false, 1};
     } else if (variant == LT_VARIANT_NEXT_IMAGENET) {
         v = {4, {-1, -1}, {0, 2}, {1, 3}, false, true, true, false, true, false, false, 2};
+    } else if (variant == LT_VARIANT_NEXT_MOE) {
+        // models2.py:783-784: scale_msa, gate_msa, scale_mlp_time, gate_mlp_time, scale_mlp_space, gate_mlp_space;
+        // index [1] is the time branch, the space branch uses chunks 4 / 5 (run_forward)
+        v = {6, {-1, -1}, {0, 2}, {1, 3}, false, true, true, false, true, false, false, 2};
     } else {  // LT_VARIANT_FLAG_T2I
         v = {6, {0, 3}, {1, 4}, {2, 5}, true, false, false, true, false, true, true, 2};
     }
@@ -103,6 +110,10 @@ struct lt_engine {
     u16 *x = nullptr, *h = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr;
     u16 *o = nullptr, *u = nullptr, *patches = nullptr, *frows = nullptr, *mod = nullptr;
     u16 *tfeat = nullptr, *t1 = nullptr, *temb = nullptr, *cap_ln = nullptr, *cap_emb = nullptr, *adaln_in = nullptr;
+    // MoE workspace: expert-sorted rows (moe.hip)
+    int E = 0, moe_tiles = 0;
+    u16 *moe_xs = nullptr, *moe_us = nullptr, *moe_ys = nullptr, *moe_logits = nullptr, *moe_wts = nullptr;
+    int *moe_sel = nullptr, *moe_pos = nullptr, *moe_tile_expert = nullptr;
     u16 *capb = nullptr, *capn = nullptr, *kvy = nullptr;
     float* txt_bias = nullptr;
     float* rope = nullptr;
@@ -210,10 +221,32 @@ int find_slot(lt_engine* e, const std::string& key, Slot* s) {
         if (r == "attention.ky_norm.weight") return set(w.ky_norm_w, 1, dkv, dkv);
         if (r == "attention.ky_norm.bias") return set(w.ky_norm_b, 1, dkv, dkv);
         if (r == "attention.gate") return set(w.gate, 1, e->H, e->H);
-        if (r == "feed_forward.w1.weight") return set(w.w13, F, d, d, 0, 1);
-        if (r == "feed_forward.w3.weight") return set(w.w13, F, d, d, 0, 2);
-        if (r == "feed_forward.w2.weight") return set(w.w2, d, F, F);
-        if (e->cfg.variant == LT_VARIANT_NEXT_T2I) {
+        if (e->E == 0) {
+            if (r == "feed_forward.w1.weight") return set(w.w13, F, d, d, 0, 1);
+            if (r == "feed_forward.w3.weight") return set(w.w13, F, d, d, 0, 2);
+            if (r == "feed_forward.w2.weight") return set(w.w2, d, F, F);
+        }
+        if (e->cfg.variant == LT_VARIANT_NEXT_MOE) {
+            if (r == "attention_norm.weight") return set(w.attn_norm2, 1, d, d);
+            if (r == "ffn_norm_time.weight") return set(w.norm_time, 1, d, d);
+            if (r == "ffn_norm_space.weight") return set(w.norm_space, 1, d, d);
+            if (r == "feed_forward_time.gate.weight") return set(w.gate_t, e->E, A, A);
+            if (r == "feed_forward_space.gate.weight") return set(w.gate_s, e->E, d, d);
+            for (int br = 0; br < 2; ++br) {
+                const char* pre = br == 0 ? "feed_forward_time.experts." : "feed_forward_space.experts.";
+                const size_t pl = strlen(pre);
+                if (r.compare(0, pl, pre) != 0) continue;
+                char* end = nullptr;
+                const long ex = strtol(r.c_str() + pl, &end, 10);
+                LT_REQUIRE(end != r.c_str() + pl && ex >= 0 && ex < e->E, "weight key %s: expert out of range", key.c_str());
+                const std::string tail(end);
+                u16* w13 = (br == 0 ? w.w13_t : w.w13_s) + (size_t)ex * 2 * F * d;
+                u16* w2 = (br == 0 ? w.w2_t : w.w2_s) + (size_t)ex * d * F;
+                if (tail == ".w1.weight") return set(w13, F, d, d, 0, 1);
+                if (tail == ".w3.weight") return set(w13, F, d, d, 0, 2);
+                if (tail == ".w2.weight") return set(w2, d, F, F);
+            }
+        } else if (e->cfg.variant == LT_VARIANT_NEXT_T2I) {
             if (r == "attention_norm1.weight") return set(w.attn_norm1, 1, d, d);
             if (r == "attention_norm2.weight") return set(w.attn_norm2, 1, d, d);
             if (r == "ffn_norm1.weight") return set(w.ffn_norm1, 1, d, d);
@@ -267,6 +300,49 @@ int ensure_rope(lt_engine* e, const lt_step_args* a, hipStream_t s) {
     }
     e->rope_scale = sf;
     e->rope_ntk = ntk;
+    return 0;
+}
+
+// one MoE feed-forward (branch 0 = TimeMoeLayer on the timestep embedding, 1 = SpaceMoeLayer on the tokens;
+// models2.py:451-506): e->h -> e->o
+int moe_ffn(lt_engine* e, LayerW& w, int branch, int M, int N, int B, hipStream_t s) {
+    const int d = e->d, F = e->F, A = e->A;
+    MoeArgs m;
+    m.x = e->h; m.rows = M; m.rows_per_sample = N; m.d = d; m.E = e->E;
+    m.sel = e->moe_sel; m.wts = e->moe_wts; m.pos = e->moe_pos; m.tile_expert = e->moe_tile_expert; m.max_tiles = e->moe_tiles;
+    m.xs = e->moe_xs; m.ys = e->moe_ys; m.out = e->o;
+    m.gate_w = nullptr; m.sample_logits = nullptr;
+    {
+        ProfScope ps(e, 2, 0, s);
+        if (branch == 0) {  // gate(cond) with cond = t_embedder(t) (models2.py:462, :950-951)
+            if (launch_linear_small_m(e->temb, w.gate_t, nullptr, e->moe_logits, B, e->E, A, 0, s)) return 1;
+            m.sample_logits = e->moe_logits;
+        } else {
+            m.gate_w = w.gate_s;
+        }
+        if (launch_moe_route(m, s)) return 1;
+        if (launch_moe_plan(m, s)) return 1;
+        if (launch_moe_gather(m, s)) return 1;
+    }
+    const int P = e->moe_tiles * 256;
+    GemmArgs g;
+    g.bias = nullptr; g.bias_dtype = -1; g.tile_expert = e->moe_tile_expert;
+    {   // grouped SwiGLU GEMM: each 256-row tile multiplies with its expert's packed w1|w3
+        g.A = e->moe_xs; g.W = branch == 0 ? w.w13_t : w.w13_s; g.C = e->moe_us; g.M = P; g.N = 2 * F; g.K = d;
+        g.lda = d; g.ldw = d; g.ldc = F; g.w_expert_stride = (long long)2 * F * d;
+        ProfScope ps(e, 0, 2.0 * (2.0 * M) * (2.0 * F) * d, s);  // algorithmic: every token visits two experts
+        if (launch_gemm_bf16(g, 1, 0, s)) return 1;
+    }
+    {
+        g.A = e->moe_us; g.W = branch == 0 ? w.w2_t : w.w2_s; g.C = e->moe_ys; g.M = P; g.N = d; g.K = F;
+        g.lda = F; g.ldw = F; g.ldc = d; g.w_expert_stride = (long long)d * F;
+        ProfScope ps(e, 0, 2.0 * (2.0 * M) * (double)d * F, s);
+        if (launch_gemm_bf16(g, 0, 1, s)) return 1;  // 256-row tiles (the tile -> expert table is per 256 rows)
+    }
+    {
+        ProfScope ps(e, 2, 0, s);
+        if (launch_moe_combine(m, s)) return 1;
+    }
     return 0;
 }
 
@@ -374,12 +450,30 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
             if (launch_gated_residual_norm(g, s)) return 1;
         }
-        if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s)) return 1;
-        if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s)) return 1;
+        const u16 *last_post_w, *last_gate;
+        if (e->E == 0) {
+            if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s)) return 1;
+            if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s)) return 1;
+            last_post_w = v.post ? w.ffn_norm2 : nullptr;
+            last_gate = chunk(l, v.i_gate[1]);
+        } else {  // time MoE -> residual -> space MoE (models2.py:793-800)
+            if (moe_ffn(e, w, 0, M, N, B, s)) return 1;
+            {
+                ProfScope ps(e, 2, 0, s);
+                GatedResArgs g;
+                g.x = e->x; g.y = e->o; g.post_w = w.norm_time; g.gate = chunk(l, 3); g.post_mode = 1; g.gate_mode = 1;
+                g.next_w = nullptr; g.next_scale = chunk(l, 4); g.next_shift = nullptr; g.next_mode = 1; g.h = e->h;
+                g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
+                if (launch_gated_residual_norm(g, s)) return 1;
+            }
+            if (moe_ffn(e, w, 1, M, N, B, s)) return 1;
+            last_post_w = w.norm_space;
+            last_gate = chunk(l, 5);
+        }
         {   // x += gate' * post(ffn) ; h = next layer's pre-norm + modulate, or the final layer's LayerNorm + modulate
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
-            g.x = e->x; g.y = e->o; g.post_w = v.post ? w.ffn_norm2 : nullptr; g.gate = chunk(l, v.i_gate[1]);
+            g.x = e->x; g.y = e->o; g.post_w = last_post_w; g.gate = last_gate;
             g.post_mode = post_mode; g.gate_mode = gate_mode; g.h = e->h;
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
             if (l + 1 < L) {
@@ -418,8 +512,9 @@ float bf16_round_host(float f) {
 // =====================================================================================================
 extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     LT_REQUIRE(cfg && out, "lt_create: null argument");
-    LT_REQUIRE(cfg->variant == LT_VARIANT_NEXT_T2I || cfg->variant == LT_VARIANT_NEXT_IMAGENET || cfg->variant == LT_VARIANT_FLAG_T2I,
-               "lt_create: unknown variant %d", cfg->variant);
+    LT_REQUIRE(cfg->variant >= LT_VARIANT_NEXT_T2I && cfg->variant <= LT_VARIANT_NEXT_MOE, "lt_create: unknown variant %d", cfg->variant);
+    LT_REQUIRE(cfg->variant != LT_VARIANT_NEXT_MOE || (cfg->num_experts >= 2 && cfg->num_experts <= 8),
+               "lt_create: the MoE variant needs 2..8 experts (top-2 routing), got %d", cfg->num_experts);
     const VariantDesc vd = variant_desc(cfg->variant);
     LT_REQUIRE(cfg->dim % cfg->n_heads == 0, "dim %% n_heads != 0");
     LT_REQUIRE(cfg->n_heads % cfg->n_kv_heads == 0, "n_heads %% n_kv_heads != 0");
@@ -439,6 +534,7 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     e->cap = vd.text ? cfg->cap_feat_dim : 0; e->nfinal = cfg->patch_size * cfg->patch_size * cfg->out_channels;
     e->kpad = 64; e->chunks = vd.chunks; e->ld_mod = e->L * e->chunks * e->d + vd.final_chunks * e->d;
     e->label_rows = vd.labels ? cfg->num_classes + 1 : 0;
+    e->E = cfg->variant == LT_VARIANT_NEXT_MOE ? cfg->num_experts : 0;
     // 2-D RoPE: positions per axis (384, model.py:734); 1-D: one position per token of the longest sequence
     e->rope_len = vd.rope_1d ? round_up(cfg->max_tokens, 64) : (cfg->rope_table_len > 0 ? cfg->rope_table_len : 384);
     const int d = e->d, L = e->L, F = e->F, dkv = e->dkv, A = e->A, cap = e->cap, H = e->H, Hkv = e->Hkv;
@@ -448,7 +544,13 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     const int Tmax = round_up(cfg->max_text > 0 ? cfg->max_text : 64, 64);
     for (int l = 0; l < L; ++l) {
         LayerW& w = e->lw[l];
-        A16(w.wqkv, (size_t)e->qkvn * d); A16(w.wo, (size_t)d * d); A16(w.w13, (size_t)2 * F * d); A16(w.w2, (size_t)d * F);
+        A16(w.wqkv, (size_t)e->qkvn * d); A16(w.wo, (size_t)d * d);
+        if (e->E == 0) { A16(w.w13, (size_t)2 * F * d); A16(w.w2, (size_t)d * F); }
+        else {
+            const size_t E_ = e->E;
+            A16(w.w13_t, E_ * 2 * F * d); A16(w.w2_t, E_ * d * F); A16(w.w13_s, E_ * 2 * F * d); A16(w.w2_s, E_ * d * F);
+            A16(w.gate_t, E_ * A); A16(w.gate_s, E_ * d); A16(w.norm_time, d); A16(w.norm_space, d);
+        }
         A16(w.q_norm_w, d); A16(w.q_norm_b, d); A16(w.k_norm_w, dkv); A16(w.k_norm_b, dkv);
         A16(w.attn_norm1, d); A16(w.attn_norm2, d); A16(w.ffn_norm1, d); A16(w.ffn_norm2, d);
         if (vd.text) {
@@ -457,11 +559,14 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         }
         char key[128];
         std::vector<const char*> names = {"attention.wq.weight", "attention.wk.weight", "attention.wv.weight", "attention.wo.weight",
-                                          "feed_forward.w1.weight", "feed_forward.w2.weight", "feed_forward.w3.weight",
                                           "adaLN_modulation.1.weight", "adaLN_modulation.1.bias"};
+        if (e->E == 0) for (const char* nm : {"feed_forward.w1.weight", "feed_forward.w2.weight", "feed_forward.w3.weight"}) names.push_back(nm);
         if (vd.text) for (const char* nm : {"attention.wk_y.weight", "attention.wv_y.weight", "attention.gate", "attention_y_norm.weight"}) names.push_back(nm);
         if (cfg->variant == LT_VARIANT_NEXT_T2I)
             for (const char* nm : {"attention_norm1.weight", "attention_norm2.weight", "ffn_norm1.weight", "ffn_norm2.weight"}) names.push_back(nm);
+        else if (cfg->variant == LT_VARIANT_NEXT_MOE)
+            for (const char* nm : {"attention_norm.weight", "ffn_norm_time.weight", "ffn_norm_space.weight",
+                                   "feed_forward_time.gate.weight", "feed_forward_space.gate.weight"}) names.push_back(nm);
         else
             for (const char* nm : {"attention_norm.weight", "ffn_norm.weight"}) names.push_back(nm);
         if (cfg->qk_norm) {
@@ -469,6 +574,12 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
             if (vd.text) for (const char* nm : {"attention.ky_norm.weight", "attention.ky_norm.bias"}) names.push_back(nm);
         }
         for (const char* nm : names) { snprintf(key, sizeof(key), "layers.%d.%s", l, nm); e->need[key] = false; }
+        for (int ex = 0; ex < e->E; ++ex)
+            for (const char* br : {"feed_forward_time", "feed_forward_space"})
+                for (const char* wn : {"w1", "w2", "w3"}) {
+                    snprintf(key, sizeof(key), "layers.%d.%s.experts.%d.%s.weight", l, br, ex, wn);
+                    e->need[key] = false;
+                }
     }
     A16(e->xemb_w, (size_t)d * e->kpad); A16(e->xemb_b, d); A16(e->t0_w, (size_t)A * 256); A16(e->t0_b, A);
     A16(e->t2_w, (size_t)A * A); A16(e->t2_b, A); A16(e->pad_token, d);
@@ -488,7 +599,20 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     const size_t Bm = cfg->max_batch, Nm = cfg->max_tokens, M = Bm * Nm;
     const size_t Npad = round_up((int)Nm, 64);
     A16(e->x, M * d); A16(e->h, M * d); A16(e->qkv, M * e->qkvn); A16(e->q, M * d); A16(e->k, M * dkv);
-    A16(e->vt, Bm * Hkv * hd * Npad); A16(e->attn, M * d); A16(e->o, M * d); A16(e->u, M * F);
+    A16(e->vt, Bm * Hkv * hd * Npad); A16(e->attn, M * d); A16(e->o, M * d);
+    if (e->E == 0) A16(e->u, M * F);
+    else {  // expert-sorted buffers: every row appears twice, each expert segment starts on a 256-row tile
+        e->moe_tiles = (int)((2 * M + (size_t)e->E * 255 + 255) / 256);
+        const size_t P = (size_t)e->moe_tiles * 256;
+        A16(e->moe_xs, P * d); A16(e->moe_us, P * F); A16(e->moe_ys, P * d); A16(e->moe_logits, Bm * e->E); A16(e->moe_wts, 2 * M);
+        void* q;
+        if (dev_alloc(e, &q, 2 * M * sizeof(int))) return fail();
+        e->moe_sel = (int*)q;
+        if (dev_alloc(e, &q, 2 * M * sizeof(int))) return fail();
+        e->moe_pos = (int*)q;
+        if (dev_alloc(e, &q, (size_t)e->moe_tiles * sizeof(int))) return fail();
+        e->moe_tile_expert = (int*)q;
+    }
     A16(e->patches, M * e->kpad); A16(e->frows, M * e->nfinal); A16(e->mod, Bm * e->ld_mod);
     A16(e->tfeat, Bm * 256); A16(e->t1, Bm * A); A16(e->temb, Bm * A);
     A16(e->cap_emb, Bm * A); A16(e->adaln_in, Bm * A);

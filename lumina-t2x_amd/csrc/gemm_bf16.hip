@@ -142,6 +142,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_tn(G
     int tm, tn;
     tile_coords(blockIdx.x, gridDim.x, TM, TN, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    const u16* Wg = p.W;
+    if (p.tile_expert) {  // grouped mode: this 256-row tile belongs to one expert (or is padding)
+        const int ex = p.tile_expert[tm];
+        if (ex < 0) return;
+        Wg += (size_t)ex * p.w_expert_stride;
+    }
 
     // descriptors based at the tile's first row; num_records = bytes left => rows past the end read 0
     const long long a_left = (long long)(p.M - m0) * p.lda * 2;
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_tn(G
     __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.A + (size_t)m0 * p.lda), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
     __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.W + (size_t)n0 * p.ldw), 0, (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left), 0x00020000);
+        (void*)(Wg + (size_t)n0 * p.ldw), 0, (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left), 0x00020000);
 
     // staging: wave w copies pieces w, w + NW, ... of the A tile and of the W tile.  Piece j holds rows
     // 8j..8j+7; the lane's 16-byte chunk c of row r is fetched from source chunk c ^ ((r >> 1) & 7).
@@ -283,8 +289,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     const long long w_left = (long long)(p.N - n0) * p.ldw * 2;
     const int a_bytes = (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left);
     const int w_bytes = (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left);
+    const u16* Wg = p.W;
+    if (p.tile_expert) {  // grouped mode (see GemmArgs); uniform exit before any barrier
+        const int ex = p.tile_expert[tm];
+        if (ex < 0) return;
+        Wg += (size_t)ex * p.w_expert_stride;
+    }
     const u16* a_base = p.A + (size_t)m0 * p.lda;
-    const u16* w_base = p.W + (size_t)n0 * p.ldw;
+    const u16* w_base = Wg + (size_t)n0 * p.ldw;
 
     // staging: wave w owns pieces w, w + NW, ... (a surplus slot re-loads the wave's previous piece: same bytes
     // to the same place, so every wave issues exactly IP loads per slab and one vmcnt literal fits all).

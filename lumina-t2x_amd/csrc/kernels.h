@@ -13,6 +13,10 @@ struct GemmArgs {
     int lda, ldw, ldc;
     int bias_dtype;    // -1 none, 0 f32, 1 bf16
     unsigned long long* trace = nullptr;  // diagnostics only (lt_op_gemm_trace): per-wave cycle totals
+    // grouped (MoE expert) mode: M-tile tm (256 rows) multiplies with W + tile_expert[tm] * w_expert_stride elements;
+    // tile_expert[tm] < 0 -> the tile is padding and the workgroup exits.  Device array of ceil(M / 256) ints.
+    const int* tile_expert = nullptr;
+    long long w_expert_stride = 0;
 };
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream);
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream);
@@ -79,6 +83,26 @@ int launch_attention(const AttnArgs& a, hipStream_t stream);
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
 void lt_set_gemm_pipeline(int v);      // 0 = classic double-buffered loop, 1 = ping-pong wave groups
+
+// ---- mixture-of-experts routing (moe.hip; Next-DiT-MoE/models/models2.py:451-506) --------------------------------
+struct MoeArgs {
+    const u16* x;              // [rows, d] FFN input (after pre-norm + modulate)
+    const u16* gate_w;         // space router weight [E, d] (per-token logits) or null
+    const u16* sample_logits;  // time router logits [B, E] bf16 (every token of a sample shares them) or null
+    int rows, rows_per_sample, d, E;
+    int* sel;                  // [rows, 2] selected experts, ascending expert id (= the reference's accumulation order)
+    u16* wts;                  // [rows, 2] bf16 softmax weights aligned with sel
+    int* pos;                  // [rows, 2] row of each (token, expert) pair in the expert-sorted buffers
+    int* tile_expert;          // [max_tiles] expert of each 256-row tile of the sorted buffers, -1 = padding
+    int max_tiles;
+    u16* xs;                   // [max_tiles * 256, d] expert-sorted copy of x
+    const u16* ys;             // [max_tiles * 256, d] expert outputs in the same order
+    u16* out;                  // [rows, d] combined result
+};
+int launch_moe_route(const MoeArgs& a, hipStream_t stream);    // logits -> top-2, weights
+int launch_moe_plan(const MoeArgs& a, hipStream_t stream);     // counts -> tile-aligned segments, pos, tile_expert
+int launch_moe_gather(const MoeArgs& a, hipStream_t stream);   // xs[pos] = x[row]
+int launch_moe_combine(const MoeArgs& a, hipStream_t stream);  // out[row] = sum over its experts, ascending, bf16 steps
 
 // ---- small kernels (misc.hip) ------------------------------------------------------------------
 int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int M, int N, int K, int act_in,

@@ -42,7 +42,7 @@ class DiTEngine:
 
     def __init__(self, *, variant: int, dim: int, n_layers: int, n_heads: int, n_kv_heads: int, ffn_hidden: int,
                  patch_size: int, in_channels: int, out_channels: int, cap_feat_dim: int, qk_norm: bool,
-                 norm_eps: float, num_classes: int = 0, limits: Optional[EngineLimits] = None,
+                 norm_eps: float, num_classes: int = 0, num_experts: int = 0, limits: Optional[EngineLimits] = None,
                  device: Optional[torch.device] = None):
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda")
@@ -55,7 +55,7 @@ class DiTEngine:
             ffn_hidden=ffn_hidden, patch_size=patch_size, in_channels=in_channels, out_channels=out_channels,
             cap_feat_dim=cap_feat_dim, adaln_dim=min(dim, 1024), qk_norm=int(bool(qk_norm)), num_classes=num_classes,
             norm_eps=norm_eps, max_batch=lim.max_batch, max_tokens=lim.max_tokens, max_text=lim.max_text,
-            rope_table_len=384,
+            rope_table_len=384, num_experts=num_experts,
         )
         self.cfg = cfg
         self.in_channels = in_channels

@@ -1,0 +1,81 @@
+"""Next-DiT with time + space mixture-of-experts FFNs behind the reference's construction / checkpoint / call API.
+
+Source compatibility target: ``Next-DiT-MoE/models/models2.py`` (``DiT_Llama_600M_patch2_Both``, BASELINE configs[4]):
+same constructor / ``forward(x, t, y)`` / ``forward_with_cfg(x, t, y, cfg_scale, rope_scaling_factor, ntk_factor)`` as the
+ImageNet model, blocks with three residual branches (attention, TimeMoeLayer, SpaceMoeLayer; models2.py:692-820).
+Parameters only; the forward runs on the HIP engine (variant ``LT_VARIANT_NEXT_MOE``: device-side top-2 routing,
+expert-sorted rows, grouped GEMMs - csrc/moe.hip).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch.nn as nn
+
+from .. import _lib
+from ..engine import ffn_hidden_dim
+from .components import Linear, RMSNorm
+from .imagenet import Attention, DiT_Llama as _ImageNetDiT
+from .model import FeedForward
+
+
+class MoeLayer(nn.Module):
+    """keys: ``experts.{e}.w1|w2|w3.weight``, ``gate.weight`` (reference models2.py:451-457 / 480-486)"""
+
+    def __init__(self, dim: int, hidden: int, gate_in: int, num_experts: int, num_experts_per_tok: int):
+        super().__init__()
+        self.experts = nn.ModuleList([FeedForward(dim, hidden) for _ in range(num_experts)])
+        self.gate = nn.Linear(gate_in, num_experts, bias=False)
+        self.num_experts_per_tok = num_experts_per_tok
+
+
+class TransformerBlockSandwichNorm2(nn.Module):
+    """reference models2.py:692-768 (num_experts > 0 branch)"""
+
+    def __init__(self, layer_id, dim, n_heads, n_kv_heads, multiple_of, ffn_dim_multiplier, norm_eps, qk_norm,
+                 num_experts: int = 4, num_experts_per_tok: int = 2):
+        super().__init__()
+        assert num_experts > 0, "models2.py:744-752: the dense branch of the reference never defines feed_forward_space"
+        assert num_experts_per_tok == 2, "the engine routes top-2 (the reference's only configuration)"
+        self.dim, self.head_dim, self.layer_id, self.num_experts = dim, dim // n_heads, layer_id, num_experts
+        hidden = ffn_hidden_dim(dim, multiple_of, ffn_dim_multiplier)
+        self.attention = Attention(dim, n_heads, n_kv_heads, qk_norm)
+        self.feed_forward_time = MoeLayer(dim, hidden, min(dim, 1024), num_experts, num_experts_per_tok)
+        self.feed_forward_space = MoeLayer(dim, hidden, dim, num_experts, num_experts_per_tok)
+        self.attention_norm = RMSNorm(dim, eps=norm_eps)
+        self.ffn_norm_time = RMSNorm(dim, eps=norm_eps)
+        self.ffn_norm_space = RMSNorm(dim, eps=norm_eps)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), Linear(min(dim, 1024), 6 * dim, bias=True, init=nn.init.zeros_))
+
+
+class DiT_Llama(_ImageNetDiT):
+    """Constructor signature follows the reference (models2.py:854-870); call surface inherited from the ImageNet class
+    (identical in the reference: models2.py:930-989 vs Next-DiT-ImageNet/models/models.py:920-974)."""
+
+    _variant = _lib.LT_VARIANT_NEXT_MOE
+
+    def __init__(self, input_size: int = 32, patch_size: int = 2, in_channels: int = 4, dim: int = 4096, n_layers: int = 32,
+                 n_heads: int = 32, n_kv_heads: Optional[int] = None, multiple_of: int = 256,
+                 ffn_dim_multiplier: Optional[float] = None, norm_eps: float = 1e-5, class_dropout_prob: float = 0.1,
+                 num_classes: int = 1000, learn_sigma: bool = True, qk_norm: bool = False) -> None:
+        super().__init__(input_size, patch_size, in_channels, dim, 0, n_heads, n_kv_heads, multiple_of, ffn_dim_multiplier,
+                         norm_eps, class_dropout_prob, num_classes, learn_sigma, qk_norm)
+        self.n_layers = n_layers
+        self.num_experts = 4
+        self.layers = nn.ModuleList([
+            TransformerBlockSandwichNorm2(i, dim, n_heads, n_kv_heads, multiple_of, ffn_dim_multiplier, norm_eps, qk_norm)
+            for i in range(n_layers)])
+
+    def _engine_kwargs(self) -> dict:
+        kw = super()._engine_kwargs()
+        kw["num_experts"] = self.num_experts
+        return kw
+
+
+def DiT_Llama_600M_patch2_Both(**kwargs):
+    """reference models2.py:1063-1066 (BASELINE configs[4] architecture)"""
+    return DiT_Llama(patch_size=2, dim=1536, n_layers=16, n_heads=32, **kwargs)
+
+
+def DiT_Llama_600M_GQA_patch2(**kwargs):
+    return DiT_Llama(patch_size=2, dim=1536, n_layers=16, n_heads=32, n_kv_heads=8, **kwargs)
