@@ -56,6 +56,18 @@ def random_init_(model, seed):
                 p.normal_(0.0, min(0.06, p.shape[-1] ** -0.5), generator=g)
 
 
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes of this same command (scripts/gpu_prof.sh ->
+    profiles/rNN/pmc_gemm.json; PMC passes are separate runs by construction).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_gemm.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return float(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], REPO)
+
+
 def cpu_baseline(n_sample_layers=2):
     """Oracle (CPU restatement of the reference forward, fp32, all host cores) on a bounded sample."""
     from oracle import nextdit_oracle as O
@@ -174,6 +186,7 @@ def main():
         attn_ms, attn_n, attn_fl = eng.profile_read(1)
         oth_ms, oth_n, _ = eng.profile_read(2)
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic()
         out = {
             "metric": "denoising-steps/s & latent-tokens/s, Next-DiT 2B 1024^2 CFG",
             "value": world * N_TOKENS * args.steps / dt,
@@ -192,7 +205,8 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "gemm_bf16_tn_256 (all GEMM launches of the timed region)",
                 "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
+                "traffic_source": traffic_src,
                 "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                 "algorithmic_flops_per_launch": gemm_fl / max(gemm_n, 1),
             },
