@@ -187,6 +187,14 @@ int lt_op_attention(const void* q_dev, const void* k_dev, const void* vt_dev, co
                     void* out_dev, const void* gate_dev, int32_t accumulate, int32_t B, int32_t H,
                     int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t hd, float scale,
                     int32_t k_prescaled, void* stream);
+/* self-attention + zero-init gated text cross-attention in ONE launch (hd 72, attention_variant 3; model.py:392-434):
+ *   out = bf16(softmax(q k^T) v) + bf16(bf16(softmax(q tk^T + tbias) tv) * tanh(tgate[h]))
+ * k and tk must already carry their softmax scale * log2(e) (lt_op_qk_norm_rope out_scale); layouts as lt_op_attention,
+ * tk [B,Hkv,Tk,hd], tvt [B,Hkv,hd,Tkpad], tbias float [B,Tkpad] (0 / -inf, -inf in the padding), tgate bf16 [H]. */
+int lt_op_attention_fused(const void* q_dev, const void* k_dev, const void* vt_dev, const void* tk_dev,
+                          const void* tvt_dev, const float* tbias_dev, const void* tgate_dev, void* out_dev, int32_t B,
+                          int32_t H, int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t Tk, int32_t Tkpad,
+                          int32_t hd, void* stream);
 /* diagnostics: the hd-72 self-attention kernel (variant 3) built with s_memtime stamps; trace_dev receives, for every
  * 64th workgroup and each of its 8 waves, 8 x uint64: cycle totals of {X phase (MFMA), DMA wait, barrier, Y phase
  * (softmax + DMA issue), barrier}, the tile count. */

@@ -449,6 +449,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel_v2(AttnArgs p) {
 }
 
 
+}  // namespace
+
+// (named namespace + explicit instantiation: hipcc 7.2 drops the host stub of an internal-linkage kernel template whose
+//  body holds a local class, the same limitation gemm_bf16.hip works around)
+namespace lt_attn {
+
 // ---- v3: ping-pong wave groups for head_dim 72 (the Next-DiT 2B self-attention) ----------------------------------
 // At hd = 72 the softmax VALU work per score is as expensive as the MFMA work (the v2 loop keeps the matrix pipe
 // ~37 % busy), so v3 removes VALU work and makes the two waves of a SIMD alternate between a pure-MFMA phase and
@@ -535,33 +541,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     // 8j..8j+7 (j < 9).  Every wave issues exactly three LDS-DMA loads per batch, branch-free, so one vmcnt literal
     // fits all waves:  A = K piece w;  B = K piece 8 (wave 0) or V piece w-1;  C = V piece 7 (wave 0), 8 (wave 1) or
     // V piece w-1 again (waves 2..7: same bytes to the same place, harmless).
-    const u16* k_head = p.k + (size_t)bhk * p.Nk * HD;
-    const u16* v_head = p.vt + (size_t)bhk * HD * p.Nkpad;
-    const int kbytes = (int)((size_t)p.Nk * HD * 2), vbytes = (int)((size_t)HD * p.Nkpad * 2);
     const bool b_is_k = (wave == 0);
     const int jb = b_is_k ? 8 : wave - 1;
     const int jc = (wave == 0) ? 7 : (wave == 1 ? 8 : wave - 1);
-    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)k_head, 0, kbytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)(b_is_k ? k_head : v_head), 0, b_is_k ? kbytes : vbytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)v_head, 0, vbytes, 0x00020000);
-    auto v_voff = [&](int j) __attribute__((always_inline)) {
-        const int d = 8 * j + (lane >> 3);
-        return d * p.Nkpad * 2 + (((lane & 7) ^ ((d >> 1) & 7)) << 4);
+    // two K / V^T sources to stage from: [0] the image keys, [1] the text keys of the fused cross-attention
+    // (plain arrays with constant indices: a local class holding buffer descriptors breaks hipcc 7.2's host-side pass)
+    __amdgpu_buffer_rsrc_t srcA[2], srcB[2], srcC[2];
+    int svoffB[2], svoffC[2];
+    auto make_src = [&](int which, const u16* k_head, int k_rows, const u16* v_head, int v_ld) __attribute__((always_inline)) {
+        const int kbytes = (int)((size_t)k_rows * HD * 2), vbytes = (int)((size_t)HD * v_ld * 2);
+        auto v_voff = [&](int j) __attribute__((always_inline)) {
+            const int d = 8 * j + (lane >> 3);
+            return d * v_ld * 2 + (((lane & 7) ^ ((d >> 1) & 7)) << 4);
+        };
+        srcA[which] = __builtin_amdgcn_make_buffer_rsrc((void*)k_head, 0, kbytes, 0x00020000);
+        srcB[which] = __builtin_amdgcn_make_buffer_rsrc((void*)(b_is_k ? k_head : v_head), 0, b_is_k ? kbytes : vbytes, 0x00020000);
+        srcC[which] = __builtin_amdgcn_make_buffer_rsrc((void*)v_head, 0, vbytes, 0x00020000);
+        svoffB[which] = b_is_k ? 8 * 1024 + lane * 16 : v_voff(jb);
+        svoffC[which] = v_voff(jc);
     };
+    make_src(0, p.k + (size_t)bhk * p.Nk * HD, p.Nk, p.vt + (size_t)bhk * HD * p.Nkpad, p.Nkpad);
     const int voffA = wave * 1024 + lane * 16;
-    const int voffB = b_is_k ? 8 * 1024 + lane * 16 : v_voff(jb);
-    const int voffC = v_voff(jc);
-    // batch = {K(tk), V(tv)}
-    auto dma_a = [&](int tk) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(smem + K_BASE + (tk & 3) * KTILE + wave * 1024), 16, voffA, tk * KTILE, 0, 0);
+    // batch = {K(tk), V(tv)}; slots are tile index & 3
+    auto dma_a_from = [&](int sr, int tk) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA[sr], LDS_PTR(smem + K_BASE + (tk & 3) * KTILE + wave * 1024), 16, voffA, tk * KTILE, 0, 0);
     };
-    auto dma_b = [&](int tk, int tv) __attribute__((always_inline)) {
+    auto dma_b_from = [&](int sr, int tk, int tv) __attribute__((always_inline)) {
         const int lds = b_is_k ? K_BASE + (tk & 3) * KTILE + 8 * 1024 : V_BASE + (tv & 3) * VTILE + jb * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_PTR(smem + lds), 16, voffB, b_is_k ? tk * KTILE : tv * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB[sr], LDS_PTR(smem + lds), 16, svoffB[sr], b_is_k ? tk * KTILE : tv * 128, 0, 0);
     };
-    auto dma_c = [&](int tv) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rC, LDS_PTR(smem + V_BASE + (tv & 3) * VTILE + jc * 1024), 16, voffC, tv * 128, 0, 0);
+    auto dma_c_from = [&](int sr, int tv) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcC[sr], LDS_PTR(smem + V_BASE + (tv & 3) * VTILE + jc * 1024), 16, svoffC[sr], tv * 128, 0, 0);
     };
+    auto dma_a = [&](int tk) __attribute__((always_inline)) { dma_a_from(0, tk); };
+    auto dma_b = [&](int tk, int tv) __attribute__((always_inline)) { dma_b_from(0, tk, tv); };
+    auto dma_c = [&](int tv) __attribute__((always_inline)) { dma_c_from(0, tv); };
     const int ntile = (p.Nk + 63) / 64;
     // prologue: K(0); K(1), V(0); K(2), V(1)  (the batches X(-3), X(-2), X(-1) would have issued; tile indices past
     // the end read zeros through the descriptor bounds and are never consumed)
@@ -684,14 +698,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     using F_ = std::false_type;
 
     // Y phase: softmax of the tile in sc -> pa
-    auto phase_y = [&](int t) __attribute__((always_inline)) {
-        if (t == ntile - 1 && (p.Nk & 63)) {  // partial last tile: keys past Nk get probability 0
+    auto phase_y_gen = [&](int t, bool tail, int nk, const float* bias) __attribute__((always_inline)) {
+        if (bias) {  // text keys: additive 0 / -inf mask (already in the log2 domain: 0 and -inf are scale free)
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 t4 = *(const f32x4*)(bias + t * 64 + 32 * kt2 + 8 * q4 + 4 * hi);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sc[kt2][4 * q4 + j] += t4[j];
+                }
+        }
+        if (tail) {  // partial last tile: keys past Nk get probability 0
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * 64 + 32 * kt2 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= p.Nk) sc[kt2][r] = -INFINITY;
+                    if (key >= nk) sc[kt2][r] = -INFINITY;
                 }
         }
         float mx = fmaxf(sc[0][0], sc[1][0]);
@@ -735,6 +759,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(pa[g]));
     };
+    auto phase_y = [&](int t) __attribute__((always_inline)) { phase_y_gen(t, t == ntile - 1 && (p.Nk & 63), p.Nk, nullptr); };
 
     unsigned long long tr[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     if constexpr (TRACE) t0 = __builtin_amdgcn_s_memtime();
@@ -789,8 +814,64 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     if (grp == 0) bar();                       // the barrier group 1 still needs after its last Y phase
 
     // l = O^T[HD][q] lives in register L_REG of tile L_DT on the hi == L_HI lane of this query row
-    const float l_tot = __shfl(o[L_DT][L_REG], l31 + 32 * L_HI, 64);
-    const float inv = 1.0f / l_tot;
+    float inv = 1.0f / __shfl(o[L_DT][L_REG], l31 + 32 * L_HI, 64);
+    u32x2 res[DT][4];  // self-attention result, bf16 (flash-attn output dtype, model.py:392-405)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            res[dt][q4][0] = pack2bf(o[dt][4 * q4] * inv, o[dt][4 * q4 + 1] * inv);
+            res[dt][q4][1] = pack2bf(o[dt][4 * q4 + 2] * inv, o[dt][4 * q4 + 3] * inv);
+        }
+
+    if (p.tk) {
+        // ---- fused zero-init gated text cross-attention (model.py:420-434): same Q rows (post-RoPE, :427), text K / V^T
+        //      staged into the now idle ring slots, plain tile loop (2-4 tiles), same max-folding softmax ----------------
+        const int bhk_t = bhk;  // text K / V share the kv-head layout
+        make_src(1, p.tk + (size_t)bhk_t * p.Tk * HD, p.Tk, p.tvt + (size_t)bhk_t * HD * p.Tkpad, p.Tkpad);
+        const float* tb = p.tbias + (size_t)b * p.Tkpad;
+        const int ntt = (p.Tk + 63) / 64;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        m_run = 0.f;
+        if (hi) {
+            qf[KS - 1][0] = (__bf16)0.0f;
+            qf[KS - 1][1] = (__bf16)0.0f;
+        }
+        for (int g0 = 0; g0 < ntt; g0 += 4) {  // up to four tiles per pass through the ring
+            const int g1 = min(ntt, g0 + 4);
+            bar();  // every wave is done with the ring slots (self-attention, or the previous pass)
+            for (int tt = g0; tt < g1; ++tt) {
+                dma_a_from(1, tt);
+                dma_b_from(1, tt, tt);
+                dma_c_from(1, tt);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+            for (int tt = g0; tt < g1; ++tt) {
+                phase_x(tt, F_{}, T_{}, F_{});                 // S = K_txt(tt) Q^T (log2 domain, minus the folded max)
+                phase_y_gen(tt, false, p.Tk, tb);               // + mask, exp2, bf16 (first tile sets the max)
+                pre_reads(tt + 1);
+                phase_x(tt + 1, T_{}, F_{}, F_{});             // O_txt += V_txt(tt)^T P   (V slot (tt + 4) & 3 = tt & 3)
+            }
+        }
+        inv = 1.0f / __shfl(o[L_DT][L_REG], l31 + 32 * L_HI, 64);
+        const float gate = bfr(tanhf(bf2f(p.tgate[h])));
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                // output + bf16(output_y * tanh(gate))  (model.py:433-434, bf16 rounding points)
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = bfr(bfr(o[dt][4 * q4 + j] * inv) * gate);
+                res[dt][q4][0] = pack2bf(bf_lo(res[dt][q4][0]) + v[0], bf_hi(res[dt][q4][0]) + v[1]);
+                res[dt][q4][1] = pack2bf(bf_lo(res[dt][q4][1]) + v[2], bf_hi(res[dt][q4][1]) + v[3]);
+            }
+    }
+
     if (q_ok) {
         u16* orow = p.out + ((size_t)b * p.N + qrow) * ((size_t)p.H * HD) + (size_t)h * HD;
 #pragma unroll
@@ -798,19 +879,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int d0 = 32 * dt + 8 * q4 + 4 * hi;
-                if (d0 < HD) {
-                    u32x2 w = {pack2bf(o[dt][4 * q4] * inv, o[dt][4 * q4 + 1] * inv),
-                               pack2bf(o[dt][4 * q4 + 2] * inv, o[dt][4 * q4 + 3] * inv)};
-                    *(u32x2*)(orow + d0) = w;
-                }
+                if (d0 < HD) *(u32x2*)(orow + d0) = res[dt][q4];
             }
     }
 }
 
-}  // namespace
+template __global__ void attn_fwd_kernel_v3<72, false>(AttnArgs);
+template __global__ void attn_fwd_kernel_v3<72, true>(AttnArgs);
+
+}  // namespace lt_attn
+
+using lt_attn::attn_fwd_kernel_v3;
 
 static int g_attn_variant = 3;  // 3: ping-pong kernel where it applies (hd 72 self-attention), v2 elsewhere
 void lt_set_attention_variant(int v) { g_attn_variant = v; }
+
+// true when launch_attention() can take the text keys along with the image keys (one kernel instead of two)
+bool attention_fuses_text(int hd) { return g_attn_variant == 3 && hd == 72; }
 
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.H % a.Hkv == 0, "attention: H=%d not a multiple of Hkv=%d", a.H, a.Hkv);
@@ -821,6 +906,10 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     dim3 grid(a.B * a.H * nqb), block(256);
 #define LAUNCH_V1(HD_) hipLaunchKernelGGL(attn_fwd_kernel<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128), stream, a)
 #define LAUNCH_V2(HD_) hipLaunchKernelGGL(attn_fwd_kernel_v2<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128 + 128), stream, a)
+    if (a.tk) {
+        LT_REQUIRE(a.k_prescaled && a.tvt && a.tbias && a.tgate && a.Tk > 0 && a.Tkpad % 64 == 0 && a.Tkpad >= a.Tk,
+                   "attention: incomplete fused text arguments");
+    }
     if (g_attn_variant == 3 && a.hd == 72 && a.bias == nullptr && !a.accumulate) {
         constexpr int SMEM3 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16;
         static bool attr_done = false;
@@ -842,6 +931,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
         return 0;
     }
     LT_REQUIRE(a.trace == nullptr, "attention trace: only the hd 72 self-attention kernel (variant 3) is instrumented");
+    LT_REQUIRE(a.tk == nullptr, "attention: fused text cross-attention needs the hd 72 ping-pong kernel (use attention_fuses_text())");
     const bool v2 = g_attn_variant >= 2;  // (variant 3 falls back to v2 for text attention and other head dims)
     switch (a.hd) {
         case 48: if (v2) LAUNCH_V2(48); else LAUNCH_V1(48); break;

@@ -174,7 +174,7 @@ int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int
 }
 
 int attention(lt_engine* e, const AttnArgs& a, hipStream_t s) {
-    ProfScope ps(e, 1, 4.0 * a.B * a.H * (double)a.N * a.Nk * a.hd, s);
+    ProfScope ps(e, 1, 4.0 * a.B * a.H * (double)a.N * (a.Nk + (a.tk ? a.Tk : 0)) * a.hd, s);
     return launch_attention(a, s);
 }
 
@@ -400,6 +400,9 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         if (launch_linear_small_m(e->t1, e->t2_w, e->t2_b, e->temb, B, A, A, 1, s)) return 1;
         if (launch_add_bf16(e->temb, e->cap_emb, e->adaln_in, (long long)B * A, s)) return 1;
         if (launch_linear_small_m(e->adaln_in, e->adaln_w, e->adaln_b, e->mod, B, e->ld_mod, A, 1, s)) return 1;
+        // tanh of the gate chunks once per (sample, channel) instead of once per token inside the residual kernels
+        if (v.gate_tanh && launch_tanh_gates(e->mod, B, e->ld_mod, L, e->chunks, e->d, v.i_gate[0], v.i_gate[1],
+                                             c.variant == LT_VARIANT_NEXT_MOE ? 5 : -1, s)) return 1;
     }
     auto chunk = [&](int layer, int idx) -> const u16* { return idx < 0 ? nullptr : e->mod + (size_t)layer * cd + (size_t)idx * d; };
     // first pre-norm: modulate(attention_norm(x), [shift,] scale) (model.py:599 / models.py:785 / lumina_t2i model.py:600)
@@ -410,7 +413,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         n.out = e->h; n.rows = M; n.rows_per_batch = N; n.d = d; n.ld_mod = e->ld_mod; n.eps = c.norm_eps;
         if (launch_rmsnorm_mod(n, s)) return 1;
     }
-    const int post_mode = v.post ? 1 : 0, gate_mode = v.gate_tanh ? 1 : 0;
+    const int post_mode = v.post ? 1 : 0, gate_mode = 0;  // gates arrive ready (tanh applied above where the family has it)
     for (int l = 0; l < L; ++l) {
         LayerW& w = e->lw[l];
         if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, nullptr, 0, s)) return 1;
@@ -433,8 +436,12 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         at.q = e->q; at.k = e->k; at.vt = e->vt; at.bias = nullptr; at.out = e->attn; at.gate = nullptr; at.accumulate = 0;
         at.B = B; at.H = H; at.Hkv = Hkv; at.N = N; at.Nk = N; at.Nkpad = Npad; at.hd = hd; at.scale = sm_scale;
         at.k_prescaled = 1;
+        const bool fuse_text = v.text && attention_fuses_text(hd);
+        if (fuse_text) {  // zero-init gated text cross-attention (model.py:420-434) inside the same launch
+            at.tk = w.ky; at.tvt = w.vty; at.tbias = e->txt_bias; at.tgate = w.gate; at.Tk = e->prompt_T; at.Tkpad = e->prompt_Tpad;
+        }
         if (attention(e, at, s)) return 1;
-        if (v.text) {  // zero-init gated text cross-attention (model.py:420-434)
+        if (v.text && !fuse_text) {
             at.k = w.ky; at.vt = w.vty; at.bias = e->txt_bias; at.gate = w.gate; at.accumulate = 1;
             at.Nk = e->prompt_T; at.Nkpad = e->prompt_Tpad; at.scale = (float)(1.0 / std::sqrt((double)hd));
             if (attention(e, at, s)) return 1;
@@ -461,7 +468,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             {
                 ProfScope ps(e, 2, 0, s);
                 GatedResArgs g;
-                g.x = e->x; g.y = e->o; g.post_w = w.norm_time; g.gate = chunk(l, 3); g.post_mode = 1; g.gate_mode = 1;
+                g.x = e->x; g.y = e->o; g.post_w = w.norm_time; g.gate = chunk(l, 3); g.post_mode = 1; g.gate_mode = 0;
                 g.next_w = nullptr; g.next_scale = chunk(l, 4); g.next_shift = nullptr; g.next_mode = 1; g.h = e->h;
                 g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
                 if (launch_gated_residual_norm(g, s)) return 1;
@@ -929,6 +936,18 @@ extern "C" int lt_op_attention(const void* q, const void* k, const void* vt, con
     a.q = (const u16*)q; a.k = (const u16*)k; a.vt = (const u16*)vt; a.bias = bias; a.out = (u16*)out;
     a.gate = (const u16*)gate; a.accumulate = accumulate; a.B = B; a.H = H; a.Hkv = Hkv; a.N = N; a.Nk = Nk;
     a.Nkpad = Nkpad; a.hd = hd; a.scale = scale; a.k_prescaled = k_prescaled;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_attention_fused(const void* q, const void* k, const void* vt, const void* tk, const void* tvt,
+                                     const float* tbias, const void* tgate, void* out, int32_t B, int32_t H, int32_t Hkv, int32_t N,
+                                     int32_t Nk, int32_t Nkpad, int32_t Tk, int32_t Tkpad, int32_t hd, void* stream) {
+    LT_REQUIRE(q && k && vt && tk && tvt && tbias && tgate && out, "lt_op_attention_fused: null pointer");
+    LT_REQUIRE(attention_fuses_text(hd), "lt_op_attention_fused: needs head_dim 72 and attention_variant 3");
+    AttnArgs a;
+    a.q = (const u16*)q; a.k = (const u16*)k; a.vt = (const u16*)vt; a.bias = nullptr; a.out = (u16*)out; a.gate = nullptr;
+    a.accumulate = 0; a.B = B; a.H = H; a.Hkv = Hkv; a.N = N; a.Nk = Nk; a.Nkpad = Nkpad; a.hd = hd; a.scale = 1.f; a.k_prescaled = 1;
+    a.tk = (const u16*)tk; a.tvt = (const u16*)tvt; a.tbias = tbias; a.tgate = (const u16*)tgate; a.Tk = Tk; a.Tkpad = Tkpad;
     return launch_attention(a, (hipStream_t)stream);
 }
 

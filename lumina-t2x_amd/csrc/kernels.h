@@ -77,9 +77,18 @@ struct AttnArgs {
     int B, H, Hkv, N, Nk, Nkpad, hd;
     float scale;
     int k_prescaled = 0;  // 1: K already carries scale * log2(e) (qk_norm_rope out_scale): scores are in the log2 domain
+    // fused gated text cross-attention (model.py:420-434), hd-72 ping-pong kernel only: after the self-attention loop the
+    // same workgroup attends its (still resident) Q rows to the text keys and writes
+    //   out = bf16(self) + bf16(bf16(text) * tanh(gate[h])).  Requires k_prescaled (both K carry their scale * log2 e).
+    const u16* tk = nullptr;      // [B, Hkv, Tk, hd]
+    const u16* tvt = nullptr;     // [B, Hkv, hd, Tkpad]
+    const float* tbias = nullptr; // [B, Tkpad] 0 / -inf (padded with -inf)
+    const u16* tgate = nullptr;   // [H] bf16
+    int Tk = 0, Tkpad = 0;
     unsigned long long* trace = nullptr;  // diagnostics only (lt_op_attention_trace)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
+bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
 void lt_set_gemm_pipeline(int v);      // 0 = classic double-buffered loop, 1 = ping-pong wave groups
@@ -122,6 +131,8 @@ int launch_timestep_features(const float* t, int t_index, u16* out, int B, int d
 // masked mean pool + affine LayerNorm (model.py:847-849, cap_embedder.0): -> [B, C] bf16
 int launch_cap_pool_ln(const void* cap, int cap_dtype, const int32_t* mask, const u16* ln_w, const u16* ln_b,
                        u16* out, int B, int T, int C, hipStream_t stream);
+// in place: gate chunks g0, g1, g2 (-1 = none) of every layer's adaLN vector -> bf16(tanh(.)); mod [B, ld_mod]
+int launch_tanh_gates(u16* mod, int B, int ld_mod, int L, int chunks, int d, int g0, int g1, int g2, hipStream_t stream);
 // c = bfr(a + b) elementwise bf16
 int launch_add_bf16(const u16* a, const u16* b, u16* c, long long n, hipStream_t stream);
 // cap_feats (any dtype) -> bf16 copy, and mask -> additive float bias (0 / -inf), padded to Tpad

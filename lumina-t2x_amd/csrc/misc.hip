@@ -160,6 +160,23 @@ __global__ __launch_bounds__(256) void cap_pool_ln_kernel(const void* __restrict
         out[(size_t)b * C + c] = f2bf((pooled[c] - mean) * rstd * bf2f(ln_w[c]) + bf2f(ln_b[c]));
 }
 
+// gate chunks of the adaLN vectors -> bf16(tanh(gate)) in place, once per NFE: `gate_msa.unsqueeze(1).tanh()` is a bf16
+// tensor op in the reference (model.py:597, :606), i.e. per (sample, channel) - not per token.  (Computing tanhf per
+// token inside the residual kernel made that HBM-bound kernel VALU-bound: 2304 tanhf x 8192 rows per launch.)
+__global__ void tanh_gates_kernel(u16* __restrict__ mod, int B, int ld_mod, int L, int chunks, int d, int g0, int g1, int g2) {
+    const long long total = (long long)B * L * 3 * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d);
+        const int which = (int)((i / d) % 3);
+        const int l = (int)((i / (3LL * d)) % L);
+        const int b = (int)(i / (3LL * d * L));
+        const int g = which == 0 ? g0 : (which == 1 ? g1 : g2);
+        if (g < 0) continue;
+        u16* p = mod + (size_t)b * ld_mod + ((size_t)l * chunks + g) * d + c;
+        *p = f2bf(tanhf(bf2f(*p)));
+    }
+}
+
 __global__ void add_bf16_kernel(const u16* a, const u16* b, u16* c, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) c[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
@@ -300,6 +317,15 @@ int launch_cap_pool_ln(const void* cap, int cap_dtype, const int32_t* mask, cons
                        int B, int T, int C, hipStream_t stream) {
     hipLaunchKernelGGL(cap_pool_ln_kernel, dim3(B), dim3(256), (C + 8) * sizeof(float), stream, cap, cap_dtype, mask,
                        ln_w, ln_b, out, T, C);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_tanh_gates(u16* mod, int B, int ld_mod, int L, int chunks, int d, int g0, int g1, int g2, hipStream_t stream) {
+    const long long total = (long long)B * L * 3 * d;
+    int g = nblk(total, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(tanh_gates_kernel, dim3(g), dim3(256), 0, stream, mod, B, ld_mod, L, chunks, d, g0, g1, g2);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

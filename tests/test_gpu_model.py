@@ -126,7 +126,17 @@ def test_engine_trajectory_vs_reference_golden(golden_dir, method):
     fn = Sampler(create_transport()).sample_ode(sampling_method=method, num_steps=5, time_shifting_factor=4)
     traj = fn(z, model.forward_with_cfg, cap_feats=cap, cap_mask=mask, cfg_scale=4.0, proportional_attn=True, base_seqlen=16)
     ref = torch.from_numpy(g[f"traj_{method}"])
-    assert rel_l2(traj[-1], ref[-1]) < 5e-2, rel_l2(traj[-1], ref[-1])  # A.6: 1.9e-2 after 4 Euler steps (600M)
+    # gate: 1.5 x the error of the reference's own bf16 choreography against its fp32 self at the same
+    # level, re-measured here on this weight draw with the bf16-emulating oracle (bf16 state, bf16 rounding points);
+    # A.6 measured 1.9e-2 after 4 Euler steps on the 600M model; guidance 4 and 8 NFE (midpoint) sit higher
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    zc, capc, maskc = z.cpu(), cap.float().cpu(), mask.cpu()
+    floor_traj = OD.sample_ode(lambda x, tv, **k: O.forward_with_cfg(sd, cfg, x, tv, bf16=True, **k).to(torch.bfloat16), zc, 5,
+                               method=method, time_shifting_factor=4, cap_feats=capc, cap_mask=maskc, cfg_scale=4.0,
+                               proportional_attn=True, base_seqlen=16)
+    floor = rel_l2(floor_traj[-1], ref[-1])
+    err = rel_l2(traj[-1], ref[-1])
+    assert err < max(5e-2, 1.5 * floor), (err, floor)
 
 
 def test_full_width_two_layers_vs_oracle():

@@ -306,6 +306,47 @@ def test_attention_text_accumulate(variant, T, valid1, fold):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
+@pytest.mark.parametrize("B,H,Hkv,N,T,valid1", [(2, 8, 8, 320, 128, 8), (2, 8, 2, 200, 77, 30), (1, 4, 4, 4096, 256, 256),
+                                                  (2, 4, 4, 96, 300, 130)])
+def test_attention_fused_text(B, H, Hkv, N, T, valid1):
+    """one launch = self-attention + gated text cross-attention (model.py:392-434), both K pre-scaled (engine path)"""
+    set_option("attention_variant", 3)
+    hd = 72
+    g = torch.Generator().manual_seed(N + T)
+    q = bf(torch.randn(B, H, N, hd, generator=g))
+    k = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    v = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    tk = bf(torch.randn(B, Hkv, T, hd, generator=g))
+    tv = bf(torch.randn(B, Hkv, T, hd, generator=g))
+    gate = bf(torch.randn(H, generator=g))
+    mask = torch.ones(B, T)
+    mask[B - 1, valid1:] = 0
+    bias = torch.where(mask > 0, 0.0, float("-inf"))
+    s_self = math.sqrt(math.log(N, 64) / hd) if N > 64 else 1 / math.sqrt(hd)
+    s_txt = 1 / math.sqrt(hd)
+    L2E = 1.4426950408889634
+    kf = (k.float() * (s_self * L2E)).to(torch.bfloat16)
+    tkf = (tk.float() * (s_txt * L2E)).to(torch.bfloat16)
+    Npad, Tpad = (N + 63) // 64 * 64, (T + 63) // 64 * 64
+    vt = torch.empty(B, Hkv, hd, Npad, device="cuda", dtype=torch.bfloat16)
+    tvt = torch.empty(B, Hkv, hd, Tpad, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_v_transpose(P(v.permute(0, 2, 1, 3).reshape(B * N, Hkv * hd).contiguous()), Hkv * hd, 0, P(vt), B, N, Npad, Hkv, hd, stream()))
+    ok(lib().lt_op_v_transpose(P(tv.permute(0, 2, 1, 3).reshape(B * T, Hkv * hd).contiguous()), Hkv * hd, 0, P(tvt), B, T, Tpad, Hkv, hd, stream()))
+    bias_dev = torch.full((B, Tpad), float("-inf"), device="cuda", dtype=torch.float32)
+    bias_dev[:, :T] = bias.cuda()
+    out = torch.full((B, N, H * hd), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_attention_fused(P(q), P(kf), P(vt), P(tkf), P(tvt), P(bias_dev), P(gate), P(out), B, H, Hkv, N, N, Npad, T, Tpad,
+                                   hd, stream()), "attention_fused")
+    torch.cuda.synchronize()
+    got = out.view(B, N, H, hd).permute(0, 2, 1, 3)
+    o_self = r16(_attn_ref(q.cpu(), k.cpu(), v.cpu(), s_self))
+    o_txt = r16(_attn_ref(q.cpu(), tk.cpu(), tv.cpu(), s_txt, bias))
+    gt = r16(torch.tanh(gate.float().cpu())).view(1, H, 1, 1)
+    ref = r16(o_self + r16(o_txt * gt))
+    assert not torch.isnan(got.float()).any()
+    assert rel_l2(got, ref) < 6e-3, rel_l2(got, ref)
+
+
 @pytest.mark.parametrize("M,N,K,act", [(2, 1000, 256, 0), (2, 9216, 1024, 1), (1, 37, 128, 1), (8, 64, 2048, 0)])
 def test_linear_small_m(M, N, K, act):
     g = torch.Generator().manual_seed(N)
