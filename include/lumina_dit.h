@@ -153,10 +153,11 @@ int lt_op_gemm_trace(const void* A_dev, const void* W_dev, void* C_dev, int32_t 
 int lt_op_pack_w13(const void* w1_dev, const void* w3_dev, void* out_dev, int32_t F, int32_t K,
                    void* stream);
 /* out = RMSNorm(x; w, eps) * (1 + scale[b]) (+ shift[b]);  w/scale/shift may be NULL.
- * x,out bf16 [B*N, d]; scale/shift bf16 [B, ld_mod] (row stride ld_mod elements). */
+ * x,out bf16 [B*N, d]; scale/shift bf16 [B, ld_mod] (row stride ld_mod elements).
+ * scale_pre != 0: `scale` already holds bf16(1 + scale) (lt_op_prep_mod), as the engine prepares it once per NFE. */
 int lt_op_rmsnorm_mod(const void* x_dev, const void* w_dev, const void* scale_dev,
                       const void* shift_dev, int32_t ld_mod, void* out_dev, int32_t B, int32_t N,
-                      int32_t d, float eps, void* stream);
+                      int32_t d, float eps, int32_t scale_pre, void* stream);
 /* x += gate' * post(y) ; h = pre_next(x) * (1+scale) (+shift)      (model.py:597-610)
  * post_mode 0: y, 1: RMSNorm(y; post_w).  gate_mode 0: gate, 1: tanh(gate), 2: no gate.
  * next_mode 0: none, 1: RMSNorm(x; next_w)(w may be NULL), 2: LayerNorm no-affine (eps_next). */
@@ -165,7 +166,12 @@ int lt_op_gated_residual_norm(void* x_dev, const void* y_dev, const void* post_w
                               const void* next_w_dev, const void* next_scale_dev,
                               const void* next_shift_dev, int32_t next_mode, int32_t ld_mod,
                               void* h_dev, int32_t B, int32_t N, int32_t d, float eps,
-                              float eps_next, void* stream);
+                              float eps_next, int32_t scale_pre, void* stream);
+/* adaLN vectors, in place (mod bf16 [B, ld_mod] = L layers x `chunks` chunks of d, then the final layer's chunks): chunk c of
+ * every layer -> bf16(tanh(.)) if bit c of tanh_mask, bf16(1 + .) if bit c of scale_mask; final_scale_chunk >= 0: that chunk
+ * of the final layer -> bf16(1 + .).  The row kernels then run with gate_mode 0 and scale_pre 1. */
+int lt_op_prep_mod(void* mod_dev, int32_t B, int32_t ld_mod, int32_t L, int32_t chunks, int32_t d,
+                   uint32_t tanh_mask, uint32_t scale_mask, int32_t final_scale_chunk, void* stream);
 /* q/k post-processing (model.py:361-371): affine LayerNorm over the full width (optional), 2-D or
  * 1-D RoPE, cast bf16, write head-major [B,heads,N,hd].  src bf16 [B*N, ld_src] at column col0.
  * rope_mode 0 none, 1 2-D interleaved (Next-DiT, model.py:959-961), 2 1-D (Flag-DiT).

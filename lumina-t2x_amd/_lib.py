@@ -76,8 +76,9 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_op_gemm_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_trace": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "lt_op_pack_w13": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
-    "lt_op_rmsnorm_mod": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp]),
-    "lt_op_gated_residual_norm": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _vp]),
+    "lt_op_rmsnorm_mod": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lt_op_gated_residual_norm": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
+    "lt_op_prep_mod": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, C.c_uint32, C.c_uint32, _i32, _vp]),
     "lt_op_qk_norm_rope": (_i32, [_vp, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _vp]),
     "lt_op_v_transpose": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),

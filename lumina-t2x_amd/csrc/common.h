@@ -51,6 +51,14 @@ __device__ __forceinline__ bf8_t pack8(const float* f) {
     return v;
 }
 
+// ---- pairwise (packed) helpers: the row kernels are VALU-heavy (a bf16 rounding after every reference op), so they
+// work on two elements per instruction: v_pk_mul/add/fma_f32 and one v_cvt_pk_bf16_f32 per rounded pair ------------------
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ unsigned pk_bf(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 unpk_bf(unsigned u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2 bfr2(f32x2 v) { return unpk_bf(pk_bf(v)); }  // round both to bf16, keep as fp32
+
 // host-side error plumbing shared by the launchers
 void lt_set_error(const char* fmt, ...);
 #define LT_CHECK_HIP(expr)                                                              \

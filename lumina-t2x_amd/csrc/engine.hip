@@ -400,9 +400,15 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         if (launch_linear_small_m(e->t1, e->t2_w, e->t2_b, e->temb, B, A, A, 1, s)) return 1;
         if (launch_add_bf16(e->temb, e->cap_emb, e->adaln_in, (long long)B * A, s)) return 1;
         if (launch_linear_small_m(e->adaln_in, e->adaln_w, e->adaln_b, e->mod, B, e->ld_mod, A, 1, s)) return 1;
-        // tanh of the gate chunks once per (sample, channel) instead of once per token inside the residual kernels
-        if (v.gate_tanh && launch_tanh_gates(e->mod, B, e->ld_mod, L, e->chunks, e->d, v.i_gate[0], v.i_gate[1],
-                                             c.variant == LT_VARIANT_NEXT_MOE ? 5 : -1, s)) return 1;
+        // once per (sample, channel) instead of once per token inside the row kernels: tanh of the gate chunks (where the
+        // family has it) and bf16(1 + scale) of every scale chunk
+        unsigned tanh_mask = 0, scale_mask = 0;
+        for (int i = 0; i < 2; ++i) {
+            if (v.gate_tanh && v.i_gate[i] >= 0) tanh_mask |= 1u << v.i_gate[i];
+            if (v.i_scale[i] >= 0) scale_mask |= 1u << v.i_scale[i];
+        }
+        if (c.variant == LT_VARIANT_NEXT_MOE) { tanh_mask |= 1u << 5; scale_mask |= 1u << 4; }
+        if (launch_prep_mod(e->mod, B, e->ld_mod, L, e->chunks, e->d, tanh_mask, scale_mask, v.final_chunks == 2 ? 1 : 0, s)) return 1;
     }
     auto chunk = [&](int layer, int idx) -> const u16* { return idx < 0 ? nullptr : e->mod + (size_t)layer * cd + (size_t)idx * d; };
     // first pre-norm: modulate(attention_norm(x), [shift,] scale) (model.py:599 / models.py:785 / lumina_t2i model.py:600)
@@ -410,7 +416,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         ProfScope ps(e, 2, 0, s);
         NormModArgs n;
         n.x = e->x; n.w = v.pre_w ? e->lw[0].attn_norm1 : nullptr; n.scale = chunk(0, v.i_scale[0]); n.shift = chunk(0, v.i_shift[0]);
-        n.out = e->h; n.rows = M; n.rows_per_batch = N; n.d = d; n.ld_mod = e->ld_mod; n.eps = c.norm_eps;
+        n.out = e->h; n.rows = M; n.rows_per_batch = N; n.d = d; n.ld_mod = e->ld_mod; n.eps = c.norm_eps; n.scale_pre = 1;
         if (launch_rmsnorm_mod(n, s)) return 1;
     }
     const int post_mode = v.post ? 1 : 0, gate_mode = 0;  // gates arrive ready (tanh applied above where the family has it)
@@ -454,7 +460,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             g.post_mode = post_mode; g.gate_mode = gate_mode;
             g.next_w = v.pre_w ? w.ffn_norm1 : nullptr; g.next_scale = chunk(l, v.i_scale[1]); g.next_shift = chunk(l, v.i_shift[1]);
             g.next_mode = 1; g.h = e->h;
-            g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
+            g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
             if (launch_gated_residual_norm(g, s)) return 1;
         }
         const u16 *last_post_w, *last_gate;
@@ -470,7 +476,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 GatedResArgs g;
                 g.x = e->x; g.y = e->o; g.post_w = w.norm_time; g.gate = chunk(l, 3); g.post_mode = 1; g.gate_mode = 0;
                 g.next_w = nullptr; g.next_scale = chunk(l, 4); g.next_shift = nullptr; g.next_mode = 1; g.h = e->h;
-                g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
+                g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
                 if (launch_gated_residual_norm(g, s)) return 1;
             }
             if (moe_ffn(e, w, 1, M, N, B, s)) return 1;
@@ -482,7 +488,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             GatedResArgs g;
             g.x = e->x; g.y = e->o; g.post_w = last_post_w; g.gate = last_gate;
             g.post_mode = post_mode; g.gate_mode = gate_mode; g.h = e->h;
-            g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f;
+            g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
             if (l + 1 < L) {
                 g.next_w = v.pre_w ? e->lw[l + 1].attn_norm1 : nullptr; g.next_scale = chunk(l + 1, v.i_scale[0]);
                 g.next_shift = chunk(l + 1, v.i_shift[0]); g.next_mode = 1;
@@ -888,25 +894,31 @@ extern "C" int lt_op_pack_w13(const void* w1, const void* w3, void* out, int32_t
 }
 
 extern "C" int lt_op_rmsnorm_mod(const void* x, const void* w, const void* scale, const void* shift, int32_t ld_mod,
-                                 void* out, int32_t B, int32_t N, int32_t d, float eps, void* stream) {
+                                 void* out, int32_t B, int32_t N, int32_t d, float eps, int32_t scale_pre, void* stream) {
     LT_REQUIRE(x && out, "lt_op_rmsnorm_mod: null pointer");
     NormModArgs n;
     n.x = (const u16*)x; n.w = (const u16*)w; n.scale = (const u16*)scale; n.shift = (const u16*)shift; n.out = (u16*)out;
-    n.rows = B * N; n.rows_per_batch = N; n.d = d; n.ld_mod = ld_mod; n.eps = eps;
+    n.rows = B * N; n.rows_per_batch = N; n.d = d; n.ld_mod = ld_mod; n.eps = eps; n.scale_pre = scale_pre;
     return launch_rmsnorm_mod(n, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_gated_residual_norm(void* x, const void* y, const void* post_w, const void* gate, int32_t post_mode,
                                          int32_t gate_mode, const void* next_w, const void* next_scale,
                                          const void* next_shift, int32_t next_mode, int32_t ld_mod, void* h, int32_t B,
-                                         int32_t N, int32_t d, float eps, float eps_next, void* stream) {
+                                         int32_t N, int32_t d, float eps, float eps_next, int32_t scale_pre, void* stream) {
     LT_REQUIRE(x && y, "lt_op_gated_residual_norm: null pointer");
     GatedResArgs g;
     g.x = (u16*)x; g.y = (const u16*)y; g.post_w = (const u16*)post_w; g.gate = (const u16*)gate;
     g.next_w = (const u16*)next_w; g.next_scale = (const u16*)next_scale; g.next_shift = (const u16*)next_shift;
     g.h = (u16*)h; g.rows = B * N; g.rows_per_batch = N; g.d = d; g.ld_mod = ld_mod; g.post_mode = post_mode;
-    g.gate_mode = gate_mode; g.next_mode = next_mode; g.eps = eps; g.eps_next = eps_next;
+    g.gate_mode = gate_mode; g.next_mode = next_mode; g.eps = eps; g.eps_next = eps_next; g.scale_pre = scale_pre;
     return launch_gated_residual_norm(g, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_prep_mod(void* mod, int32_t B, int32_t ld_mod, int32_t L, int32_t chunks, int32_t d, uint32_t tanh_mask,
+                              uint32_t scale_mask, int32_t final_scale_chunk, void* stream) {
+    LT_REQUIRE(mod, "lt_op_prep_mod: null pointer");
+    return launch_prep_mod((u16*)mod, B, ld_mod, L, chunks, d, tanh_mask, scale_mask, final_scale_chunk, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_qk_norm_rope(const void* src, int32_t ld_src, int32_t col0, const void* ln_w, const void* ln_b,

@@ -30,6 +30,7 @@ struct NormModArgs {
     u16* out;          // [rows, d]
     int rows, rows_per_batch, d, ld_mod;
     float eps;
+    int scale_pre = 0;  // 1: `scale` already holds bf16(1 + scale) (engine: prepared once per NFE by launch_prep_mod)
 };
 int launch_rmsnorm_mod(const NormModArgs& a, hipStream_t stream);
 
@@ -45,6 +46,7 @@ struct GatedResArgs {
     int rows, rows_per_batch, d, ld_mod;
     int post_mode, gate_mode, next_mode;
     float eps, eps_next;
+    int scale_pre = 0;  // 1: next_scale already holds bf16(1 + scale)
 };
 int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream);
 
@@ -131,8 +133,11 @@ int launch_timestep_features(const float* t, int t_index, u16* out, int B, int d
 // masked mean pool + affine LayerNorm (model.py:847-849, cap_embedder.0): -> [B, C] bf16
 int launch_cap_pool_ln(const void* cap, int cap_dtype, const int32_t* mask, const u16* ln_w, const u16* ln_b,
                        u16* out, int B, int T, int C, hipStream_t stream);
-// in place: gate chunks g0, g1, g2 (-1 = none) of every layer's adaLN vector -> bf16(tanh(.)); mod [B, ld_mod]
-int launch_tanh_gates(u16* mod, int B, int ld_mod, int L, int chunks, int d, int g0, int g1, int g2, hipStream_t stream);
+// in place, once per NFE, on every layer's adaLN vector (mod [B, ld_mod], `chunks` chunks of d per layer + final_chunks for
+// the final layer): chunks whose bit is set in tanh_mask -> bf16(tanh(.)) (gates), in scale_mask -> bf16(1 + .) (scales);
+// final_scale_chunk >= 0: that chunk of the final layer's vector -> bf16(1 + .).  Per (sample, channel) instead of per token.
+int launch_prep_mod(u16* mod, int B, int ld_mod, int L, int chunks, int d, unsigned tanh_mask, unsigned scale_mask,
+                    int final_scale_chunk, hipStream_t stream);
 // c = bfr(a + b) elementwise bf16
 int launch_add_bf16(const u16* a, const u16* b, u16* c, long long n, hipStream_t stream);
 // cap_feats (any dtype) -> bf16 copy, and mask -> additive float bias (0 / -inf), padded to Tpad

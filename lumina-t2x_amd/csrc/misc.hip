@@ -160,20 +160,28 @@ __global__ __launch_bounds__(256) void cap_pool_ln_kernel(const void* __restrict
         out[(size_t)b * C + c] = f2bf((pooled[c] - mean) * rstd * bf2f(ln_w[c]) + bf2f(ln_b[c]));
 }
 
-// gate chunks of the adaLN vectors -> bf16(tanh(gate)) in place, once per NFE: `gate_msa.unsqueeze(1).tanh()` is a bf16
-// tensor op in the reference (model.py:597, :606), i.e. per (sample, channel) - not per token.  (Computing tanhf per
-// token inside the residual kernel made that HBM-bound kernel VALU-bound: 2304 tanhf x 8192 rows per launch.)
-__global__ void tanh_gates_kernel(u16* __restrict__ mod, int B, int ld_mod, int L, int chunks, int d, int g0, int g1, int g2) {
-    const long long total = (long long)B * L * 3 * d;
+// adaLN vectors, in place, once per NFE: gate chunks -> bf16(tanh(gate)) (`gate_msa.unsqueeze(1).tanh()` is a bf16 tensor
+// op per (sample, channel) in the reference, model.py:597, :606) and scale chunks -> bf16(1 + scale) (modulate, :28-29).
+// Doing either per token inside the row kernels made those HBM-bound kernels VALU-bound.
+__global__ void prep_mod_kernel(u16* __restrict__ mod, int B, int ld_mod, int L, int chunks, int d, unsigned tanh_mask,
+                                unsigned scale_mask, int final_scale_chunk) {
+    const long long per_b = (long long)L * chunks * d + (final_scale_chunk >= 0 ? d : 0);
+    const long long total = (long long)B * per_b;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % d);
-        const int which = (int)((i / d) % 3);
-        const int l = (int)((i / (3LL * d)) % L);
-        const int b = (int)(i / (3LL * d * L));
-        const int g = which == 0 ? g0 : (which == 1 ? g1 : g2);
-        if (g < 0) continue;
-        u16* p = mod + (size_t)b * ld_mod + ((size_t)l * chunks + g) * d + c;
-        *p = f2bf(tanhf(bf2f(*p)));
+        const int b = (int)(i / per_b);
+        const long long r = i % per_b;
+        u16* p;
+        int mode;  // 1 tanh, 2 one-plus
+        if (r < (long long)L * chunks * d) {
+            const int ch = (int)((r / d) % chunks);
+            mode = ((tanh_mask >> ch) & 1u) ? 1 : (((scale_mask >> ch) & 1u) ? 2 : 0);
+            p = mod + (size_t)b * ld_mod + r;
+        } else {
+            mode = 2;
+            p = mod + (size_t)b * ld_mod + (size_t)L * chunks * d + (size_t)final_scale_chunk * d + (r - (long long)L * chunks * d);
+        }
+        if (mode == 1) *p = f2bf(tanhf(bf2f(*p)));
+        else if (mode == 2) *p = f2bf(1.0f + bf2f(*p));
     }
 }
 
@@ -321,11 +329,13 @@ int launch_cap_pool_ln(const void* cap, int cap_dtype, const int32_t* mask, cons
     return 0;
 }
 
-int launch_tanh_gates(u16* mod, int B, int ld_mod, int L, int chunks, int d, int g0, int g1, int g2, hipStream_t stream) {
-    const long long total = (long long)B * L * 3 * d;
+int launch_prep_mod(u16* mod, int B, int ld_mod, int L, int chunks, int d, unsigned tanh_mask, unsigned scale_mask,
+                    int final_scale_chunk, hipStream_t stream) {
+    const long long total = (long long)B * ((long long)L * chunks * d + d);
     int g = nblk(total, 256);
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(tanh_gates_kernel, dim3(g), dim3(256), 0, stream, mod, B, ld_mod, L, chunks, d, g0, g1, g2);
+    hipLaunchKernelGGL(prep_mod_kernel, dim3(g), dim3(256), 0, stream, mod, B, ld_mod, L, chunks, d, tanh_mask, scale_mask,
+                       final_scale_chunk);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -13,103 +13,117 @@
 
 namespace {
 
-constexpr int MAXCH = 8;  // 16-byte chunks per lane -> d <= 64 * 8 * 8 = 4096
+constexpr int MAXCH_LIMIT = 8;  // 16-byte chunks per lane -> d <= 64 * 8 * 8 = 4096; kernels are compiled per chunk count
 
-struct RowRegs {
-    float v[MAXCH][8];
+// A row lives in registers as raw bf16 pairs (4 dwords per 16-byte chunk); all arithmetic is pairwise
+// (v_pk_*_f32 + one v_cvt_pk_bf16_f32 per rounded pair, common.h) - these kernels do a bf16 rounding after every
+// reference op and were VALU-bound with scalar math.
+template <int MAXCH>
+struct RowRaw {
+    bf8_t c[MAXCH];
 };
 
-__device__ __forceinline__ void load_row(const u16* row, int nch, int lane, RowRegs& r) {
+template <int MAXCH>
+__device__ __forceinline__ void load_row(const u16* row, int nch, int lane, RowRaw<MAXCH>& r) {
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-            const bf8_t t = *(const bf8_t*)(row + c * 8);
-            unpack8(t, r.v[i]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) r.v[i][e] = 0.f;
-        }
+        const int ch = lane + 64 * i;
+        if (ch < nch) r.c[i] = *(const bf8_t*)(row + ch * 8);
+        else r.c[i].w[0] = r.c[i].w[1] = r.c[i].w[2] = r.c[i].w[3] = 0u;
     }
 }
 
-__device__ __forceinline__ float row_sumsq(const RowRegs& r) {
-    float s = 0.f;
+template <int MAXCH>
+__device__ __forceinline__ float row_sumsq(const RowRaw<MAXCH>& r) {
+    f32x2 s = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += r.v[i][e] * r.v[i][e];
-    return wave_sum(s);
+        for (int k = 0; k < 4; ++k) {
+            const f32x2 v = unpk_bf(r.c[i].w[k]);
+            s = v * v + s;
+        }
+    return wave_sum(s[0] + s[1]);
 }
 
-// h = bfr(bfr(bfr(x * r) * w) * bfr(1 + scale)) (+ shift)   -- each step optional as in the reference
-__device__ __forceinline__ void apply_rms_mod_store(const RowRegs& r, float rinv, const u16* w, const u16* scale,
-                                                    const u16* shift, u16* out, int nch, int lane) {
+// h = bfr(bfr(bfr(x * r) * w) * bfr(1 + scale)) (+ shift)   -- each step optional as in the reference;
+// scale_pre: `scale` already holds bfr(1 + scale)
+template <int MAXCH>
+__device__ __forceinline__ void apply_rms_mod_store(const RowRaw<MAXCH>& r, float rinv, const u16* w, const u16* scale,
+                                                    const u16* shift, int scale_pre, u16* out, int nch, int lane) {
+    const f32x2 rv = {rinv, rinv};
+    const f32x2 one = {1.f, 1.f};
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-            float o[8], wf[8], sf[8], hf[8];
-            if (w) unpack8(*(const bf8_t*)(w + c * 8), wf);
-            if (scale) unpack8(*(const bf8_t*)(scale + c * 8), sf);
-            if (shift) unpack8(*(const bf8_t*)(shift + c * 8), hf);
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            bf8_t wv, sv, hv, o;
+            if (w) wv = *(const bf8_t*)(w + ch * 8);
+            if (scale) sv = *(const bf8_t*)(scale + ch * 8);
+            if (shift) hv = *(const bf8_t*)(shift + ch * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float n = bfr(r.v[i][e] * rinv);
-                if (w) n = bfr(n * wf[e]);
-                if (scale) n = bfr(n * bfr(1.0f + sf[e]));
-                if (shift) n = bfr(n + hf[e]);
-                o[e] = n;
+            for (int k = 0; k < 4; ++k) {
+                f32x2 n = unpk_bf(r.c[i].w[k]) * rv;
+                if (w) n = bfr2(n) * unpk_bf(wv.w[k]);
+                if (scale) n = bfr2(n) * (scale_pre ? unpk_bf(sv.w[k]) : bfr2(one + unpk_bf(sv.w[k])));
+                if (shift) n = bfr2(n) + unpk_bf(hv.w[k]);
+                o.w[k] = pk_bf(n);
             }
-            *(bf8_t*)(out + c * 8) = pack8(o);
+            *(bf8_t*)(out + ch * 8) = o;
         }
     }
 }
 
+template <int MAXCH>
 __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(NormModArgs p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const int b = row / p.rows_per_batch;
     const int nch = p.d >> 3;
-    RowRegs r;
+    RowRaw<MAXCH> r;
     load_row(p.x + (size_t)row * p.d, nch, lane, r);
     const float rinv = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
     apply_rms_mod_store(r, rinv, p.w, p.scale ? p.scale + (size_t)b * p.ld_mod : nullptr,
-                        p.shift ? p.shift + (size_t)b * p.ld_mod : nullptr, p.out + (size_t)row * p.d, nch, lane);
+                        p.shift ? p.shift + (size_t)b * p.ld_mod : nullptr, p.scale_pre, p.out + (size_t)row * p.d, nch, lane);
 }
 
+template <int MAXCH>
 __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const int b = row / p.rows_per_batch;
     const int nch = p.d >> 3;
-    RowRegs r;
+    u16* xrow = p.x + (size_t)row * p.d;
+    RowRaw<MAXCH> r, xr;
     load_row(p.y + (size_t)row * p.d, nch, lane, r);
+    load_row(xrow, nch, lane, xr);  // issued with y: one memory round trip for both streams
     float rinv = 1.f;
     if (p.post_mode == 1) rinv = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
     const u16* gate = p.gate ? p.gate + (size_t)b * p.ld_mod : nullptr;
-    u16* xrow = p.x + (size_t)row * p.d;
+    const f32x2 rv = {rinv, rinv};
     // x' = bfr(x + bfr(g * yn));  r <- x'
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-            float xf[8], wf[8], gf[8], o[8];
-            unpack8(*(const bf8_t*)(xrow + c * 8), xf);
-            if (p.post_mode == 1) unpack8(*(const bf8_t*)(p.post_w + c * 8), wf);
-            if (p.gate_mode != 2) unpack8(*(const bf8_t*)(gate + c * 8), gf);
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            bf8_t wv, gv;
+            if (p.post_mode == 1) wv = *(const bf8_t*)(p.post_w + ch * 8);
+            if (p.gate_mode != 2) gv = *(const bf8_t*)(gate + ch * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float yn = r.v[i][e];
-                if (p.post_mode == 1) yn = bfr(bfr(yn * rinv) * wf[e]);
-                if (p.gate_mode == 1) yn = bfr(bfr(tanhf(gf[e])) * yn);
-                else if (p.gate_mode == 0) yn = bfr(gf[e] * yn);
-                o[e] = bfr(xf[e] + yn);
-                r.v[i][e] = o[e];
+            for (int k = 0; k < 4; ++k) {
+                f32x2 yn = unpk_bf(r.c[i].w[k]);
+                if (p.post_mode == 1) yn = bfr2(bfr2(yn * rv) * unpk_bf(wv.w[k]));
+                if (p.gate_mode == 1) {
+                    const f32x2 g = unpk_bf(gv.w[k]);
+                    yn = bfr2(bfr2(f32x2{tanhf(g[0]), tanhf(g[1])}) * yn);
+                } else if (p.gate_mode == 0) {
+                    yn = bfr2(unpk_bf(gv.w[k]) * yn);
+                }
+                r.c[i].w[k] = pk_bf(unpk_bf(xr.c[i].w[k]) + yn);
             }
-            *(bf8_t*)(xrow + c * 8) = pack8(o);
+            *(bf8_t*)(xrow + ch * 8) = r.c[i];
         }
     }
     if (p.next_mode == 0) return;
@@ -118,44 +132,47 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
     u16* hrow = p.h + (size_t)row * p.d;
     if (p.next_mode == 1) {
         const float r2 = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
-        apply_rms_mod_store(r, r2, p.next_w, nscale, nshift, hrow, nch, lane);
+        apply_rms_mod_store(r, r2, p.next_w, nscale, nshift, p.scale_pre, hrow, nch, lane);
     } else {
         // affine-free LayerNorm in fp32, modulate in fp32, one rounding (the cast autocast applies at the
         // final Linear) -- model.py:634-638, :660-661
-        float s = 0.f;
+        f32x2 s2 = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += r.v[i][e];
-        const float mean = wave_sum(s) / (float)p.d;
-        float q = 0.f;
+            for (int k = 0; k < 4; ++k) s2 += unpk_bf(r.c[i].w[k]);
+        const float mean = wave_sum(s2[0] + s2[1]) / (float)p.d;
+        const f32x2 mv = {mean, mean};
+        f32x2 q2 = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float dlt = r.v[i][e] - mean;
-                    q += dlt * dlt;
+                for (int k = 0; k < 4; ++k) {
+                    const f32x2 dlt = unpk_bf(r.c[i].w[k]) - mv;
+                    q2 = dlt * dlt + q2;
                 }
             }
         }
-        const float rstd = rsqrtf(wave_sum(q) / (float)p.d + p.eps_next);
+        const float rstd = rsqrtf(wave_sum(q2[0] + q2[1]) / (float)p.d + p.eps_next);
+        const f32x2 rs = {rstd, rstd};
+        const f32x2 one = {1.f, 1.f};
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) {
-                float sf[8], hf[8], o[8];
-                if (nscale) unpack8(*(const bf8_t*)(nscale + c * 8), sf);
-                if (nshift) unpack8(*(const bf8_t*)(nshift + c * 8), hf);
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                bf8_t sv, hv, o;
+                if (nscale) sv = *(const bf8_t*)(nscale + ch * 8);
+                if (nshift) hv = *(const bf8_t*)(nshift + ch * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float n = (r.v[i][e] - mean) * rstd;
-                    if (nscale) n = n * bfr(1.0f + sf[e]);
-                    if (nshift) n = n + hf[e];
-                    o[e] = n;
+                for (int k = 0; k < 4; ++k) {
+                    f32x2 n = (unpk_bf(r.c[i].w[k]) - mv) * rs;
+                    if (nscale) n = n * (p.scale_pre ? unpk_bf(sv.w[k]) : bfr2(one + unpk_bf(sv.w[k])));
+                    if (nshift) n = n + unpk_bf(hv.w[k]);
+                    o.w[k] = pk_bf(n);
                 }
-                *(bf8_t*)(hrow + c * 8) = pack8(o);
+                *(bf8_t*)(hrow + ch * 8) = o;
             }
         }
     }
@@ -163,21 +180,32 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
 
 }  // namespace
 
+#define LT_DISPATCH_CHUNKS(kernel, grid, args)                                                          \
+    switch ((((args).d >> 3) + 63) / 64) {                                                                \
+        case 1: hipLaunchKernelGGL(kernel<1>, grid, dim3(256), 0, stream, args); break;                   \
+        case 2: hipLaunchKernelGGL(kernel<2>, grid, dim3(256), 0, stream, args); break;                   \
+        case 3: hipLaunchKernelGGL(kernel<3>, grid, dim3(256), 0, stream, args); break;                   \
+        case 4: hipLaunchKernelGGL(kernel<4>, grid, dim3(256), 0, stream, args); break;                   \
+        case 5: hipLaunchKernelGGL(kernel<5>, grid, dim3(256), 0, stream, args); break;                   \
+        case 6: hipLaunchKernelGGL(kernel<6>, grid, dim3(256), 0, stream, args); break;                   \
+        default: hipLaunchKernelGGL(kernel<8>, grid, dim3(256), 0, stream, args); break;                  \
+    }
+
 int launch_rmsnorm_mod(const NormModArgs& a, hipStream_t stream) {
-    LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH, "rmsnorm_mod: d=%d must be a multiple of 8 and <= 4096", a.d);
+    LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH_LIMIT, "rmsnorm_mod: d=%d must be a multiple of 8 and <= 4096", a.d);
     LT_REQUIRE(a.rows_per_batch > 0 && a.rows > 0, "rmsnorm_mod: empty input");
-    hipLaunchKernelGGL(rmsnorm_mod_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
+    LT_DISPATCH_CHUNKS(rmsnorm_mod_kernel, dim3((a.rows + 3) / 4), a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream) {
-    LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH, "gated_residual_norm: d=%d must be a multiple of 8 and <= 4096", a.d);
+    LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH_LIMIT, "gated_residual_norm: d=%d must be a multiple of 8 and <= 4096", a.d);
     LT_REQUIRE(a.rows_per_batch > 0 && a.rows > 0, "gated_residual_norm: empty input");
     LT_REQUIRE(a.gate_mode == 2 || a.gate != nullptr, "gated_residual_norm: gate pointer missing");
     LT_REQUIRE(a.post_mode == 0 || a.post_w != nullptr, "gated_residual_norm: post-norm weight missing");
     LT_REQUIRE(a.next_mode == 0 || a.h != nullptr, "gated_residual_norm: h output missing");
-    hipLaunchKernelGGL(gated_residual_norm_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
+    LT_DISPATCH_CHUNKS(gated_residual_norm_kernel, dim3((a.rows + 3) / 4), a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -111,7 +111,7 @@ def test_rmsnorm_mod():
     ld = 3 * d
     mod = bf(torch.randn(B, ld, generator=g) * 0.5)
     out = torch.empty_like(x)
-    ok(lib().lt_op_rmsnorm_mod(P(x), P(w), P(mod[:, d:]), None, ld, P(out), B, N, d, 1e-5, stream()))
+    ok(lib().lt_op_rmsnorm_mod(P(x), P(w), P(mod[:, d:]), None, ld, P(out), B, N, d, 1e-5, 0, stream()))
     torch.cuda.synchronize()
     xf = x.float().cpu()
     n = r16(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
@@ -136,8 +136,18 @@ def test_gated_residual_norm(next_mode):
     h = torch.full_like(x, float("nan"))
     ok(lib().lt_op_gated_residual_norm(P(x_dev), P(y), P(pw), P(mod[:, d:]), 1, 1, P(nw) if next_mode == 1 else None,
                                        P(mod[:, 2 * d:]) if next_mode else None, None, next_mode, ld, P(h), B, N, d,
-                                       1e-5, 1e-6, stream()))
+                                       1e-5, 1e-6, 0, stream()))
+    # engine path: gates / scales prepared once (tanh, 1 + scale) by prep_mod, row kernel with gate_mode 0 + scale_pre 1
+    # -> must be bit identical to the in-kernel form
+    mod2, x2, h2 = mod.clone(), x.clone(), torch.full_like(x, float("nan"))
+    ok(lib().lt_op_prep_mod(P(mod2), B, ld, 1, 4, d, 0b0010, 0b0100, -1, stream()))
+    ok(lib().lt_op_gated_residual_norm(P(x2), P(y), P(pw), P(mod2[:, d:]), 1, 0, P(nw) if next_mode == 1 else None,
+                                       P(mod2[:, 2 * d:]) if next_mode else None, None, next_mode, ld, P(h2), B, N, d,
+                                       1e-5, 1e-6, 1, stream()))
     torch.cuda.synchronize()
+    assert torch.equal(x2, x_dev)
+    if next_mode:
+        assert torch.equal(h2, h)
     m = mod.float().cpu()
     gate = r16(torch.tanh(m[:, d:2 * d])).repeat_interleave(N, dim=0)
     scale = m[:, 2 * d:3 * d].repeat_interleave(N, dim=0)
