@@ -16,8 +16,8 @@
 
 namespace {
 
-constexpr int MAXCH = 8;
-
+// one wave per token row; compiled per chunk count (16-byte chunks per lane) so small widths keep occupancy
+template <int MAXCH>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkPostArgs p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -29,36 +29,35 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkPostArgs p) {
     const int cph = p.hd >> 3;  // chunks per head
     const u16* src = p.src + (size_t)row * p.ld_src + p.col0;
 
-    float v[MAXCH][8];
-    float s = 0.f;
+    bf8_t raw[MAXCH];
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         const int c = lane + 64 * i;
-        if (c < nch) {
-            unpack8(*(const bf8_t*)(src + c * 8), v[i]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[i][e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-        }
+        if (c < nch) raw[i] = *(const bf8_t*)(src + c * 8);
+        else raw[i].w[0] = raw[i].w[1] = raw[i].w[2] = raw[i].w[3] = 0u;
     }
     float mean = 0.f, rstd = 1.f;
-    if (p.ln_w) {
-        mean = wave_sum(s) / (float)width;
-        float q = 0.f;
+    if (p.ln_w) {  // nn.LayerNorm over the full projection width, fp32 (model.py:211-215, :361-362)
+        f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s2 += unpk_bf(raw[i].w[k]);
+        mean = wave_sum(s2[0] + s2[1]) / (float)width;
+        const f32x2 mv = {mean, mean};
+        f32x2 q2 = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = v[i][e] - mean;
-                    q += d * d;
+                for (int k = 0; k < 4; ++k) {
+                    const f32x2 dl = unpk_bf(raw[i].w[k]) - mv;
+                    q2 = dl * dl + q2;
                 }
             }
         }
-        rstd = rsqrtf(wave_sum(q) / (float)width + p.ln_eps);
+        rstd = rsqrtf(wave_sum(q2[0] + q2[1]) / (float)width + p.ln_eps);
     }
 
     // rotary table: branch 0 = linear interpolation (t < watershed), branch 1 = NTK (model.py:944-949)
@@ -67,45 +66,34 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkPostArgs p) {
     const int nfreq = (p.rope_mode == 1) ? (p.hd >> 2) : (p.hd >> 1);
     const float* cs = p.cs ? p.cs + (size_t)branch * p.cs_len * nfreq * 2 : nullptr;
     const int gr = n / p.grid_w, gc = n - gr * p.grid_w;
+    const f32x2 mv = {mean, mean}, rv = {rstd, rstd}, osc = {p.out_scale, p.out_scale};
 
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
             const int head = c / cph, ci = c - head * cph;
-            float y[8];
+            bf8_t wv, bv, o;
             if (p.ln_w) {
-                float wf[8], bf[8];
-                unpack8(*(const bf8_t*)(p.ln_w + c * 8), wf);
-                unpack8(*(const bf8_t*)(p.ln_b + c * 8), bf);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (v[i][e] - mean) * rstd * wf[e] + bf[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = v[i][e];
+                wv = *(const bf8_t*)(p.ln_w + c * 8);
+                bv = *(const bf8_t*)(p.ln_b + c * 8);
             }
-            float o[8];
-            if (p.rope_mode == 0) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = y[e];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {  // one complex slot = one bf16 pair
+                f32x2 y = unpk_bf(raw[i].w[j]);
+                if (p.ln_w) y = (y - mv) * rv * unpk_bf(wv.w[j]) + unpk_bf(bv.w[j]);
+                if (p.rope_mode != 0) {
                     const int pr = 4 * ci + j;  // complex slot inside the head
                     int pos, fi;
                     if (p.rope_mode == 1) { fi = pr >> 1; pos = (pr & 1) ? gc : gr; }
                     else { fi = pr; pos = n; }
                     const float2 t = *(const float2*)(cs + ((size_t)pos * nfreq + fi) * 2);
-                    o[2 * j] = y[2 * j] * t.x - y[2 * j + 1] * t.y;
-                    o[2 * j + 1] = y[2 * j] * t.y + y[2 * j + 1] * t.x;
+                    y = f32x2{y[0] * t.x - y[1] * t.y, y[0] * t.y + y[1] * t.x};
                 }
+                if (p.out_scale != 1.0f) y = y * osc;
+                o.w[j] = pk_bf(y);
             }
-            if (p.out_scale != 1.0f) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] *= p.out_scale;
-            }
-            u16* dst = p.dst + (((size_t)b * p.heads + head) * p.N + n) * p.hd + ci * 8;
-            *(bf8_t*)dst = pack8(o);
+            *(bf8_t*)(p.dst + (((size_t)b * p.heads + head) * p.N + n) * p.hd + ci * 8) = o;
         }
     }
 }
@@ -147,13 +135,22 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const u16* __restrict_
 
 int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
     const int width = a.heads * a.hd;
-    LT_REQUIRE(a.hd % 8 == 0 && width <= 64 * 8 * MAXCH, "qk_norm_rope: hd %% 8 == 0 and heads*hd <= 4096 required (got %d x %d)", a.heads, a.hd);
+    LT_REQUIRE(a.hd % 8 == 0 && width <= 64 * 8 * 8, "qk_norm_rope: hd %% 8 == 0 and heads*hd <= 4096 required (got %d x %d)", a.heads, a.hd);
     LT_REQUIRE(a.ld_src % 8 == 0 && a.col0 % 8 == 0, "qk_norm_rope: ld_src/col0 must be multiples of 8");
     LT_REQUIRE(a.rope_mode == 0 || a.cs != nullptr, "qk_norm_rope: rotary table missing");
     LT_REQUIRE(a.rope_mode != 1 || (a.hd % 4 == 0 && a.grid_w > 0), "qk_norm_rope: 2-D rope needs hd %% 4 == 0");
     LT_REQUIRE((a.ln_w == nullptr) == (a.ln_b == nullptr), "qk_norm_rope: LayerNorm weight and bias must come together");
     const int rows = a.B * a.N;
-    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+    const dim3 grid((rows + 3) / 4);
+    switch (((width >> 3) + 63) / 64) {
+        case 1: hipLaunchKernelGGL(qk_norm_rope_kernel<1>, grid, dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(qk_norm_rope_kernel<2>, grid, dim3(256), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(qk_norm_rope_kernel<3>, grid, dim3(256), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(qk_norm_rope_kernel<4>, grid, dim3(256), 0, stream, a); break;
+        case 5: hipLaunchKernelGGL(qk_norm_rope_kernel<5>, grid, dim3(256), 0, stream, a); break;
+        case 6: hipLaunchKernelGGL(qk_norm_rope_kernel<6>, grid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL(qk_norm_rope_kernel<8>, grid, dim3(256), 0, stream, a); break;
+    }
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
