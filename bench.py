@@ -115,6 +115,14 @@ def main():
     ap.add_argument("--steps", type=int, default=29, help="timed denoising steps (NFE); 29 = one 30-point Euler grid")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-steps", type=int, default=1,
+                    help="NFEs of the timed region whose GEMM launches carry HIP start/stop events (0 = all).  A timed launch "
+                         "costs ~0.1 ms of queue idle time on this stack (the host waits on the dispatch signal), so the default "
+                         "samples one NFE = 98 launches = every GEMM shape x 24 layers; all NFEs have the same launch mix")
+    ap.add_argument("--profile-classes", type=int, default=1,
+                    help="bit mask of kernel classes bracketed by HIP events IN THE TIMED REGION: 1 GEMM (the roofline kernel, "
+                         "default), 2 attention, 4 other.  Every bracketed launch costs two event packets (all classes: +4 %% "
+                         "wall), so the attention / other breakdown is taken in a short untimed pass after the timed region")
     ap.add_argument("--gqa", action="store_true", help="NextDiT_2B_GQA_patch2 instead of the MHA model")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B knob: 1 baseline, 2 VALU-diet, 3 ping-pong (default)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B knob: 0 auto (default), 1 256x256, 2 256x288")
@@ -162,7 +170,11 @@ def main():
         run(args.warmup)
     torch.cuda.synchronize()
     eng = model._engine
-    eng.profile_enable(True)
+    eng.profile_enable(args.profile_classes)
+    # HIP start/stop events on the GEMM dispatches of the first --event-steps NFE of the timed region (every NFE has the
+    # same launch mix; timing all of them costs ~2.5 ms per NFE of queue idle time, which would be charged to `value`)
+    gemm_launches_per_nfe = 4 * model.n_layers + 2
+    eng.profile_set_budget(0, -1 if args.event_steps <= 0 else args.event_steps * gemm_launches_per_nfe)
     eng.profile_reset()
     parallel.barrier()
     torch.cuda.synchronize()
@@ -174,6 +186,17 @@ def main():
     dt = parallel.max_over_ranks(dt, dev)
     eng.profile_enable(False)
     assert eng.last_nfe() == args.steps
+    gemm_prof = eng.profile_read(0)
+    # untimed pass for the per-class breakdown (events around every launch)
+    nb = min(4, args.steps)
+    eng.profile_set_budget(0, -1)
+    eng.profile_enable(7)
+    eng.profile_reset()
+    run(nb)
+    torch.cuda.synchronize()
+    eng.profile_enable(False)
+    breakdown = {k: eng.profile_read(i)[0] / nb for i, k in enumerate(("gemm", "attention", "other"))}
+    attn_ms_b, _, attn_fl_b = eng.profile_read(1)
     assert torch.isfinite(traj[-1].float()).all(), "non-finite latent"
 
     if rank == 0:
@@ -182,9 +205,7 @@ def main():
 
         cfgm = NextDiTConfig(n_kv_heads=8) if args.gqa else NEXT_2B
         nfe_flops = flops_per_nfe(cfgm, N_TOKENS, TEXT_LEN, 2)
-        gemm_ms, gemm_n, gemm_fl = eng.profile_read(0)
-        attn_ms, attn_n, attn_fl = eng.profile_read(1)
-        oth_ms, oth_n, _ = eng.profile_read(2)
+        gemm_ms, gemm_n, gemm_fl = gemm_prof
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic()
         out = {
@@ -208,11 +229,11 @@ def main():
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
                 "traffic_source": traffic_src,
                 "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                "event_bracketed_launches": (gemm_n if args.event_steps <= 0 else min(gemm_n, args.event_steps * gemm_launches_per_nfe)),
                 "algorithmic_flops_per_launch": gemm_fl / max(gemm_n, 1),
             },
-            "kernel_time_ms_per_step": {"gemm": gemm_ms / args.steps, "attention": attn_ms / args.steps,
-                                        "other": oth_ms / args.steps},
-            "attention_tflops_per_s": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0,
+            "kernel_time_ms_per_step": dict(breakdown, note=f"untimed pass of {nb} NFE with events around every launch"),
+            "attention_tflops_per_s": attn_fl_b / (attn_ms_b * 1e-3) / 1e12 if attn_ms_b > 0 else 0.0,
             "kernel_variants": {"attention": args.attn_variant or 3, "gemm": args.gemm_variant or 0},
         }
         if world == 1 and not args.no_cpu_baseline:

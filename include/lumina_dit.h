@@ -133,10 +133,14 @@ int64_t lt_last_nfe(lt_engine* e);
 /* ---- profiling hooks (bench.py roofline object) ----------------------------------------------- */
 /* class 0 = MFMA GEMM kernel, 1 = attention kernel, 2 = everything else.  When enabled, every
  * launch of that class is bracketed by HIP events on the launch stream. */
-int lt_profile_enable(lt_engine* e, int32_t on);
+int lt_profile_enable(lt_engine* e, int32_t on); /* 0 off, 1 all classes, else bit mask: 1 GEMM | 2 attention | 4 other (1 alone = all) */
 /* after the caller synchronised the stream: total ms, launches and algorithmic flops per class */
 int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t* launches, double* flops);
 int lt_profile_reset(lt_engine* e);
+/* bracket only the first max_event_launches launches of a class after each reset (the rest are counted, and
+ * lt_profile_read scales the measured time to all launches: every NFE has the same launch mix); < 0 = no limit.
+ * Event brackets serialise the queue (~1.4 ms per NFE when every launch is bracketed), so bench.py samples. */
+int lt_profile_set_budget(lt_engine* e, int32_t klass, int64_t max_event_launches);
 
 /* ---- operator-level entry points (parity tests call each kernel through these) ---------------- */
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in/out, fp32 accumulate.  K % 64 == 0.

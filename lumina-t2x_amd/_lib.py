@@ -73,6 +73,7 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_profile_enable": (_i32, [_vp, _i32]),
     "lt_profile_read": (_i32, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "lt_profile_reset": (_i32, [_vp]),
+    "lt_profile_set_budget": (_i32, [_vp, _i32, _i64]),
     "lt_op_gemm_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_trace": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "lt_op_pack_w13": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),

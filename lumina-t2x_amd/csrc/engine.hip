@@ -55,6 +55,7 @@ struct ProfClass {
     long long launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
+    size_t budget = (size_t)-1;  // bracket at most this many launches with events, count the rest (same launch mix every step)
 };
 
 }  // namespace
@@ -127,6 +128,7 @@ struct lt_engine {
     std::vector<float> t_host;
     long long last_nfe = 0;
     // profiling
+    int prof_mask = 0;  // bit k: class k launches are bracketed by HIP events
     bool prof_on = false;
     ProfClass prof[3];
 };
@@ -146,21 +148,23 @@ struct ProfScope {
     lt_engine* e;
     int k;
     hipStream_t s;
-    bool on = false;
+    bool on = false, attach = false;  // attach: the launch carries the event pair itself (no records here)
     size_t slot = 0;
-    ProfScope(lt_engine* e_, int klass, double flops, hipStream_t s_) : e(e_), k(klass), s(s_) {
-        if (!e->prof_on) return;
+    hipEvent_t ev0() const { return on ? e->prof[k].ev[slot].first : nullptr; }
+    hipEvent_t ev1() const { return on ? e->prof[k].ev[slot].second : nullptr; }
+    ProfScope(lt_engine* e_, int klass, double flops, hipStream_t s_, bool attach_ = false) : e(e_), k(klass), s(s_), attach(attach_) {
+        if (!e->prof_on || !((e->prof_mask >> k) & 1)) return;
         ProfClass& pc = e->prof[k];
         pc.flops += flops;
         pc.launches += 1;
-        if (pc.used < pc.ev.size()) {
+        if (pc.used < pc.ev.size() && pc.used < pc.budget) {
             on = true;
             slot = pc.used++;
-            hipEventRecord(pc.ev[slot].first, s);
+            if (!attach) hipEventRecord(pc.ev[slot].first, s);
         }
     }
     ~ProfScope() {
-        if (on) hipEventRecord(e->prof[k].ev[slot].second, s);
+        if (on && !attach) hipEventRecord(e->prof[k].ev[slot].second, s);
     }
 };
 
@@ -169,8 +173,8 @@ int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.bias_dtype = bias ? 1 : -1;
-    ProfScope ps(e, 0, 2.0 * M * (double)N * K, s);
-    return launch_gemm_bf16(g, epi, 0, s);
+    ProfScope ps(e, 0, 2.0 * M * (double)N * K, s, true);
+    return launch_gemm_bf16(g, epi, 0, s, ps.ev0(), ps.ev1());
 }
 
 int attention(lt_engine* e, const AttnArgs& a, hipStream_t s) {
@@ -330,14 +334,14 @@ int moe_ffn(lt_engine* e, LayerW& w, int branch, int M, int N, int B, hipStream_
     {   // grouped SwiGLU GEMM: each 256-row tile multiplies with its expert's packed w1|w3
         g.A = e->moe_xs; g.W = branch == 0 ? w.w13_t : w.w13_s; g.C = e->moe_us; g.M = P; g.N = 2 * F; g.K = d;
         g.lda = d; g.ldw = d; g.ldc = F; g.w_expert_stride = (long long)2 * F * d;
-        ProfScope ps(e, 0, 2.0 * (2.0 * M) * (2.0 * F) * d, s);  // algorithmic: every token visits two experts
-        if (launch_gemm_bf16(g, 1, 0, s)) return 1;
+        ProfScope ps(e, 0, 2.0 * (2.0 * M) * (2.0 * F) * d, s, true);  // algorithmic: every token visits two experts
+        if (launch_gemm_bf16(g, 1, 0, s, ps.ev0(), ps.ev1())) return 1;
     }
     {
         g.A = e->moe_us; g.W = branch == 0 ? w.w2_t : w.w2_s; g.C = e->moe_ys; g.M = P; g.N = d; g.K = F;
         g.lda = F; g.ldw = F; g.ldc = d; g.w_expert_stride = (long long)d * F;
-        ProfScope ps(e, 0, 2.0 * (2.0 * M) * (double)d * F, s);
-        if (launch_gemm_bf16(g, 0, 1, s)) return 1;  // 256-row tiles (the tile -> expert table is per 256 rows)
+        ProfScope ps(e, 0, 2.0 * (2.0 * M) * (double)d * F, s, true);
+        if (launch_gemm_bf16(g, 0, 1, s, ps.ev0(), ps.ev1())) return 1;  // 256-row tiles (the tile -> expert table is per 256 rows)
     }
     {
         ProfScope ps(e, 2, 0, s);
@@ -824,16 +828,34 @@ extern "C" int lt_profile_enable(lt_engine* e, int32_t on) {
     LT_REQUIRE(e, "null engine");
     if (on) {
         const size_t want[3] = {8192, 4096, 16384};
+        bool created = false;
         for (int k = 0; k < 3; ++k) {
             while (e->prof[k].ev.size() < want[k]) {
                 hipEvent_t a, b;
-                LT_CHECK_HIP(hipEventCreate(&a));
-                LT_CHECK_HIP(hipEventCreate(&b));
+                // device-scope release: the default event flags make every record a system-scope release (L2 write-back)
+                LT_CHECK_HIP(hipEventCreateWithFlags(&a, hipEventReleaseToDevice));
+                LT_CHECK_HIP(hipEventCreateWithFlags(&b, hipEventReleaseToDevice));
                 e->prof[k].ev.push_back({a, b});
+                created = true;
             }
+        }
+        if (created) {  // first use of an event allocates its signal (tens of us): pay that here, not in a timed region
+            for (int k = 0; k < 3; ++k)
+                for (auto& pr : e->prof[k].ev) {
+                    LT_CHECK_HIP(hipEventRecord(pr.first, nullptr));
+                    LT_CHECK_HIP(hipEventRecord(pr.second, nullptr));
+                }
+            LT_CHECK_HIP(hipStreamSynchronize(nullptr));
         }
     }
     e->prof_on = on != 0;
+    e->prof_mask = on == 1 ? 7 : (on & 7);  // 1 = all classes (historic), otherwise bit mask: 1 GEMM | 2 attention | 4 other
+    return 0;
+}
+
+extern "C" int lt_profile_set_budget(lt_engine* e, int32_t klass, int64_t max_event_launches) {
+    LT_REQUIRE(e && klass >= 0 && klass < 3, "lt_profile_set_budget: bad class");
+    e->prof[klass].budget = max_event_launches < 0 ? (size_t)-1 : (size_t)max_event_launches;
     return 0;
 }
 

@@ -21,6 +21,7 @@
 //    grouped (4 tile-rows, column-major) order so neighbouring tiles share A/W panels in one L2.
 #include "common.h"
 #include "kernels.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 namespace {
@@ -489,8 +490,11 @@ __global__ void pack_w13_kernel(const u16* __restrict__ w1, const u16* __restric
 }  // namespace
 
 namespace {
+// ev0 / ev1 (optional): start / stop events attached to THIS dispatch packet (hipExtLaunchKernelGGL) - the timestamps come
+// from the dispatch's own completion signal, no extra barrier packets in the queue (event records around a launch cost
+// tens of microseconds of queue idle time each on this stack)
 template <int WM, int WN, int MT, int NT, int EPI, bool PP>
-int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int SMEM = PP ? 4 * (BM + BN) * 64 : 2 * (BM + BN) * 128;
     const void* fn = PP ? (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI> : (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
@@ -500,8 +504,13 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
         attr_done = true;
     }
     const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
-    if (PP) hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
-    else hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
+    if (ev0) {
+        if (PP) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, ev0, ev1, 0, a);
+        else hipExtLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, ev0, ev1, 0, a);
+    } else {
+        if (PP) hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
+        else hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
+    }
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -525,7 +534,7 @@ void lt_set_gemm_pipeline(int v) { g_gemm_pipeline = v; }
 
 // variant: 0 = pick the tile shape that minimises (rounds over the CUs) x (tile width); 1 = 256x256; 2 = 256x288;
 //          3 / 4 = the same two shapes with the ping-pong kernel regardless of the process-wide pipeline option
-int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream) {
+int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     LT_REQUIRE(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
@@ -550,7 +559,7 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     }
     // SwiGLU GEMM (N = 2F = 12288 at cfg 2: whole rounds of 256x256 tiles): the ping-pong kernel measured +5 % over the classic
     // loop (opbench r01), so it is the default there; g_gemm_pipeline == 2 forces the classic loop everywhere (A/B).
-    if (epilogue == 1) return (pp || g_gemm_pipeline == 0) ? launch_cfg<2, 4, 4, 2, 1, true>(a, stream) : launch_cfg<2, 4, 4, 2, 1, false>(a, stream);
+    if (epilogue == 1) return (pp || g_gemm_pipeline == 0) ? launch_cfg<2, 4, 4, 2, 1, true>(a, stream, ev0, ev1) : launch_cfg<2, 4, 4, 2, 1, false>(a, stream, ev0, ev1);
     if (variant == 0) variant = g_gemm_variant;
     if (variant == 0) {
         const int cus = num_cus();
@@ -559,8 +568,8 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
         const long long c256 = ((t256 + cus - 1) / cus) * 256, c288 = ((t288 + cus - 1) / cus) * 288;
         variant = c288 < c256 ? 2 : 1;
     }
-    if (variant == 2) return pp ? launch_cfg<4, 3, 2, 3, 0, true>(a, stream) : launch_cfg<4, 3, 2, 3, 0, false>(a, stream);
-    return pp ? launch_cfg<2, 4, 4, 2, 0, true>(a, stream) : launch_cfg<2, 4, 4, 2, 0, false>(a, stream);
+    if (variant == 2) return pp ? launch_cfg<4, 3, 2, 3, 0, true>(a, stream, ev0, ev1) : launch_cfg<4, 3, 2, 3, 0, false>(a, stream, ev0, ev1);
+    return pp ? launch_cfg<2, 4, 4, 2, 0, true>(a, stream, ev0, ev1) : launch_cfg<2, 4, 4, 2, 0, false>(a, stream, ev0, ev1);
 }
 
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream) {

@@ -18,7 +18,9 @@ struct GemmArgs {
     const int* tile_expert = nullptr;
     long long w_expert_stride = 0;
 };
-int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream);
+// ev0 / ev1: optional start / stop events carried by the dispatch packet itself (profiling without extra queue packets)
+int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0 = nullptr,
+                     hipEvent_t ev1 = nullptr);
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream);
 
 // ---- norm / residual kernels (norm.hip) --------------------------------------------------------

@@ -184,8 +184,13 @@ class DiTEngine:
         return int(self.lib.lt_last_nfe(self.handle))
 
     # ---- profiling hooks used by bench.py -----------------------------------------------------------
-    def profile_enable(self, on: bool) -> None:
-        _lib.check(self.lib.lt_profile_enable(self.handle, int(on)), "lt_profile_enable")
+    def profile_enable(self, on) -> None:
+        """False / 0: off; True: every kernel class; int: bit mask (1 GEMM, 2 attention, 4 other)"""
+        mask = 7 if on is True else int(on)
+        _lib.check(self.lib.lt_profile_enable(self.handle, mask), "lt_profile_enable")
+
+    def profile_set_budget(self, klass: int, max_event_launches: int) -> None:
+        _lib.check(self.lib.lt_profile_set_budget(self.handle, klass, max_event_launches), "lt_profile_set_budget")
 
     def profile_reset(self) -> None:
         _lib.check(self.lib.lt_profile_reset(self.handle), "lt_profile_reset")

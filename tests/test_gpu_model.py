@@ -160,3 +160,29 @@ def test_full_width_two_layers_vs_oracle():
     one = model.forward_with_cfg(zb, t.cuda(), capb, mask.cuda(), 1.0, base_seqlen=4096, proportional_attn=True)
     plain = model(zb, t.cuda(), capb, mask.cuda())  # proportional flags persist on the module like the reference
     assert rel_l2(one[0], plain[0]) < 1e-2
+
+
+def test_cfg4_2048px_gqa_ntk_one_layer_vs_oracle():
+    """BASELINE configs[3] shapes: Lumina-Next-SFT 2B at 2048x2048 (latent 256x256 -> 16384 tokens per sample, M = 32768
+    rows), GQA (32 query / 8 kv heads), NTK-aware RoPE (scale_factor 2, t >= watershed), proportional attention against
+    base_seqlen 4096 - one layer at full width against the CPU oracle, plus the size-independent CFG property."""
+    cfg = synth.NextDiTConfig(n_layers=1, n_kv_heads=8)
+    sd = synth.synth_state_dict(cfg, seed=51)
+    z, t, cap, mask = synth.synth_inputs(cfg, latent_hw=(256, 256), text_len=64, uncond_len=8, seed=52, t_value=0.6)
+    model = models.NextDiT(**cfg.ctor_kwargs())
+    model.load_state_dict(sd, strict=True)
+    model = model.eval().to("cuda", torch.bfloat16)
+    zb, capb = z.to("cuda", torch.bfloat16), cap.to("cuda", torch.bfloat16)
+    kw = dict(scale_factor=2.0, scale_watershed=0.3, base_seqlen=4096, proportional_attn=True)
+    got = model.forward_with_cfg(zb, t.cuda(), capb, mask.cuda(), 4.0, **kw)
+    assert got.shape == zb.shape and torch.isfinite(got.float()).all()
+    assert torch.equal(got[0, :3], got[1, :3])
+    want = O.forward_with_cfg(sd, cfg, zb.float().cpu(), t, capb.float().cpu(), mask, 4.0, **kw)
+    err = rel_l2(got, want)
+    assert err < TOL_CFG4, err
+    assert rel_l2(got[:, 3], want[:, 3]) < TOL_FWD
+    # linear-interpolation branch (t < watershed) must differ from the NTK branch and still match the oracle
+    t_lo = torch.full((2,), 0.1)
+    got_lo = model.forward_with_cfg(zb, t_lo.cuda(), capb, mask.cuda(), 4.0, **kw)
+    want_lo = O.forward_with_cfg(sd, cfg, zb.float().cpu(), t_lo, capb.float().cpu(), mask, 4.0, **kw)
+    assert rel_l2(got_lo, want_lo) < TOL_CFG4, rel_l2(got_lo, want_lo)
