@@ -756,8 +756,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) pa[g][e] = (__bf16)__builtin_amdgcn_exp2f(sc[g >> 1][8 * (g & 1) + e]);
         // keep the bf16 packing in THIS phase (hipcc otherwise sinks the cvt_pk next to the PV MFMAs of the X phase)
+#ifndef LT_ATTN_UNPIN_CVT
 #pragma unroll
         for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(pa[g]));
+#endif
     };
     auto phase_y = [&](int t) __attribute__((always_inline)) { phase_y_gen(t, t == ntile - 1 && (p.Nk & 63), p.Nk, nullptr); };
 
