@@ -274,6 +274,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     static_assert(EPI == 0 || NT % 2 == 0, "SwiGLU epilogue pairs accumulator tiles");
     static_assert(IP <= 4, "staging pieces per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long t_entry = 0;
+    if constexpr (TRACE) t_entry = __builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -444,17 +446,22 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         }
     }
     for (int g = grp; g < G - 1; ++g) pp_barrier();  // equalise barrier counts before the (barrier-free) epilogue
+    unsigned long long t_loop_end = 0;
+    if constexpr (TRACE) t_loop_end = __builtin_amdgcn_s_memtime();
+
+    store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
+
     if constexpr (TRACE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores acknowledged
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         if (p.trace && lane == 0 && (blockIdx.x & 63) == 5) {
             unsigned long long* o = p.trace + ((size_t)(blockIdx.x >> 6) * NW + wave) * 8;
 #pragma unroll
             for (int i = 0; i < 6; ++i) o[i] = tr[i];
-            o[6] = (unsigned long long)ns;
-            o[7] = __builtin_amdgcn_s_memtime() - tstart;
+            o[6] = ((unsigned long long)ns << 32) | (unsigned)(tstart - t_entry);   // slabs | prologue cycles
+            o[7] = ((t_loop_end - tstart) << 20) | ((t_end - t_loop_end) & 0xfffff);  // main-loop cycles | epilogue cycles
         }
     }
-
-    store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
 }
 
 // explicit instantiations (hipcc 7.2 does not emit the kernel body for address-only uses inside another template)

@@ -38,12 +38,15 @@ for (M, N, K, variant, nw) in [(8192, 6912, 2304, 3, 8), (8192, 2304, 6144, 4, 1
     bm, bn = (256, 256) if variant == 3 else (256, 288)
     tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     rounds = (tiles + 255) // 256
-    blk_cyc = float(t[0, 0, 7])
-    print(f"== M{M} N{N} K{K} variant {variant}: slabs {int(t[0,0,6])} tiles {tiles} rounds {rounds}; wall us {walls}; "
-          f"main-loop cycles of one traced block {blk_cyc:.0f} -> implied clock >= {rounds * blk_cyc / walls['traced'] / 1e3:.2f} GHz")
+    v6, v7 = int(t[0, 0, 6]), int(t[0, 0, 7])
+    ns, pro, loop, epi = v6 >> 32, v6 & 0xffffffff, v7 >> 20, v7 & 0xfffff
+    blk_cyc = float(pro + loop + epi)
+    print(f"== M{M} N{N} K{K} variant {variant}: slabs {ns} tiles {tiles} rounds {rounds}; wall us {walls}; wave 0 of one traced "
+          f"block: prologue {pro} + main loop {loop} + epilogue {epi} cycles -> implied clock >= {rounds * blk_cyc / walls['traced'] / 1e3:.2f} GHz")
     for blk in range(0, min(4, t.shape[0])):
         if int(t[blk, 0, 6]) == 0:
             continue
         for w in range(nw):
-            per = [float(t[blk, w, i]) / float(t[blk, w, 6]) for i in range(6)]
+            nsl = float(int(t[blk, w, 6]) >> 32)
+            per = [float(t[blk, w, i]) / nsl for i in range(6)]
             print(f"  blk {blk*64+5:4d} wave {w:2d} grp {w//4}: " + " ".join(f"{n} {v:6.0f}" for n, v in zip(names, per)) + f" | step {sum(per):6.0f} cyc")
