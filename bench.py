@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--steps", type=int, default=29, help="timed denoising steps (NFE); 29 = one 30-point Euler grid")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine A/B knob name=value (lt_set_option), repeatable")
     ap.add_argument("--event-steps", type=int, default=1,
                     help="NFEs of the timed region whose GEMM launches carry HIP start/stop events (0 = all).  A timed launch "
                          "costs ~0.1 ms of queue idle time on this stack (the host waits on the dispatch signal), so the default "
@@ -130,6 +131,9 @@ def main():
     from lumina_t2x_amd import _lib
     if args.attn_variant is not None:
         _lib.check(_lib.load().lt_set_option(b"attention_variant", args.attn_variant))
+    for opt in args.opt:
+        k, v = opt.split("=")
+        _lib.check(_lib.load().lt_set_option(k.encode(), int(v)))
     if args.gemm_variant is not None:
         _lib.check(_lib.load().lt_set_option(b"gemm_variant", args.gemm_variant))
 

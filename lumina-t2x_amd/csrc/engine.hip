@@ -33,6 +33,7 @@ extern "C" const char* lt_version(void) { return "lumina_dit gfx950 r1"; }
 namespace {
 
 constexpr float LOG2E = 1.44269504088896340736f;
+int g_qkv_post_fused = 1;  // lt_set_option("qkv_post_fused"): one launch for q / k post-processing + V transpose (A/B knob)
 
 struct DevBuf {
     void* p = nullptr;
@@ -433,14 +434,23 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             qa.src = e->qkv; qa.ld_src = e->qkvn; qa.B = B; qa.N = N; qa.hd = hd; qa.rope_mode = v.rope_1d ? 2 : 1;
             qa.cs = e->rope; qa.t = t_dev; qa.grid_w = Wp; qa.cs_len = e->rope_len; qa.ln_eps = 1e-5f;
             qa.watershed = c.variant == LT_VARIANT_NEXT_T2I ? a->scale_watershed : 0.f;  // other families: one table (branch 1)
+            QkvPostArgs pa;
             qa.col0 = 0; qa.heads = H; qa.dst = e->q;
             qa.ln_w = c.qk_norm ? w.q_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.q_norm_b : nullptr;
-            if (launch_qk_norm_rope(qa, s)) return 1;
+            pa.q = qa;
             qa.col0 = d; qa.heads = Hkv; qa.dst = e->k;
             qa.ln_w = c.qk_norm ? w.k_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.k_norm_b : nullptr;
             qa.out_scale = sm_scale * LOG2E;  // softmax scale folded into K's one bf16 rounding (scores in log2 units)
-            if (launch_qk_norm_rope(qa, s)) return 1;
-            if (launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
+            pa.k = qa;
+            pa.v_src = e->qkv; pa.v_dst = e->vt; pa.v_ld_src = e->qkvn; pa.v_col0 = d + dkv; pa.v_B = B; pa.v_N = N;
+            pa.v_Npad = Npad; pa.v_kv_heads = Hkv; pa.v_hd = hd;
+            if (g_qkv_post_fused) {
+                if (launch_qkv_post(pa, s)) return 1;  // q, k post-processing and the V transpose in one launch
+            } else {
+                if (launch_qk_norm_rope(pa.q, s)) return 1;
+                if (launch_qk_norm_rope(pa.k, s)) return 1;
+                if (launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
+            }
         }
         AttnArgs at;
         at.q = e->q; at.k = e->k; at.vt = e->vt; at.bias = nullptr; at.out = e->attn; at.gate = nullptr; at.accumulate = 0;
@@ -885,6 +895,7 @@ extern "C" int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t*
 extern "C" int lt_set_option(const char* name, int32_t value) {
     LT_REQUIRE(name, "lt_set_option: null name");
     if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 3, "attention_variant must be 1, 2 or 3"); lt_set_attention_variant(value); return 0; }
+    if (strcmp(name, "qkv_post_fused") == 0) { g_qkv_post_fused = value != 0; return 0; }
     if (strcmp(name, "gemm_pipeline") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_pipeline must be 0, 1 or 2"); lt_set_gemm_pipeline(value); return 0; }
     if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }
     lt_set_error("lt_set_option: unknown option '%s'", name);

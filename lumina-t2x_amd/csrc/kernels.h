@@ -68,6 +68,15 @@ struct QkPostArgs {
 int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream);
 int launch_v_transpose(const u16* src, int ld_src, int col0, u16* dst, int B, int N, int Npad, int kv_heads,
                        int hd, hipStream_t stream);
+// the three passes above in one launch (engine path)
+struct QkvPostArgs {
+    QkPostArgs q, k;
+    const u16* v_src;
+    u16* v_dst;
+    int v_ld_src, v_col0, v_B, v_N, v_Npad, v_kv_heads, v_hd;
+    int nq_blocks = 0, nk_blocks = 0;  // filled by the launcher
+};
+int launch_qkv_post(const QkvPostArgs& a, hipStream_t stream);
 
 // ---- attention (attention.hip) -----------------------------------------------------------------
 struct AttnArgs {

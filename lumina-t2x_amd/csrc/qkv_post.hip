@@ -18,9 +18,7 @@ namespace {
 
 // one wave per token row; compiled per chunk count (16-byte chunks per lane) so small widths keep occupancy
 template <int MAXCH>
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkPostArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void qk_norm_rope_row(const QkPostArgs& p, int row, int lane) {
     const int rows = p.B * p.N;
     if (row >= rows) return;
     const int b = row / p.N, n = row - b * p.N;
@@ -98,14 +96,18 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkPostArgs p) {
     }
 }
 
+template <int MAXCH>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkPostArgs p) {
+    qk_norm_rope_row<MAXCH>(p, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
 // one block per (64-key tile, kv head, batch): V rows -> LDS (transposed, permuted) -> 128-byte rows
-__global__ __launch_bounds__(256) void v_transpose_kernel(const u16* __restrict__ src, int ld_src, int col0,
-                                                          u16* __restrict__ dst, int N, int Npad, int kv_heads,
-                                                          int hd) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void v_transpose_tile(const u16* __restrict__ src, int ld_src, int col0, u16* __restrict__ dst,
+                                                 int N, int Npad, int kv_heads, int hd, int bx, int kvh, int b,
+                                                 char* smem_raw) {
     u16* T = (u16*)smem_raw;  // [hd][72] (row stride 144 B: 16-B aligned, spreads banks)
     constexpr int LDT = 72;
-    const int n0 = blockIdx.x * 64, kvh = blockIdx.y, b = blockIdx.z;
+    const int n0 = bx * 64;
     const int cph = hd >> 3;
     const int nin = 64 * cph;
     for (int id = threadIdx.x; id < nin; id += 256) {
@@ -129,6 +131,35 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const u16* __restrict_
         const bf8_t t = *(const bf8_t*)(T + d * LDT + c * 8);
         *(bf8_t*)(dst + (((size_t)b * kv_heads + kvh) * hd + d) * Npad + n0 + c * 8) = t;
     }
+}
+
+__global__ __launch_bounds__(256) void v_transpose_kernel(const u16* __restrict__ src, int ld_src, int col0,
+                                                          u16* __restrict__ dst, int N, int Npad, int kv_heads,
+                                                          int hd) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    v_transpose_tile(src, ld_src, col0, dst, N, Npad, kv_heads, hd, blockIdx.x, blockIdx.y, blockIdx.z, smem_raw);
+}
+
+// q post-processing, k post-processing and the V transpose of one layer in ONE launch (three independent, HBM-bound
+// passes over the QKV GEMM output): workgroups [0, nq) take q rows, [nq, nq + nk) k rows, the rest V tiles, so the three
+// streams overlap instead of running back to back with two launch boundaries in between.
+template <int MAXCH>
+__global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int bid = blockIdx.x;
+    if (bid < p.nq_blocks) {
+        qk_norm_rope_row<MAXCH>(p.q, bid * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+        return;
+    }
+    bid -= p.nq_blocks;
+    if (bid < p.nk_blocks) {
+        qk_norm_rope_row<MAXCH>(p.k, bid * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+        return;
+    }
+    bid -= p.nk_blocks;
+    const int nx = p.v_Npad / 64;
+    v_transpose_tile(p.v_src, p.v_ld_src, p.v_col0, p.v_dst, p.v_N, p.v_Npad, p.v_kv_heads, p.v_hd, bid % nx,
+                     (bid / nx) % p.v_kv_heads, bid / (nx * p.v_kv_heads), smem_raw);
 }
 
 }  // namespace
@@ -163,6 +194,29 @@ int launch_v_transpose(const u16* src, int ld_src, int col0, u16* dst, int B, in
     dim3 grid(Npad / 64, kv_heads, B);
     hipLaunchKernelGGL(v_transpose_kernel, grid, dim3(256), hd * 72 * 2, stream, src, ld_src, col0, dst, N, Npad,
                        kv_heads, hd);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_qkv_post(const QkvPostArgs& a0, hipStream_t stream) {
+    QkvPostArgs a = a0;
+    const int wq = a.q.heads * a.q.hd, wk = a.k.heads * a.k.hd;
+    LT_REQUIRE(a.q.hd % 8 == 0 && wq <= 4096 && wk <= wq, "qkv_post: widths %d / %d unsupported", wq, wk);
+    LT_REQUIRE(a.v_Npad % 64 == 0 && a.v_Npad >= a.v_N && a.v_hd <= 128, "qkv_post: bad V shape");
+    a.nq_blocks = (a.q.B * a.q.N + 3) / 4;
+    a.nk_blocks = (a.k.B * a.k.N + 3) / 4;
+    const int nv = (a.v_Npad / 64) * a.v_kv_heads * a.v_B;
+    const dim3 grid(a.nq_blocks + a.nk_blocks + nv);
+    const int smem = a.v_hd * 72 * 2;
+    switch (((wq >> 3) + 63) / 64) {
+        case 1: hipLaunchKernelGGL(qkv_post_kernel<1>, grid, dim3(256), smem, stream, a); break;
+        case 2: hipLaunchKernelGGL(qkv_post_kernel<2>, grid, dim3(256), smem, stream, a); break;
+        case 3: hipLaunchKernelGGL(qkv_post_kernel<3>, grid, dim3(256), smem, stream, a); break;
+        case 4: hipLaunchKernelGGL(qkv_post_kernel<4>, grid, dim3(256), smem, stream, a); break;
+        case 5: hipLaunchKernelGGL(qkv_post_kernel<5>, grid, dim3(256), smem, stream, a); break;
+        case 6: hipLaunchKernelGGL(qkv_post_kernel<6>, grid, dim3(256), smem, stream, a); break;
+        default: hipLaunchKernelGGL(qkv_post_kernel<8>, grid, dim3(256), smem, stream, a); break;
+    }
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
