@@ -8,7 +8,12 @@ not vendored).  Here:
   (``lt_sample_ode``: one host loop in C++, no Python per step, no device syncs);
 * for any other callable the fixed-grid solvers of torchdiffeq (euler / midpoint / rk4 "3/8 rule") are
   restated below in plain torch ops on whatever device the state lives on.  This is host glue for the
-  model-callable protocol (transport.py:192-195), not a fallback of the HIP path.
+  model-callable protocol (transport.py:192-195), not a fallback of the HIP path;
+* ``dopri5`` (the default ``--solver`` of ``Next-DiT-ImageNet/sample.py:48`` and of ``Sampler.sample_ode``,
+  transport.py:349) is torchdiffeq's adaptive Dormand-Prince 5(4) solver, restated below: the step-size controller
+  lives on the host (one scalar device->host read per attempted step is inherent to adaptive stepping), every
+  model evaluation still runs on the engine through the model callable.  PARITY UNPINNED like the fixed-grid
+  solvers (torchdiffeq is neither vendored nor installed); anchored on closed-form ODEs in the tests.
 """
 import torch as th
 
@@ -30,8 +35,7 @@ def fixed_grid_odeint(func, y0, t, method="euler"):
     """
     if method not in FIXED_GRID_METHODS:
         raise NotImplementedError(
-            f"ODE method '{method}': only the fixed-grid solvers {FIXED_GRID_METHODS} are built "
-            "(adaptive dopri5 is listed as a later row in SURVEY.md 8f)")
+            f"ODE method '{method}': built solvers are {FIXED_GRID_METHODS} (fixed grid) and 'dopri5' (adaptive)")
     out = th.empty((len(t),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
     out[0] = y0
     y = y0
@@ -52,6 +56,124 @@ def fixed_grid_odeint(func, y0, t, method="euler"):
             dy = (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
         y = y + dy
         out[j + 1] = y
+    return out
+
+
+# ---- torchdiffeq's adaptive Dormand-Prince 5(4) (rk_common.RKAdaptiveStepsizeODESolver + dopri5.py) -------------------
+_DP_ALPHA = (1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0)
+_DP_BETA = (
+    (1 / 5,),
+    (3 / 40, 9 / 40),
+    (44 / 45, -56 / 15, 32 / 9),
+    (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+    (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
+    (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84),
+)
+_DP_C_SOL = (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0)
+_DP_C_ERR = (35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720, -2187 / 6784 + 12231 / 42400,
+             11 / 84 - 649 / 6300, -1 / 60)
+_DP_C_MID = (6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+             187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2)
+
+
+def _rms(x):
+    return x.float().pow(2).mean().sqrt()
+
+
+def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 1, stats=None):
+    """torchdiffeq.odeint(func, y0, t, rtol=rtol, atol=atol, method="dopri5"): solution at every point of ``t`` (dense
+    output through the 4th-order interpolant), steps chosen by the embedded error estimate.
+
+    Follows torchdiffeq's controller: initial step from Hairer's heuristic (``_select_initial_step``), error ratio =
+    rms(err / (atol + rtol max(|y0|, |y1|))), accept if <= 1, next step = dt * min(10, max(0.9 ratio^-1/5, 0.2 or 1)).
+    ``stats`` (optional dict) receives the number of function evaluations and accepted / rejected steps."""
+    t = t.to(device=y0.device)
+    tdt = t.dtype
+
+    def f(tt, y):
+        return _call(func, tt.to(tdt) if th.is_tensor(tt) else th.as_tensor(tt, dtype=tdt, device=y0.device), y)
+
+    nfe = 0
+    t0 = t[0]
+    f0 = f(t0, y0)
+    nfe += 1
+    # _select_initial_step(func, t0, y0, order = 4, ...)
+    scale = atol + y0.abs() * rtol
+    d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
+    h0 = 0.01 * d0 / d1 if (float(d0) >= 1e-5 and float(d1) >= 1e-5) else th.tensor(1e-6, device=y0.device)
+    h0 = h0.to(tdt)
+    f1 = f(t0 + h0, y0 + h0.to(y0.dtype) * f0)
+    nfe += 1
+    d2 = _rms((f1 - f0) / scale) / h0
+    if float(d1) <= 1e-15 and float(d2) <= 1e-15:
+        h1 = th.max(th.tensor(1e-6, dtype=tdt, device=y0.device), h0 * 1e-3)
+    else:
+        h1 = (0.01 / th.max(d1, d2)) ** (1.0 / 5.0)
+    dt = th.min(100 * h0, h1.to(tdt)).to(tdt)
+
+    out = th.empty((len(t),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+    out[0] = y0
+    y, fy, tcur = y0, f0, t0
+    tprev = t0
+    coeffs = [y0] * 5
+    accepted = rejected = 0
+    for i in range(1, len(t)):
+        next_t = t[i]
+        steps = 0
+        while float(next_t) > float(tcur):
+            assert steps < max_num_steps, "max_num_steps exceeded"
+            steps += 1
+            t1 = tcur + dt
+            dty = dt.to(y.dtype)
+            k = [fy]
+            yi = y
+            for alpha, beta in zip(_DP_ALPHA, _DP_BETA):
+                ti = t1 if alpha == 1.0 else tcur + alpha * dt
+                acc = k[0] * beta[0]
+                for kj, bj in zip(k[1:], beta[1:]):
+                    if bj != 0.0:
+                        acc = acc + kj * bj
+                yi = y + dty * acc
+                k.append(f(ti, yi))
+                nfe += 1
+            y1, f_1 = yi, k[-1]  # FSAL: the last stage is the 5th-order solution
+            err = k[0] * _DP_C_ERR[0]
+            for kj, cj in zip(k[1:], _DP_C_ERR[1:]):
+                if cj != 0.0:
+                    err = err + kj * cj
+            err = dty * err
+            tol = atol + rtol * th.max(y.abs(), y1.abs())
+            ratio = float(_rms(err / tol))
+            if ratio <= 1.0:  # accept: dense-output coefficients of this step, then move on
+                mid = k[0] * _DP_C_MID[0]
+                for kj, cj in zip(k[1:], _DP_C_MID[1:]):
+                    if cj != 0.0:
+                        mid = mid + kj * cj
+                y_mid = y + dty * mid
+                a = 2 * dty * (f_1 - fy) - 8 * (y1 + y) + 16 * y_mid
+                b = dty * (5 * fy - 3 * f_1) + 18 * y + 14 * y1 - 32 * y_mid
+                c = dty * (f_1 - 4 * fy) - 11 * y - 5 * y1 + 16 * y_mid
+                coeffs = [y, dty * fy, c, b, a]
+                tprev, tcur, y, fy = tcur, t1, y1, f_1
+                accepted += 1
+            else:
+                rejected += 1
+            # _optimal_step_size(dt, ratio, safety 0.9, ifactor 10, dfactor 0.2, order 5)
+            if ratio == 0.0:
+                dt = dt * 10.0
+            else:
+                dfactor = 1.0 if ratio < 1.0 else 0.2
+                dt = dt * min(10.0, max(0.9 / ratio ** 0.2, dfactor))
+        # _interp_evaluate(coeffs, tprev, tcur, next_t)
+        x = ((next_t - tprev) / (tcur - tprev)).to(y.dtype)
+        total = coeffs[0] + x * coeffs[1]
+        xp = x
+        for cf in coeffs[2:]:
+            xp = xp * x
+            total = total + xp * cf
+        out[i] = total
+    if stats is not None:
+        stats.update(nfe=nfe, accepted=accepted, rejected=rejected)
     return out
 
 
@@ -97,6 +219,8 @@ class ode:
             tvec = th.ones(y.size(0)).to(device) * t  # fp32 [B] (reference integrators.py:108)
             return self.drift(y, tvec, model, **model_kwargs)
 
+        if self.sampler_type == "dopri5":
+            return dopri5_odeint(_fn, x, self.t.to(device), rtol=self.rtol, atol=self.atol)
         return fixed_grid_odeint(_fn, x, self.t.to(device), method=self.sampler_type)
 
     def _sample_on_engine(self, x, target, kw):

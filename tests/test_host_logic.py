@@ -90,7 +90,7 @@ def test_drift_shape_assert_and_unknown_method():
     fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=3)
     with pytest.raises(AssertionError, match="Output shape"):
         fn(torch.ones(2, 4, 8, 8), lambda x, t, **kw: x[:, :2])
-    fn = Sampler(create_transport()).sample_ode(sampling_method="dopri5", num_steps=3)
+    fn = Sampler(create_transport()).sample_ode(sampling_method="bosh3", num_steps=3)  # a torchdiffeq solver we do not restate
     with pytest.raises(NotImplementedError):
         fn(torch.ones(2, 4, 8, 8), lambda x, t, **kw: -x)
 
@@ -124,3 +124,54 @@ def test_sde_sampler_shapes():
     fn = Sampler(create_transport()).sample_sde(num_steps=6, last_step="Mean")
     xs = fn(torch.randn(2, 4, 4, 4), lambda x, t, **kw: -x)
     assert len(xs) == 6 and all(v.shape == (2, 4, 4, 4) for v in xs)
+
+
+def test_dopri5_closed_forms_and_tolerance_scaling():
+    """adaptive Dormand-Prince 5(4) (default --solver of Next-DiT-ImageNet/sample.py:48): closed-form ODEs, error shrinks with
+    the tolerances, dense output at the requested grid, and agreement with scipy's RK45 (same pair, different controller)."""
+    import math
+
+    import numpy as np
+    from scipy.integrate import solve_ivp
+
+    from lumina_t2x_amd.transport.integrators import dopri5_odeint
+
+    t = torch.linspace(0, 1, 7, dtype=torch.float64)
+    errs = []
+    for rtol, atol in ((1e-3, 1e-6), (1e-5, 1e-8), (1e-7, 1e-10)):
+        st = {}
+        y = dopri5_odeint(lambda tt, y: -2.0 * y, torch.full((3, 2), 1.5, dtype=torch.float64), t, rtol=rtol, atol=atol, stats=st)
+        assert y.shape == (7, 3, 2) and torch.equal(y[0], torch.full((3, 2), 1.5, dtype=torch.float64))
+        exact = 1.5 * torch.exp(-2.0 * t)
+        errs.append(float((y[:, 0, 0] - exact).abs().max()))
+        assert errs[-1] < 5 * rtol * 1.5, (rtol, errs[-1])
+        assert st["nfe"] == 2 + 6 * (st["accepted"] + st["rejected"])  # f0 + initial-step probe + 6 stages per attempt (FSAL)
+    assert errs[0] > errs[1] > errs[2]
+    # non-autonomous, oscillatory: y' = A y + cos(5 t); compare with scipy RK45 at tight tolerances
+    A = torch.tensor([[0.0, 1.0], [-4.0, -0.3]], dtype=torch.float64)
+
+    def rhs(tt, y):
+        return y @ A.T + torch.cos(5.0 * tt)
+
+    y = dopri5_odeint(rhs, torch.tensor([[1.0, 0.0]], dtype=torch.float64), t, rtol=1e-8, atol=1e-10)
+    ref = solve_ivp(lambda tt, yy: A.numpy() @ yy + math.cos(5.0 * tt), (0.0, 1.0), [1.0, 0.0], method="RK45", rtol=1e-10,
+                    atol=1e-12, t_eval=t.numpy())
+    np.testing.assert_allclose(y[:, 0].numpy(), ref.y.T, rtol=0, atol=2e-7)
+
+
+def test_sampler_dopri5_through_transport_api():
+    """Sampler.sample_ode's default method is dopri5 (reference transport.py:349): the sampler must run it on any callable."""
+    tr = create_transport()
+    fn = Sampler(tr).sample_ode(num_steps=5, atol=1e-8, rtol=1e-6)  # sampling_method defaults to "dopri5"
+    z = torch.ones(2, 4, 4, 4)
+    calls = []
+
+    def model(x, t, **kw):
+        assert t.shape == (2,) and t.dtype == torch.float32  # integrators.py:108
+        calls.append(float(t[0]))
+        return -x
+
+    traj = fn(z, model)
+    assert traj.shape == (5, 2, 4, 4, 4)
+    assert abs(float(traj[-1].flatten()[0]) - 0.36787944) < 1e-5  # exp(-1)
+    assert len(calls) >= 8
