@@ -263,7 +263,11 @@ __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false>
+// TAILN: the barrier that hands the matrix pipe to the other group may sit TAILN MFMAs before the end of the MFMA segment
+// (those last MFMAs need registers only) so that the barrier's release latency overlaps with MFMA work.  Measured
+// (profiles/r01/opbench_pp_tail_ab.log): TAILN = 3 is 5-8 % SLOWER than 0 - the group's next READ segment (~420 cycles, LDS
+// bandwidth bound) starts that much later and becomes the period; kept as a documented negative result, default 0.
+template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(GemmArgs p) {
     constexpr int NW = WM * WN, G = NW / 4;
     static_assert(NW % 4 == 0 && G >= 2 && G <= 3, "ping-pong needs 2 or 3 waves per SIMD");
@@ -378,29 +382,29 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         pp_barrier();
         if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); }
     };
-    auto mfma_seg = [&](int s, auto do_stage) {
+    constexpr int NM = 2 * MT * NT;  // MFMAs of one segment
+    static_assert(TAILN >= 0 && TAILN < NM, "tail");
+    auto one_mfma = [&](int idx) __attribute__((always_inline)) {
+        const int k = idx / (MT * NT), mt = (idx / NT) % MT, nt = idx % NT;
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], af[k][mt], acc[mt][nt], 0, 0, 0);
+    };
+    auto mfma_seg = [&](int s, auto do_stage) __attribute__((always_inline)) {  // MFMAs [0, NM - TAILN) + the LDS-DMA of slab s+3
         __builtin_amdgcn_s_setprio(1);
-        constexpr int NM = 2 * MT * NT;                 // MFMAs of this segment
-        constexpr int EVERY = NM / (IP + 1) > 0 ? NM / (IP + 1) : 1;
-        int issued = 0, cnt = 0;
+        constexpr int HEAD = NM - TAILN;
+        constexpr int EVERY = HEAD / IP > 0 ? HEAD / IP : 1;
+        int issued = 0;
         char* base = smem + ((s + 3) & 3) * SLAB;
         const int soff = (s + 3) * 64;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], af[k][mt], acc[mt][nt], 0, 0, 0);
-                    ++cnt;
-                    if constexpr (decltype(do_stage)::value) {
-                        if (cnt % EVERY == 0 && issued < IP) {
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[issued], LDS_PTR(base + ldsoff[issued]), 16,
-                                                                     voff[issued], soff, 0, 0);
-                            ++issued;
-                        }
-                    }
+        for (int i = 0; i < HEAD; ++i) {
+            one_mfma(i);
+            if constexpr (decltype(do_stage)::value) {
+                if ((i + 1) % EVERY == 0 && issued < IP) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[issued], LDS_PTR(base + ldsoff[issued]), 16, voff[issued], soff, 0, 0);
+                    ++issued;
                 }
+            }
+        }
         if constexpr (decltype(do_stage)::value) {
             // pin the interleave: EVERY MFMAs, one LDS-DMA issue, ... (a clustered burst of DMA issues would
             // starve the matrix pipe of this in-order wave for a few hundred cycles)
@@ -409,15 +413,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
                 __builtin_amdgcn_sched_group_barrier(0x8, EVERY, 0);
                 __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x8, NM - IP * EVERY, 0);
+            if constexpr (HEAD - IP * EVERY > 0) __builtin_amdgcn_sched_group_barrier(0x8, HEAD - IP * EVERY, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
         if constexpr (TRACE) {
             __builtin_amdgcn_sched_barrier(0);
             ta = __builtin_amdgcn_s_memtime();
             tr[3] += tprev - tc; tr[4] += ta - tprev;
             tprev = ta;
         }
+    };
+    auto mfma_tail = [&]() __attribute__((always_inline)) {  // the last TAILN MFMAs, after the hand-over barrier
+#pragma unroll
+        for (int i = NM - TAILN; i < NM; ++i) one_mfma(i);
+        __builtin_amdgcn_s_setprio(0);
     };
     auto trace_gap = [&]() {  // after the post-MFMA barrier(s)
         if constexpr (TRACE) {
@@ -432,6 +440,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         read_seg(s);
         mfma_seg(s, std::true_type{});
         pp_barrier();
+        mfma_tail();
 #pragma unroll
         for (int g = 0; g < G - 2; ++g) pp_barrier();
         trace_gap();
@@ -441,8 +450,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         mfma_seg(s, std::false_type{});
         if (s + 1 < ns) {
             pp_barrier();
+            mfma_tail();
 #pragma unroll
             for (int g = 0; g < G - 2; ++g) pp_barrier();
+        } else {
+            mfma_tail();
         }
     }
     for (int g = grp; g < G - 1; ++g) pp_barrier();  // equalise barrier counts before the (barrier-free) epilogue
