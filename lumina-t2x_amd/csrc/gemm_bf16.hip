@@ -263,12 +263,24 @@ __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// TAILN: the barrier that hands the matrix pipe to the other group may sit TAILN MFMAs before the end of the MFMA segment
-// (those last MFMAs need registers only) so that the barrier's release latency overlaps with MFMA work.  Measured
-// (profiles/r01/opbench_pp_tail_ab.log): TAILN = 3 is 5-8 % SLOWER than 0 - the group's next READ segment (~420 cycles, LDS
-// bandwidth bound) starts that much later and becomes the period; kept as a documented negative result, default 0.
-template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0>
+// TAILN: the barrier that hands the matrix pipe to the other group sits TAILN MFMAs before the end of the MFMA segment; those
+// last MFMAs (k-step 1 fragments, registers only) are issued after the barrier INSIDE the group's next READ segment, between
+// its k-step 0 fragment reads, so the barrier's release latency (~95 cycles) is covered by this group's MFMA work while the
+// other group starts.  (First attempt, tail issued BEFORE the next READ: 5-8 % slower, profiles/r01/opbench_pp_tail_ab.log -
+// READ then started TAILN MFMAs late and READ + tail, not the MFMA segment, set the barrier interval.)
+// Measured (profiles/r01/opbench_gemm_pipelines.log): no gain either - a wave parked in s_barrier cannot issue, so the pipe
+// still idles for the release latency, and the tail MFMAs simply come out of the other group's segment (505 instead of 416
+// cycles for its 13 MFMAs).  Default stays TAILN = 0; option "gemm_pp_tail" keeps the A/B.
+//
+// MODE 1 ("rendezvous"): ONE barrier per slab.  Between two barriers group 0 runs MFMA(k) then READ(k+1), the other groups run
+// READ(k) then MFMA(k): matrix work sits beside memory work in both halves of the interval without a hand-over barrier in the
+// middle (an in-order wave whose MFMA finds the pipe busy simply waits for it), so the pipe idles for one barrier release per
+// slab instead of one per segment.  Hazards (interval k = after barrier k): slab k+1 is read in interval k (group 0) or k+1
+// (others) and every wave waited for its pieces of slab k+1 before barrier k; slab k+3 is issued in interval k into the slot
+// of slab k-1, whose last reads (other groups, interval k-1) completed before barrier k.
+template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0, int MODE = 0>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(GemmArgs p) {
+    static_assert(MODE == 0 || TAILN == 0, "rendezvous mode has no hand-over barrier");
     constexpr int NW = WM * WN, G = NW / 4;
     static_assert(NW % 4 == 0 && G >= 2 && G <= 3, "ping-pong needs 2 or 3 waves per SIMD");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
@@ -354,22 +366,58 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     else if (ns > 1) wait_vmcnt<IP>();
     else wait_vmcnt<0>();
     pp_barrier();
-    for (int g = 0; g < grp; ++g) pp_barrier();
+    if constexpr (MODE == 0)
+        for (int g = 0; g < grp; ++g) pp_barrier();
 
     bf16x8 wf[2][NT], af[2][MT];
     // TRACE build only: per-wave cycle totals of the six sub-segments of a step (s_memtime stamps)
     unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, ta = 0, tb = 0, tc = 0;
     unsigned long long tstart = 0;
     if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
-    auto read_seg = [&](int s) {
+    constexpr int NM = 2 * MT * NT;  // MFMAs of one segment
+    static_assert(TAILN >= 0 && TAILN < MT * NT, "tail MFMAs must all belong to k-step 1");
+    auto one_mfma = [&](int idx) __attribute__((always_inline)) {
+        const int k = idx / (MT * NT), mt = (idx / NT) % MT, nt = idx % NT;
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], af[k][mt], acc[mt][nt], 0, 0, 0);
+    };
+    // READ(s).  with_tail: the last TAILN MFMAs of the previous slab (k-step 1 fragments, registers only) are issued here,
+    // AFTER the hand-over barrier, interleaved with the k-step 0 fragment reads of slab s - so the barrier's release latency
+    // is covered by MFMA work of this group and this group's reads start at the hand-over, not TAILN MFMAs later.
+    auto read_seg = [&](int s, auto with_tail) __attribute__((always_inline)) {
         const char* sb = smem + (s & 3) * SLAB;
+        constexpr bool WT = decltype(with_tail)::value && TAILN > 0;
+        constexpr int R0 = NT + MT;
+        auto read0 = [&](int r) __attribute__((always_inline)) {
+            if (r < NT) wf[0][r] = *(const bf16x8*)(sb + w_row_off + r * 2048 + coff[0]);
+            else af[0][r - NT] = *(const bf16x8*)(sb + a_row_off + (r - NT) * 2048 + coff[0]);
+        };
+        if constexpr (WT) {
+            constexpr int RPT = R0 / (TAILN > 0 ? TAILN : 1);  // k-step 0 reads per tail MFMA
+            static_assert(R0 % (TAILN > 0 ? TAILN : 1) == 0, "tail interleave");
+            // the tail must win the matrix pipe against the other group's freshly started segment (same-priority arbitration
+            // is oldest-wave-first: the younger group's tail would sit behind the older group's whole segment and hold up
+            // this in-order wave's fragment reads behind it)
+            __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+            for (int i = 0; i < TAILN; ++i) {
+                one_mfma(NM - TAILN + i);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * 2048 + coff[k]);
+                for (int r = i * RPT; r < (i + 1) * RPT; ++r) read0(r);
+            }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * 2048 + coff[k]);
+            for (int i = 0; i < TAILN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RPT, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R0; ++r) read0(r);
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[1][nt] = *(const bf16x8*)(sb + w_row_off + nt * 2048 + coff[1]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[1][mt] = *(const bf16x8*)(sb + a_row_off + mt * 2048 + coff[1]);
         if constexpr (TRACE) ta = __builtin_amdgcn_s_memtime();
         if (s + 2 < ns) wait_vmcnt<IP>();  // slab s+1 landed (slab s+2 may still be in flight)
         else wait_vmcnt<0>();
@@ -381,12 +429,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         }
         pp_barrier();
         if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); }
-    };
-    constexpr int NM = 2 * MT * NT;  // MFMAs of one segment
-    static_assert(TAILN >= 0 && TAILN < NM, "tail");
-    auto one_mfma = [&](int idx) __attribute__((always_inline)) {
-        const int k = idx / (MT * NT), mt = (idx / NT) % MT, nt = idx % NT;
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], af[k][mt], acc[mt][nt], 0, 0, 0);
     };
     auto mfma_seg = [&](int s, auto do_stage) __attribute__((always_inline)) {  // MFMAs [0, NM - TAILN) + the LDS-DMA of slab s+3
         __builtin_amdgcn_s_setprio(1);
@@ -418,11 +460,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         if constexpr (TRACE) {
             __builtin_amdgcn_sched_barrier(0);
             ta = __builtin_amdgcn_s_memtime();
-            tr[3] += tprev - tc; tr[4] += ta - tprev;
+            if constexpr (MODE == 0) tr[3] += tprev - tc;
+            tr[4] += ta - tprev;
             tprev = ta;
         }
     };
-    auto mfma_tail = [&]() __attribute__((always_inline)) {  // the last TAILN MFMAs, after the hand-over barrier
+    auto mfma_tail = [&]() __attribute__((always_inline)) {  // the last slab's tail (no hand-over follows)
 #pragma unroll
         for (int i = NM - TAILN; i < NM; ++i) one_mfma(i);
         __builtin_amdgcn_s_setprio(0);
@@ -435,29 +478,91 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         }
     };
 
-    int s = 0;
-    for (; s + 3 < ns; ++s) {
-        read_seg(s);
-        mfma_seg(s, std::true_type{});
-        pp_barrier();
-        mfma_tail();
-#pragma unroll
-        for (int g = 0; g < G - 2; ++g) pp_barrier();
-        trace_gap();
-    }
-    for (; s < ns; ++s) {
-        read_seg(s);
-        mfma_seg(s, std::false_type{});
+    // every MFMA segment but the last one ends with the hand-over barrier; its tail is issued by the next READ
+    auto step = [&](int s, auto do_stage, auto with_tail) __attribute__((always_inline)) {
+        read_seg(s, with_tail);
+        mfma_seg(s, do_stage);
         if (s + 1 < ns) {
             pp_barrier();
-            mfma_tail();
+            if constexpr (TAILN == 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int g = 0; g < G - 2; ++g) pp_barrier();
         } else {
             mfma_tail();
         }
+        trace_gap();
+    };
+    if constexpr (MODE == 0) {
+        int s = 0;
+        if (ns > 3) { step(0, std::true_type{}, std::false_type{}); s = 1; }
+        for (; s + 3 < ns; ++s) step(s, std::true_type{}, std::true_type{});
+        if (s == 0) { step(0, std::false_type{}, std::false_type{}); s = 1; }
+        for (; s < ns; ++s) step(s, std::false_type{}, std::true_type{});
+        for (int g = grp; g < G - 1; ++g) pp_barrier();  // equalise barrier counts before the (barrier-free) epilogue
+    } else {
+        auto reads = [&](int s) __attribute__((always_inline)) {
+            const char* sb = smem + (s & 3) * SLAB;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * 2048 + coff[k]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * 2048 + coff[k]);
+            }
+        };
+        const bool lead = __builtin_amdgcn_readfirstlane(grp == 0 ? 1 : 0) != 0;
+        auto stamp = [&](int i) __attribute__((always_inline)) {  // TRACE: cycles since the previous stamp -> bucket i
+            if constexpr (TRACE) {
+                __builtin_amdgcn_sched_barrier(0);
+                ta = __builtin_amdgcn_s_memtime();
+                tr[i] += ta - tprev;
+                tprev = ta;
+            }
+        };
+        auto sync = [&](int k, auto do_stage) __attribute__((always_inline)) {
+            if (k + 1 < ns) {
+                if constexpr (decltype(do_stage)::value) wait_vmcnt<IP>();  // slab k+2 landed, slab k+3 in flight
+                else wait_vmcnt<0>();
+                stamp(1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                stamp(2);
+                pp_barrier();
+                stamp(5);
+            }
+        };
+        if (lead) {  // MFMA(k) then READ(k+1)
+            reads(0);
+            if (ns > 2) wait_vmcnt<IP>();  // slab 1 landed
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pp_barrier();
+            auto interval = [&](int k, auto do_stage) __attribute__((always_inline)) {
+                mfma_seg(k, do_stage);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < ns) reads(k + 1);
+                stamp(0);
+                sync(k, do_stage);
+            };
+            int k = 0;
+            for (; k + 3 < ns; ++k) interval(k, std::true_type{});
+            for (; k < ns; ++k) interval(k, std::false_type{});
+        } else {     // READ(k) then MFMA(k)
+            if (ns > 2) wait_vmcnt<IP>();
+            else wait_vmcnt<0>();
+            pp_barrier();
+            auto interval = [&](int k, auto do_stage) __attribute__((always_inline)) {
+                reads(k);
+                stamp(0);
+                mfma_seg(k, do_stage);
+                __builtin_amdgcn_s_setprio(0);
+                sync(k, do_stage);
+            };
+            int k = 0;
+            for (; k + 3 < ns; ++k) interval(k, std::true_type{});
+            for (; k < ns; ++k) interval(k, std::false_type{});
+        }
     }
-    for (int g = grp; g < G - 1; ++g) pp_barrier();  // equalise barrier counts before the (barrier-free) epilogue
     unsigned long long t_loop_end = 0;
     if constexpr (TRACE) t_loop_end = __builtin_amdgcn_s_memtime();
 
@@ -484,6 +589,13 @@ template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, false, 0, 1>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true, 0, 1>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1, false, 0, 1>(GemmArgs);
+template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0, false, 0, 1>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, false, 3>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1, false, 3>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true, 3>(GemmArgs);
 template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0, true>(GemmArgs);
 
 }  // namespace lt_gemm
@@ -512,11 +624,11 @@ namespace {
 // ev0 / ev1 (optional): start / stop events attached to THIS dispatch packet (hipExtLaunchKernelGGL) - the timestamps come
 // from the dispatch's own completion signal, no extra barrier packets in the queue (event records around a launch cost
 // tens of microseconds of queue idle time each on this stack)
-template <int WM, int WN, int MT, int NT, int EPI, bool PP>
+template <int WM, int WN, int MT, int NT, int EPI, bool PP, int TAIL = 0, int MODE = 0>
 int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int SMEM = PP ? 4 * (BM + BN) * 64 : 2 * (BM + BN) * 128;
-    const void* fn = PP ? (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI> : (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
+    const void* fn = PP ? (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE> : (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         LT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -524,10 +636,10 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     }
     const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
     if (ev0) {
-        if (PP) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, ev0, ev1, 0, a);
+        if (PP) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, ev0, ev1, 0, a);
         else hipExtLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, ev0, ev1, 0, a);
     } else {
-        if (PP) hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
+        if (PP) hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
         else hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
     }
     LT_CHECK_HIP(hipGetLastError());
@@ -547,38 +659,50 @@ int num_cus() {
 }  // namespace
 
 static int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 256x256, 2 = 256x288
-static int g_gemm_pipeline = 0;  // variant <= 2: 0 auto (ping-pong for the SwiGLU GEMM, classic elsewhere), 1 ping-pong, 2 classic
+static int g_gemm_pipeline = 0;  // variant <= 2: 0 auto (ping-pong for the SwiGLU GEMM, classic elsewhere), 1 ping-pong, 2 classic, 3 rendezvous
 void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
 void lt_set_gemm_pipeline(int v) { g_gemm_pipeline = v; }
+static int g_gemm_pp_tail = 0;   // 8-wave ping-pong kernel: 1 = tail MFMAs issued after the hand-over (TAILN = 3; measured no gain), 0 = plain
+void lt_set_gemm_pp_tail(int v) { g_gemm_pp_tail = v; }
 
 // variant: 0 = pick the tile shape that minimises (rounds over the CUs) x (tile width); 1 = 256x256; 2 = 256x288;
-//          3 / 4 = the same two shapes with the ping-pong kernel regardless of the process-wide pipeline option
+//          3 / 4 = the same two shapes with the ping-pong kernel regardless of the process-wide pipeline option;
+//          5 / 6 = the same two shapes with the single-barrier rendezvous kernel
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     LT_REQUIRE(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 4, "gemm: unknown variant %d", variant);
-    bool pp = g_gemm_pipeline == 1;
-    if (variant >= 3) { pp = true; variant -= 2; }
+    LT_REQUIRE(variant >= 0 && variant <= 6, "gemm: unknown variant %d", variant);
+    bool pp = g_gemm_pipeline == 1, rv = g_gemm_pipeline == 3;
+    if (variant >= 5) { rv = true; pp = false; variant -= 4; }
+    else if (variant >= 3) { pp = true; rv = false; variant -= 2; }
     if (a.trace) {  // diagnostic build of the ping-pong kernel with s_memtime stamps (scripts/gemm_trace.py)
         LT_REQUIRE(epilogue == 0 && (variant == 1 || variant == 2), "gemm trace: plain epilogue, explicit tile shape");
         constexpr int S1 = 4 * 512 * 64, S2 = 4 * 544 * 64;
         static bool done = false;
         if (!done) {
             LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp<2, 4, 4, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, S1));
+            LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp<2, 4, 4, 2, 0, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, S1));
+            LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp<2, 4, 4, 2, 0, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S1));
             LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp<4, 3, 2, 3, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, S2));
             done = true;
         }
         const int TMx = (a.M + 255) / 256;
-        if (variant == 1) hipLaunchKernelGGL((gemm_bf16_pp<2, 4, 4, 2, 0, true>), dim3(TMx * ((a.N + 255) / 256)), dim3(512), S1, stream, a);
+        if (variant == 1 && rv) hipLaunchKernelGGL((gemm_bf16_pp<2, 4, 4, 2, 0, true, 0, 1>), dim3(TMx * ((a.N + 255) / 256)), dim3(512), S1, stream, a);
+        else if (variant == 1 && g_gemm_pp_tail) hipLaunchKernelGGL((gemm_bf16_pp<2, 4, 4, 2, 0, true, 3>), dim3(TMx * ((a.N + 255) / 256)), dim3(512), S1, stream, a);
+        else if (variant == 1) hipLaunchKernelGGL((gemm_bf16_pp<2, 4, 4, 2, 0, true>), dim3(TMx * ((a.N + 255) / 256)), dim3(512), S1, stream, a);
         else hipLaunchKernelGGL((gemm_bf16_pp<4, 3, 2, 3, 0, true>), dim3(TMx * ((a.N + 287) / 288)), dim3(768), S2, stream, a);
         LT_CHECK_HIP(hipGetLastError());
         return 0;
     }
     // SwiGLU GEMM (N = 2F = 12288 at cfg 2: whole rounds of 256x256 tiles): the ping-pong kernel measured +5 % over the classic
     // loop (opbench r01), so it is the default there; g_gemm_pipeline == 2 forces the classic loop everywhere (A/B).
-    if (epilogue == 1) return (pp || g_gemm_pipeline == 0) ? launch_cfg<2, 4, 4, 2, 1, true>(a, stream, ev0, ev1) : launch_cfg<2, 4, 4, 2, 1, false>(a, stream, ev0, ev1);
+    if (epilogue == 1) {
+        if (rv) return launch_cfg<2, 4, 4, 2, 1, true, 0, 1>(a, stream, ev0, ev1);
+        if (!(pp || g_gemm_pipeline == 0)) return launch_cfg<2, 4, 4, 2, 1, false>(a, stream, ev0, ev1);
+        return g_gemm_pp_tail ? launch_cfg<2, 4, 4, 2, 1, true, 3>(a, stream, ev0, ev1) : launch_cfg<2, 4, 4, 2, 1, true>(a, stream, ev0, ev1);
+    }
     if (variant == 0) variant = g_gemm_variant;
     if (variant == 0) {
         const int cus = num_cus();
@@ -587,8 +711,10 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
         const long long c256 = ((t256 + cus - 1) / cus) * 256, c288 = ((t288 + cus - 1) / cus) * 288;
         variant = c288 < c256 ? 2 : 1;
     }
+    if (rv) return variant == 2 ? launch_cfg<4, 3, 2, 3, 0, true, 0, 1>(a, stream, ev0, ev1) : launch_cfg<2, 4, 4, 2, 0, true, 0, 1>(a, stream, ev0, ev1);
     if (variant == 2) return pp ? launch_cfg<4, 3, 2, 3, 0, true>(a, stream, ev0, ev1) : launch_cfg<4, 3, 2, 3, 0, false>(a, stream, ev0, ev1);
-    return pp ? launch_cfg<2, 4, 4, 2, 0, true>(a, stream, ev0, ev1) : launch_cfg<2, 4, 4, 2, 0, false>(a, stream, ev0, ev1);
+    if (!pp) return launch_cfg<2, 4, 4, 2, 0, false>(a, stream, ev0, ev1);
+    return g_gemm_pp_tail ? launch_cfg<2, 4, 4, 2, 0, true, 3>(a, stream, ev0, ev1) : launch_cfg<2, 4, 4, 2, 0, true>(a, stream, ev0, ev1);
 }
 
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream) {

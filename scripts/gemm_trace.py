@@ -9,11 +9,16 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
-from gpu_util import P, lib, ok, stream  # noqa: E402
+from gpu_util import P, lib, ok, set_option, stream  # noqa: E402
 
 L = lib()
+set_option("gemm_pp_tail", int(os.environ.get("LT_PP_TAIL", "1")))
+print("gemm_pp_tail =", os.environ.get("LT_PP_TAIL", "1"))
 names = ["ds_issue", "vm_wait", "lgkm_wait", "bar1", "mfma", "bar2"]
-for (M, N, K, variant, nw) in [(8192, 6912, 2304, 3, 8), (8192, 2304, 6144, 4, 12), (8192, 6912, 2304, 4, 12)]:
+CASES = [(8192, 6912, 2304, 3, 8), (8192, 2304, 6144, 4, 12), (8192, 6912, 2304, 4, 12)]
+if os.environ.get("LT_TRACE_VARIANT"):  # e.g. 5 = single-barrier rendezvous kernel, 256x256 tile
+    CASES = [(8192, 6912, 2304, int(os.environ["LT_TRACE_VARIANT"]), 8)]
+for (M, N, K, variant, nw) in CASES:
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     W = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(torch.bfloat16)
     Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
@@ -25,7 +30,7 @@ for (M, N, K, variant, nw) in [(8192, 6912, 2304, 3, 8), (8192, 2304, 6144, 4, 1
     walls = {}
     for nm, fn in (("traced", lambda: L.lt_op_gemm_trace(P(A), P(W), P(Cc), M, N, K, variant, P(tr), stream())),
                    ("untraced", lambda: L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(Cc), M, N, K, 0, variant, stream())),
-                   ("classic", lambda: L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(Cc), M, N, K, 0, variant - 2, stream()))):
+                   ("classic", lambda: L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(Cc), M, N, K, 0, 2 - variant % 2, stream()))):
         for _ in range(3):
             fn()
         st.record()
@@ -35,7 +40,7 @@ for (M, N, K, variant, nw) in [(8192, 6912, 2304, 3, 8), (8192, 2304, 6144, 4, 1
         torch.cuda.synchronize()
         walls[nm] = st.elapsed_time(en) / 10 * 1e3
     t = tr.cpu()
-    bm, bn = (256, 256) if variant == 3 else (256, 288)
+    bm, bn = (256, 256) if variant in (3, 5) else (256, 288)
     tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     rounds = (tiles + 255) // 256
     v6, v7 = int(t[0, 0, 6]), int(t[0, 0, 7])

@@ -41,7 +41,7 @@ def ab(cases, rounds):
     return {k: (statistics.median(v), min(v)) for k, v in res.items()}
 
 
-def bench_gemm(rounds, variants):
+def bench_gemm(rounds, variants, zeros=False):
     L = lib()
     shapes = [("qkv", 8192, 6912, 2304, 0), ("wo", 8192, 2304, 2304, 0), ("w13", 8192, 12288, 2304, 1),
               ("w2", 8192, 2304, 6144, 0)]
@@ -50,14 +50,19 @@ def bench_gemm(rounds, variants):
     for name, M, N, K, epi in shapes:
         A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        if zeros:  # power probe: same instruction stream, no operand toggling (clock is power-managed under MFMA load)
+            A.zero_()
+            W.zero_()
         outs = {}
         cases = {}
         for v in variants:
             out = torch.empty(M, N // 2 if epi else N, device="cuda", dtype=torch.bfloat16)
             outs[v] = out
 
-            def fn(v=v, out=out):
-                ok(L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(out), M, N, K, epi, v, stream()), "gemm")
+            def fn(v=v, out=out):  # "3t0" = variant 3 with the ping-pong tail overlap switched off
+                vi, tail = (int(v[:-2]), int(v[-1])) if isinstance(v, str) and "t" in v else (int(v), 1)
+                set_option("gemm_pp_tail", tail)
+                ok(L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(out), M, N, K, epi, vi, stream()), "gemm")
             cases[v] = fn
         r = ab(cases, rounds)
         ref = outs[variants[0]].float()
@@ -66,7 +71,7 @@ def bench_gemm(rounds, variants):
             med, mn = r[v]
             err = rel_l2(outs[v], ref) if v != variants[0] else 0.0
             tot[v] += med
-            print(f"gemm {name:4s} M{M} N{N} K{K} epi{epi} variant {v}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s"
+            print(f"gemm {name:4s} M{M} N{N} K{K} epi{epi} variant {v:>3}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s"
                   f"  (best {fl/mn/1e9:7.1f})  rel-vs-v{variants[0]} {err:.2e}", flush=True)
     fl_layer = 2.0 * 8192 * 2304 * (6912 + 2304 + 12288 + 6144)
     for v in variants:
@@ -152,10 +157,12 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--gemm-variants", type=str, default="1,2,3,4")
     ap.add_argument("--attn-variants", type=str, default="1,2")
+    ap.add_argument("--gemm-zeros", action="store_true", help="all-zero operands (power / clock probe)")
     a = ap.parse_args()
     print("device:", torch.cuda.get_device_name(0), flush=True)
     if "gemm" in a.what:
-        bench_gemm(a.rounds, [int(v) for v in a.gemm_variants.split(",")])
+        bench_gemm(a.rounds, [v if "t" in v else int(v) for v in a.gemm_variants.split(",")], zeros=a.gemm_zeros)
+        set_option("gemm_pp_tail", 1)
     if "attn" in a.what:
         bench_attn(a.rounds, [int(v) for v in a.attn_variants.split(",")])
     if "elem" in a.what:

@@ -45,7 +45,7 @@ def test_gemm_plain(M, N, K):
     assert max_abs(out, ref) < 0.04 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 2304), (300, 576, 128), (1024, 6912, 2304), (256, 288, 64), (257, 296, 192),
                                    (512, 512, 6144)])
 def test_gemm_tile_variants(variant, M, N, K):
@@ -61,7 +61,7 @@ def test_gemm_tile_variants(variant, M, N, K):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_gemm_identity_asymmetric(variant):
     """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
     K, N = 320, 576
@@ -86,7 +86,7 @@ def test_gemm_bias_and_edges():
     assert torch.all(big[200:] == 7.0)
 
 
-@pytest.mark.parametrize("pipeline", [1, 2])  # 1 = ping-pong wave groups (the default for this epilogue), 2 = classic loop
+@pytest.mark.parametrize("pipeline", [1, 2, 3])  # 1 = ping-pong wave groups, 2 = classic loop, 3 = single-barrier rendezvous
 @pytest.mark.parametrize("M,F_,K", [(256, 128, 64), (300, 1536, 576), (4096, 6144, 2304)])
 def test_gemm_swiglu(M, F_, K, pipeline):
     set_option("gemm_pipeline", pipeline)
