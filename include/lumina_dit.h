@@ -148,6 +148,12 @@ int lt_profile_set_budget(lt_engine* e, int32_t klass, int64_t max_event_launche
 int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, int32_t bias_dtype,
                     void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
                     void* stream);
+/* grouped (mixture-of-experts) form of lt_op_gemm_bf16 - replaces the per-expert Python loop `for i, expert in
+ * enumerate(self.experts): ... expert(x[batch_idx])` of Next-DiT-MoE/models/models2.py:470-476, :499-505 on expert-sorted
+ * rows: rows [256 t, 256 t + 256) of A multiply with W_dev + tile_expert[t] * w_expert_stride (elements); tile_expert[t] < 0
+ * marks a padding segment whose output rows are left untouched.  M % 256 == 0; tile_expert_dev: int32 [M / 256]. */
+int lt_op_gemm_grouped(const void* A_dev, const void* W_dev, const void* tile_expert_dev, int64_t w_expert_stride,
+                       void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* stream);
 /* diagnostics: the ping-pong GEMM (variant 3 | 4) built with s_memtime stamps; trace_dev receives, for every 64th
  * workgroup and each of its waves, 8 x uint64: cycle totals of {fragment-read issue, vmcnt wait, lgkmcnt wait,
  * pre-MFMA barrier, MFMA segment, post-MFMA barrier}, the slab count and the end stamp. */

@@ -75,6 +75,7 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_profile_reset": (_i32, [_vp]),
     "lt_profile_set_budget": (_i32, [_vp, _i32, _i64]),
     "lt_op_gemm_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "lt_op_gemm_grouped": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_trace": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "lt_op_pack_w13": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "lt_op_rmsnorm_mod": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),

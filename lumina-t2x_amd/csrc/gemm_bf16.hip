@@ -144,8 +144,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_tn(G
     tile_coords(blockIdx.x, gridDim.x, TM, TN, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const u16* Wg = p.W;
-    if (p.tile_expert) {  // grouped mode: this 256-row tile belongs to one expert (or is padding)
-        const int ex = p.tile_expert[tm];
+    if (p.tile_expert) {  // grouped mode: the 256-row segment this tile lies in belongs to one expert (or is padding)
+        const int ex = p.tile_expert[(tm * BM) >> 8];
         if (ex < 0) return;
         Wg += (size_t)ex * p.w_expert_stride;
     }
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     const int a_bytes = (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left);
     const int w_bytes = (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left);
     const u16* Wg = p.W;
-    if (p.tile_expert) {  // grouped mode (see GemmArgs); uniform exit before any barrier
-        const int ex = p.tile_expert[tm];
+    if (p.tile_expert) {  // grouped mode (see GemmArgs; the table is per 256 rows); uniform exit before any barrier
+        const int ex = p.tile_expert[(tm * BM) >> 8];
         if (ex < 0) return;
         Wg += (size_t)ex * p.w_expert_stride;
     }
@@ -585,10 +585,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 1>(GemmArgs);
 template __global__ void gemm_bf16_tn<4, 3, 2, 3, 0>(GemmArgs);
+template __global__ void gemm_bf16_tn<2, 2, 2, 2, 0>(GemmArgs);  // 128 x 128 classic loop (64-deep slabs: 128-byte rows per fetch)
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0>(GemmArgs);  // 128 x 128, small-M problems
+template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1>(GemmArgs);  // 128 x 128 with the SwiGLU epilogue (needs NT even)
+template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0>(GemmArgs);  //  64 x 128
+template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0, false, 0, 1>(GemmArgs);  // the same three with one barrier per slab
+template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1, false, 0, 1>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0, false, 0, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, false, 0, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true, 0, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1, false, 0, 1>(GemmArgs);
@@ -628,19 +635,22 @@ template <int WM, int WN, int MT, int NT, int EPI, bool PP, int TAIL = 0, int MO
 int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int SMEM = PP ? 4 * (BM + BN) * 64 : 2 * (BM + BN) * 128;
-    const void* fn = PP ? (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE> : (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
+    const void* fn;
+    if constexpr (PP) fn = (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>;
+    else fn = (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         LT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_done = true;
     }
     const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
-    if (ev0) {
-        if (PP) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, ev0, ev1, 0, a);
-        else hipExtLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, ev0, ev1, 0, a);
+    const dim3 grid(TM * TN), block(WM * WN * 64);
+    if constexpr (PP) {
+        if (ev0) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>), grid, block, SMEM, stream, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>), grid, block, SMEM, stream, a);
     } else {
-        if (PP) hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
-        else hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), dim3(TM * TN), dim3(WM * WN * 64), SMEM, stream, a);
+        if (ev0) hipExtLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), grid, block, SMEM, stream, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), grid, block, SMEM, stream, a);
     }
     LT_CHECK_HIP(hipGetLastError());
     return 0;
@@ -667,13 +677,36 @@ void lt_set_gemm_pp_tail(int v) { g_gemm_pp_tail = v; }
 
 // variant: 0 = pick the tile shape that minimises (rounds over the CUs) x (tile width); 1 = 256x256; 2 = 256x288;
 //          3 / 4 = the same two shapes with the ping-pong kernel regardless of the process-wide pipeline option;
-//          5 / 6 = the same two shapes with the single-barrier rendezvous kernel
+//          5 / 6 = the same two shapes with the single-barrier rendezvous kernel;
+//          7 / 8 = 128x128 / 64x128 ping-pong tiles (picked automatically when 256-wide tiles would fill < half the CUs)
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     LT_REQUIRE(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 6, "gemm: unknown variant %d", variant);
+    LT_REQUIRE(variant >= 0 && variant <= 9, "gemm: unknown variant %d", variant);
+    if (variant == 9) {  // experiment: 128 x 128 classic loop
+        LT_REQUIRE(epilogue == 0 && !a.trace, "gemm variant 9: plain epilogue only");
+        return launch_cfg<2, 2, 2, 2, 0, false>(a, stream, ev0, ev1);
+    }
+    const int cus = num_cus();
+    const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    // small-M problems (cfg 1 / cfg 5: 512 rows): 256-wide tiles leave most CUs idle and every workgroup is a long serial
+    // K loop that streams weights nobody else re-uses; 128 x 128 (or 64 x 128) ping-pong tiles give 4-8x the workgroups,
+    // each with its own 3-slab prefetch window.  Variants 7 / 8 force them.
+    const bool small = !a.trace && (variant == 7 || variant == 8 || (variant == 0 && g_gemm_variant == 0 && 2 * t256 <= cus));
+    if (small) {
+        const bool tiny = variant == 8 || (variant == 0 && 2 * t128 <= cus);
+        if (g_gemm_pipeline == 3) {  // A/B: single-barrier rendezvous loop
+            if (epilogue == 1) return launch_cfg<4, 2, 1, 2, 1, true, 0, 1>(a, stream, ev0, ev1);
+            if (tiny) return launch_cfg<2, 4, 1, 1, 0, true, 0, 1>(a, stream, ev0, ev1);
+            return launch_cfg<2, 4, 2, 1, 0, true, 0, 1>(a, stream, ev0, ev1);
+        }
+        if (epilogue == 1) return launch_cfg<4, 2, 1, 2, 1, true>(a, stream, ev0, ev1);
+        if (tiny) return launch_cfg<2, 4, 1, 1, 0, true>(a, stream, ev0, ev1);
+        return launch_cfg<2, 4, 2, 1, 0, true>(a, stream, ev0, ev1);
+    }
     bool pp = g_gemm_pipeline == 1, rv = g_gemm_pipeline == 3;
     if (variant >= 5) { rv = true; pp = false; variant -= 4; }
     else if (variant >= 3) { pp = true; rv = false; variant -= 2; }
@@ -705,9 +738,8 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     }
     if (variant == 0) variant = g_gemm_variant;
     if (variant == 0) {
-        const int cus = num_cus();
         const long long tm = (a.M + 255) / 256;
-        const long long t256 = tm * ((a.N + 255) / 256), t288 = tm * ((a.N + 287) / 288);
+        const long long t288 = tm * ((a.N + 287) / 288);
         const long long c256 = ((t256 + cus - 1) / cus) * 256, c288 = ((t288 + cus - 1) / cus) * 288;
         variant = c288 < c256 ? 2 : 1;
     }

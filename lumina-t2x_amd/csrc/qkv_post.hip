@@ -96,9 +96,13 @@ __device__ __forceinline__ void qk_norm_rope_row(const QkPostArgs& p, int row, i
     }
 }
 
+// 8 waves = 8 consecutive token rows per workgroup: in the head-major destination one head's 8 rows are 16 * hd bytes =
+// whole 128-byte lines (hd % 8 == 0), so no line is shared between workgroups (= between XCD L2s; a line written half by
+// one XCD and half by another goes to memory twice as partial writes).
+constexpr int QK_ROWS = 8;
 template <int MAXCH>
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkPostArgs p) {
-    qk_norm_rope_row<MAXCH>(p, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+__global__ __launch_bounds__(64 * QK_ROWS) void qk_norm_rope_kernel(QkPostArgs p) {
+    qk_norm_rope_row<MAXCH>(p, blockIdx.x * QK_ROWS + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // one block per (64-key tile, kv head, batch): V rows -> LDS (transposed, permuted) -> 128-byte rows
@@ -110,7 +114,7 @@ __device__ __forceinline__ void v_transpose_tile(const u16* __restrict__ src, in
     const int n0 = bx * 64;
     const int cph = hd >> 3;
     const int nin = 64 * cph;
-    for (int id = threadIdx.x; id < nin; id += 256) {
+    for (int id = threadIdx.x; id < nin; id += blockDim.x) {
         const int tok = id / cph, ci = id - tok * cph;
         const int n = n0 + tok;
         bf8_t t;
@@ -126,7 +130,7 @@ __device__ __forceinline__ void v_transpose_tile(const u16* __restrict__ src, in
     }
     __syncthreads();
     const int nout = hd * 8;
-    for (int id = threadIdx.x; id < nout; id += 256) {
+    for (int id = threadIdx.x; id < nout; id += blockDim.x) {
         const int d = id >> 3, c = id & 7;
         const bf8_t t = *(const bf8_t*)(T + d * LDT + c * 8);
         *(bf8_t*)(dst + (((size_t)b * kv_heads + kvh) * hd + d) * Npad + n0 + c * 8) = t;
@@ -144,16 +148,16 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const u16* __restrict_
 // passes over the QKV GEMM output): workgroups [0, nq) take q rows, [nq, nq + nk) k rows, the rest V tiles, so the three
 // streams overlap instead of running back to back with two launch boundaries in between.
 template <int MAXCH>
-__global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostArgs p) {
+__global__ __launch_bounds__(64 * QK_ROWS) void qkv_post_kernel(QkvPostArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int bid = blockIdx.x;
     if (bid < p.nq_blocks) {
-        qk_norm_rope_row<MAXCH>(p.q, bid * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+        qk_norm_rope_row<MAXCH>(p.q, bid * QK_ROWS + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
     bid -= p.nq_blocks;
     if (bid < p.nk_blocks) {
-        qk_norm_rope_row<MAXCH>(p.k, bid * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+        qk_norm_rope_row<MAXCH>(p.k, bid * QK_ROWS + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
     bid -= p.nk_blocks;
@@ -172,15 +176,15 @@ int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.rope_mode != 1 || (a.hd % 4 == 0 && a.grid_w > 0), "qk_norm_rope: 2-D rope needs hd %% 4 == 0");
     LT_REQUIRE((a.ln_w == nullptr) == (a.ln_b == nullptr), "qk_norm_rope: LayerNorm weight and bias must come together");
     const int rows = a.B * a.N;
-    const dim3 grid((rows + 3) / 4);
+    const dim3 grid((rows + QK_ROWS - 1) / QK_ROWS);
     switch (((width >> 3) + 63) / 64) {
-        case 1: hipLaunchKernelGGL(qk_norm_rope_kernel<1>, grid, dim3(256), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL(qk_norm_rope_kernel<2>, grid, dim3(256), 0, stream, a); break;
-        case 3: hipLaunchKernelGGL(qk_norm_rope_kernel<3>, grid, dim3(256), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL(qk_norm_rope_kernel<4>, grid, dim3(256), 0, stream, a); break;
-        case 5: hipLaunchKernelGGL(qk_norm_rope_kernel<5>, grid, dim3(256), 0, stream, a); break;
-        case 6: hipLaunchKernelGGL(qk_norm_rope_kernel<6>, grid, dim3(256), 0, stream, a); break;
-        default: hipLaunchKernelGGL(qk_norm_rope_kernel<8>, grid, dim3(256), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL(qk_norm_rope_kernel<1>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(qk_norm_rope_kernel<2>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(qk_norm_rope_kernel<3>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(qk_norm_rope_kernel<4>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
+        case 5: hipLaunchKernelGGL(qk_norm_rope_kernel<5>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
+        case 6: hipLaunchKernelGGL(qk_norm_rope_kernel<6>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
+        default: hipLaunchKernelGGL(qk_norm_rope_kernel<8>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
     }
     LT_CHECK_HIP(hipGetLastError());
     return 0;
@@ -203,19 +207,19 @@ int launch_qkv_post(const QkvPostArgs& a0, hipStream_t stream) {
     const int wq = a.q.heads * a.q.hd, wk = a.k.heads * a.k.hd;
     LT_REQUIRE(a.q.hd % 8 == 0 && wq <= 4096 && wk <= wq, "qkv_post: widths %d / %d unsupported", wq, wk);
     LT_REQUIRE(a.v_Npad % 64 == 0 && a.v_Npad >= a.v_N && a.v_hd <= 128, "qkv_post: bad V shape");
-    a.nq_blocks = (a.q.B * a.q.N + 3) / 4;
-    a.nk_blocks = (a.k.B * a.k.N + 3) / 4;
+    a.nq_blocks = (a.q.B * a.q.N + QK_ROWS - 1) / QK_ROWS;
+    a.nk_blocks = (a.k.B * a.k.N + QK_ROWS - 1) / QK_ROWS;
     const int nv = (a.v_Npad / 64) * a.v_kv_heads * a.v_B;
     const dim3 grid(a.nq_blocks + a.nk_blocks + nv);
     const int smem = a.v_hd * 72 * 2;
     switch (((wq >> 3) + 63) / 64) {
-        case 1: hipLaunchKernelGGL(qkv_post_kernel<1>, grid, dim3(256), smem, stream, a); break;
-        case 2: hipLaunchKernelGGL(qkv_post_kernel<2>, grid, dim3(256), smem, stream, a); break;
-        case 3: hipLaunchKernelGGL(qkv_post_kernel<3>, grid, dim3(256), smem, stream, a); break;
-        case 4: hipLaunchKernelGGL(qkv_post_kernel<4>, grid, dim3(256), smem, stream, a); break;
-        case 5: hipLaunchKernelGGL(qkv_post_kernel<5>, grid, dim3(256), smem, stream, a); break;
-        case 6: hipLaunchKernelGGL(qkv_post_kernel<6>, grid, dim3(256), smem, stream, a); break;
-        default: hipLaunchKernelGGL(qkv_post_kernel<8>, grid, dim3(256), smem, stream, a); break;
+        case 1: hipLaunchKernelGGL(qkv_post_kernel<1>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
+        case 2: hipLaunchKernelGGL(qkv_post_kernel<2>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
+        case 3: hipLaunchKernelGGL(qkv_post_kernel<3>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
+        case 4: hipLaunchKernelGGL(qkv_post_kernel<4>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
+        case 5: hipLaunchKernelGGL(qkv_post_kernel<5>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
+        case 6: hipLaunchKernelGGL(qkv_post_kernel<6>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
+        default: hipLaunchKernelGGL(qkv_post_kernel<8>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
     }
     LT_CHECK_HIP(hipGetLastError());
     return 0;

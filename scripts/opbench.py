@@ -41,10 +41,16 @@ def ab(cases, rounds):
     return {k: (statistics.median(v), min(v)) for k, v in res.items()}
 
 
-def bench_gemm(rounds, variants, zeros=False):
+SHAPES_CFG2 = [("qkv", 8192, 6912, 2304, 0), ("wo", 8192, 2304, 2304, 0), ("w13", 8192, 12288, 2304, 1),
+               ("w2", 8192, 2304, 6144, 0)]
+# BASELINE cfg 1 (Next-DiT-ImageNet 600M, 256 tokens, cond + null row): 512 rows - the small-M regime
+SHAPES_CFG1 = [("qkv", 512, 4608, 1536, 0), ("wo", 512, 1536, 1536, 0), ("w13", 512, 8192, 1536, 1), ("w2", 512, 1536, 4096, 0)]
+
+
+def bench_gemm(rounds, variants, zeros=False, shapes=SHAPES_CFG2, cold=0):
+    """cold > 0: rotate through `cold` different weight buffers (> 256 MiB of MALL in total) so every launch streams its
+    weights from HBM like the engine does (one GEMM per layer, 16-32 layers of distinct weights)."""
     L = lib()
-    shapes = [("qkv", 8192, 6912, 2304, 0), ("wo", 8192, 2304, 2304, 0), ("w13", 8192, 12288, 2304, 1),
-              ("w2", 8192, 2304, 6144, 0)]
     g = torch.Generator(device="cuda").manual_seed(0)
     tot = {v: 0.0 for v in variants}
     for name, M, N, K, epi in shapes:
@@ -53,14 +59,26 @@ def bench_gemm(rounds, variants, zeros=False):
         if zeros:  # power probe: same instruction stream, no operand toggling (clock is power-managed under MFMA load)
             A.zero_()
             W.zero_()
+        Ws = [W] + [W.clone() for _ in range(max(0, cold - 1))]
+        rot = [0]
         outs = {}
         cases = {}
         for v in variants:
             out = torch.empty(M, N // 2 if epi else N, device="cuda", dtype=torch.bfloat16)
             outs[v] = out
 
-            def fn(v=v, out=out):  # "3t0" = variant 3 with the ping-pong tail overlap switched off
-                vi, tail = (int(v[:-2]), int(v[-1])) if isinstance(v, str) and "t" in v else (int(v), 1)
+            def fn(v=v, out=out):
+                if epi == 1 and v == 9:
+                    return
+                rot[0] = (rot[0] + 1) % len(Ws)
+                W = Ws[rot[0]]  # "3t0" = variant 3 with the ping-pong tail overlap switched off
+                # "7p3" = variant 7 under gemm_pipeline 3 (single-barrier loop)
+                if isinstance(v, str) and "p" in v:
+                    vi, pipe, tail = int(v.split("p")[0]), int(v.split("p")[1]), 0
+                else:
+                    vi, tail = (int(v[:-2]), int(v[-1])) if isinstance(v, str) and "t" in v else (int(v), 0)
+                    pipe = 0
+                set_option("gemm_pipeline", pipe)
                 set_option("gemm_pp_tail", tail)
                 ok(L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(out), M, N, K, epi, vi, stream()), "gemm")
             cases[v] = fn
@@ -73,9 +91,37 @@ def bench_gemm(rounds, variants, zeros=False):
             tot[v] += med
             print(f"gemm {name:4s} M{M} N{N} K{K} epi{epi} variant {v:>3}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s"
                   f"  (best {fl/mn/1e9:7.1f})  rel-vs-v{variants[0]} {err:.2e}", flush=True)
-    fl_layer = 2.0 * 8192 * 2304 * (6912 + 2304 + 12288 + 6144)
+    fl_layer = sum(2.0 * M * N * K for _, M, N, K, _ in shapes)
     for v in variants:
-        print(f"gemm per-layer total variant {v}: {tot[v]*1e3:8.1f} us  -> {fl_layer/tot[v]/1e9:7.1f} TF/s ; x24 = {tot[v]*24:.2f} ms/NFE")
+        print(f"gemm per-layer total variant {v}: {tot[v]*1e3:8.1f} us  -> {fl_layer/tot[v]/1e9:7.1f} TF/s")
+
+
+def bench_gemm_moe(rounds, variants, cold=0):
+    """BASELINE cfg 5 expert GEMMs: 512 tokens x top-2 over 4 experts = 8 segments of 256 expert-sorted rows (two per expert,
+    the worst case of the plan), each streaming its own expert's weights; dense GEMMs of the same shape for comparison."""
+    L = lib()
+    E, M, d, F_ = 4, 2048, 1536, 4096
+    g = torch.Generator(device="cuda").manual_seed(3)
+    te = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3], dtype=torch.int32, device="cuda")
+    for name, N, K, epi in (("w13", 2 * F_, d, 1), ("w2", d, F_, 0)):
+        A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        W0 = (torch.randn(E, N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        Ws = [W0] + [W0.clone() for _ in range(max(0, cold - 1))]
+        rot = [0]
+
+        def nextw():
+            rot[0] = (rot[0] + 1) % len(Ws)
+            return Ws[rot[0]]
+        out = torch.empty(M, N // 2 if epi else N, device="cuda", dtype=torch.bfloat16)
+        cases = {}
+        for v in variants:
+            cases[f"grouped v{v}"] = lambda v=v: ok(L.lt_op_gemm_grouped(P(A), P(nextw()), P(te), N * K, P(out), M, N, K, epi, v, stream()))
+            cases[f"dense   v{v}"] = lambda v=v: ok(L.lt_op_gemm_bf16(P(A), P(nextw()), P(None), 1, P(out), M, N, K, epi, v, stream()))
+        r = ab(cases, rounds)
+        fl = 2.0 * M * N * K
+        for k, (med, mn) in r.items():
+            print(f"moe gemm {name} M{M} N{N} K{K} epi{epi} {k}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s  "
+                  f"weights {E * N * K * 2 / med / 1e9 if k.startswith('grouped') else N * K * 2 / med / 1e9:6.2f} TB/s", flush=True)
 
 
 def bench_attn(rounds, variants):
@@ -157,12 +203,19 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--gemm-variants", type=str, default="1,2,3,4")
     ap.add_argument("--attn-variants", type=str, default="1,2")
+    ap.add_argument("--cold", type=int, default=0, help="gemm_small: rotate through this many weight copies (HBM-cold weights)")
     ap.add_argument("--gemm-zeros", action="store_true", help="all-zero operands (power / clock probe)")
     a = ap.parse_args()
     print("device:", torch.cuda.get_device_name(0), flush=True)
     if "gemm" in a.what:
-        bench_gemm(a.rounds, [v if "t" in v else int(v) for v in a.gemm_variants.split(",")], zeros=a.gemm_zeros)
-        set_option("gemm_pp_tail", 1)
+        bench_gemm(a.rounds, [v if ("t" in v or "p" in v) else int(v) for v in a.gemm_variants.split(",")], zeros=a.gemm_zeros)
+        set_option("gemm_pp_tail", 0)
+        set_option("gemm_pipeline", 0)
+    if "gemm_small" in a.what:
+        bench_gemm(a.rounds, [v if ("t" in v or "p" in v) else int(v) for v in a.gemm_variants.split(",")], shapes=SHAPES_CFG1,
+                   cold=a.cold)
+    if "gemm_moe" in a.what:
+        bench_gemm_moe(a.rounds, [int(v) for v in a.gemm_variants.split(",")], cold=a.cold)
     if "attn" in a.what:
         bench_attn(a.rounds, [int(v) for v in a.attn_variants.split(",")])
     if "elem" in a.what:

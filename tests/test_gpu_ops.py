@@ -45,7 +45,7 @@ def test_gemm_plain(M, N, K):
     assert max_abs(out, ref) < 0.04 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 2304), (300, 576, 128), (1024, 6912, 2304), (256, 288, 64), (257, 296, 192),
                                    (512, 512, 6144)])
 def test_gemm_tile_variants(variant, M, N, K):
@@ -61,7 +61,7 @@ def test_gemm_tile_variants(variant, M, N, K):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_identity_asymmetric(variant):
     """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
     K, N = 320, 576
@@ -101,6 +101,36 @@ def test_gemm_swiglu(M, F_, K, pipeline):
     b = r16(A.float() @ w3.float().t())
     ref = r16(r16(F.silu(a)) * b)
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3, 7])
+@pytest.mark.parametrize("epilogue", [0, 1])
+def test_gemm_grouped_expert_segments(variant, epilogue):
+    """grouped (MoE) mode: every 256-row segment of the expert-sorted rows multiplies with ITS expert's weight
+    (Next-DiT-MoE/models/models2.py:470-476 per-expert loop); padding segments (-1) must leave their output rows untouched."""
+    E, K, N = 4, 192, 384
+    te = [2, 0, -1, 3, 3, 1]
+    M = 256 * len(te)
+    g = torch.Generator().manual_seed(17 + variant + epilogue)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(E, N, K, generator=g) / math.sqrt(K))
+    tile_expert = torch.tensor(te, dtype=torch.int32, device="cuda")
+    No = N // 2 if epilogue else N
+    out = torch.full((M, No), 3.0, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_gemm_grouped(P(A), P(W), P(tile_expert), N * K, P(out), M, N, K, epilogue, variant, stream()), "grouped")
+    torch.cuda.synchronize()
+    for t, ex in enumerate(te):
+        rows = slice(256 * t, 256 * t + 256)
+        if ex < 0:
+            assert torch.all(out[rows] == 3.0), "padding segment was written"
+            continue
+        y = A[rows].float() @ W[ex].float().t()
+        if epilogue:  # packed layout: 32-row groups alternate w1 / w3 (lt_op_pack_w13)
+            y = y.view(256, N // 64, 2, 32)
+            ref = r16(r16(F.silu(r16(y[:, :, 0]))) * r16(y[:, :, 1])).reshape(256, No)
+        else:
+            ref = y
+        assert rel_l2(out[rows], ref) < 6e-3, (t, ex, rel_l2(out[rows], ref))
 
 
 def test_rmsnorm_mod():
