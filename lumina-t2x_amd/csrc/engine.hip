@@ -807,7 +807,10 @@ extern "C" int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, vo
     for (int i = 0; i + 1 < n_grid; ++i) {
         void* y0 = e->ys[cur];
         void* y1 = e->ys[cur ^ 1];
-        const float dt = dts[i];
+        // torchdiffeq multiplies the 0-dim DEVICE tensor dt = t1 - t0 (fp32) with the bf16 state / slopes; PyTorch's type
+        // promotion keeps bf16 and casts the 0-dim operand to it first, so with a bf16 state every `dt * k` of the reference
+        // sees bf16(dt) (0.5 dt is exact after that).  The stage TIMES above stay fp32 (t0 + dt / 2 is fp32 arithmetic).
+        const float dt = bf ? bf16_round_host(dts[i]) : dts[i];
         const int c0 = i * stages;
         if (method == LT_ODE_EULER) {
             if (model(y0, c0, e->kbuf[0])) return 1;

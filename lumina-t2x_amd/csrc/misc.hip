@@ -228,7 +228,8 @@ __global__ void unpatchify_cfg_kernel(const u16* __restrict__ rows, int ld, void
 
 // torchdiffeq fixed-grid solver arithmetic on the ODE state (euler / midpoint / rk4 "3/8 rule",
 // torchdiffeq rk_common.rk4_alt_step_func).  With a bf16 state every tensor op of the Python expression
-// rounds to bf16 (a 0-dim fp32 dt times a bf16 tensor stays bf16 - SURVEY.md 8c); R() marks those points.
+// rounds to bf16 (a 0-dim fp32 dt times a bf16 tensor stays bf16 AND sees dt cast to bf16 first - the caller passes
+// bf16(dt) for a bf16 state); R() marks those points.
 //   mode 0: y0 + R(dt k1)                               euler step, midpoint half step / full step
 //   mode 1: y0 + R(R(dt k1) / 3)                        rk4 stage-2 input
 //   mode 2: y0 + R(dt R(k2 - R(k1 / 3)))                rk4 stage-3 input

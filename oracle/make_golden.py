@@ -162,6 +162,25 @@ def family_case(name, cfg, latent_hw, seed_w, seed_x, text_len=16, uncond_len=8)
     print(f"{name}.npz:", {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 0})
 
 
+def mini_ode_kats():
+    """time grids of the mini package's flat ODE class incl. the img2img `strength` cut
+    (lumina_next_t2i_mini/transport.py:57-83); the module is loaded by path (its package has no __init__ we could import)"""
+    import importlib.util
+    path = os.path.join(R.REFERENCE_ROOT, "lumina_next_t2i_mini", "transport.py")
+    spec = importlib.util.spec_from_file_location("ref_mini_transport", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)  # needs only the torchdiffeq stub (oracle/stubs) for `from torchdiffeq import odeint`
+    d = {}
+    cases = {"n30_s4": dict(num_steps=30, time_shifting_factor=4), "n30_s4_str06": dict(num_steps=30, time_shifting_factor=4, strength=0.6),
+             "n10_str03": dict(num_steps=10, strength=0.3), "n17_s6_str085": dict(num_steps=17, time_shifting_factor=6.0, strength=0.85),
+             "n5": dict(num_steps=5)}
+    for k, kw in cases.items():
+        d[k] = _np(mod.ODE(sampler_type="euler", **kw).t)
+    d["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(OUT, "mini_ode.npz"), **d)
+    print("mini_ode.npz:", {k: v.shape for k, v in d.items() if v.ndim > 0})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -173,6 +192,7 @@ def main():
     family_case("imagenet_tiny", synth.TINY_IMAGENET, (16, 16), 7, 8)
     family_case("moe_tiny", synth.TINY_MOE, (16, 16), 9, 10)
     family_case("flag_tiny", synth.TINY_FLAG, (16, 24), 11, 12)
+    mini_ode_kats()
 
 
 if __name__ == "__main__":

@@ -17,6 +17,9 @@ def odeint(func, y0, t, *, method="euler", atol=None, rtol=None, t_cast=True):
     def f(tt, y):
         return func(tt.to(y.dtype) if t_cast else tt, y)
 
+    # torchdiffeq coerces t to y0's device; dt = t1 - t0 is then a 0-dim tensor on that device, and `dt * k` with a bf16 k
+    # rounds dt to bf16 first (type promotion keeps bf16; only a CPU scalar next to a CUDA tensor would stay fp32)
+    t = t.to(y0.device)
     sol = torch.empty((len(t),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
     sol[0] = y0
     y = y0
@@ -54,7 +57,7 @@ def sample_ode(model_fn, z, num_steps, method="euler", time_shifting_factor=None
     t = time_grid(num_steps, time_shifting_factor)
 
     def _fn(tt, x):
-        tvec = torch.ones(x.size(0)) * tt
+        tvec = torch.ones(x.size(0)).to(x.device) * tt  # integrators.py:108
         out = model_fn(x, tvec, **model_kwargs)
         assert out.shape == x.shape
         return out

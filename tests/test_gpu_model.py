@@ -118,6 +118,30 @@ def test_engine_ode_loop_equals_stepwise_torch(golden_dir, method):
     assert torch.equal(fast, slow), max_abs(fast, slow)
 
 
+def test_mini_ode_img2img_on_engine_equals_generic_stepping(golden_dir):
+    """lumina_next_t2i_mini ODE class with the img2img `strength` cut (transport.py:79-80, sample_img2img.py:146-216): the
+    engine fast path (one lt_sample_ode call over the cut grid) == the same grid stepped through the model callable."""
+    from lumina_t2x_amd.transport.integrators import fixed_grid_odeint
+    from lumina_t2x_amd.transport.mini import ODE
+
+    g, cfg = _golden(golden_dir, "nextdit_tiny")
+    model = _model(cfg, int(g["seed_w"]))
+    z, _, cap, mask = _inputs(g)
+    kw = dict(cap_feats=cap, cap_mask=mask, cfg_scale=4.0, proportional_attn=True, base_seqlen=16, scale_factor=1.0,
+              scale_watershed=1.0)
+    o = ODE(9, "midpoint", 4, strength=0.6)
+    assert len(o.t) == 9 - int(9 * (1 - 0.6))
+    fast = o.sample(z, model.forward_with_cfg, **kw)
+    assert fast.shape == (len(o.t),) + tuple(z.shape)
+    assert model._engine.last_nfe() == 2 * (len(o.t) - 1)
+
+    def fn(t, y):  # bf16 state: torchdiffeq hands the model t rounded to the state dtype
+        return model.forward_with_cfg(y, torch.ones(y.size(0), device=y.device) * t.to(y.dtype).float(), **kw)
+
+    slow = fixed_grid_odeint(fn, z, o.t.cuda(), method="midpoint")
+    assert torch.equal(fast, slow), max_abs(fast, slow)
+
+
 @pytest.mark.parametrize("method", ["euler", "midpoint"])
 def test_engine_trajectory_vs_reference_golden(golden_dir, method):
     g, cfg = _golden(golden_dir, "nextdit_tiny")
@@ -209,3 +233,58 @@ def test_full_2b_24_layers_vs_oracle():
     print(f"2B/24L: engine vs fp32 {e_all:.3e} (ch3 {e_c3:.3e}); bf16-choreography oracle vs fp32 {f_all:.3e} (ch3 {f_c3:.3e}); "
           f"engine vs bf16 oracle {e_floor:.3e}")
     assert e_all < 1.5 * f_all and e_c3 < 1.5 * f_c3, (e_all, f_all, e_c3, f_c3)
+
+
+def test_sample_driver_end_to_end_with_injected_encoder(golden_dir, tmp_path):
+    """lumina_t2x_amd.sample.run (reference sample.py:85-265 flow) on the engine: checkpoint directory -> model ->
+    per-caption CFG sampling -> output files.  The third-party stages (text encoder, VAE) are injected; the latent the
+    driver writes must equal a direct Sampler call with the same seed and kwargs."""
+    import argparse
+
+    from safetensors.torch import save_file
+
+    from lumina_t2x_amd import sample as S
+
+    g, cfg = _golden(golden_dir, "nextdit_tiny")
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ck / "consolidated_ema.00-of-01.safetensors"))
+    torch.save(argparse.Namespace(model="NextDiT_tiny_test", qk_norm=cfg.qk_norm, image_size=256, vae="sdxl"), str(ck / "model_args.pth"))
+    models.__dict__["NextDiT_tiny_test"] = lambda **kw: models.NextDiT(**{**cfg.ctor_kwargs(), **kw})
+    (tmp_path / "prompts.txt").write_text("a red cube\n\na blue sphere\n")
+    gen = torch.Generator().manual_seed(3)
+    table = {c: torch.randn(16, cfg.cap_feat_dim, generator=gen) for c in ("a red cube", "a blue sphere", "")}
+
+    def encode(caps):
+        feats = torch.stack([table[c] for c in caps]).to("cuda", torch.bfloat16)
+        mask = torch.ones(len(caps), 16, dtype=torch.int64, device="cuda")
+        mask[-1, 8:] = 0
+        return feats, mask
+
+    decoded = []
+
+    def decode(lat):
+        decoded.append(lat.clone())
+        return torch.sigmoid(lat[:, :3].float())
+
+    out = tmp_path / "out"
+    args = S.build_parser().parse_args(["--ckpt", str(ck), "--caption_path", str(tmp_path / "prompts.txt"), "--resolution",
+                                        "256:128x128", "--num_sampling_steps", "4", "--sampling-method", "midpoint",
+                                        "--time_shifting_factor", "4", "--seed", "11", "--image_save_path", str(out)])
+    try:
+        info = S.run(args, encode_fn=encode, cap_feat_dim=cfg.cap_feat_dim, decode_fn=decode)
+    finally:
+        del models.__dict__["NextDiT_tiny_test"]
+    assert [i["caption"] for i in info] == ["a red cube", "a blue sphere"] and len(decoded) == 2
+    assert all(os.path.exists(i["image_url"]) and i["image_url"].endswith("_128x128.png") for i in info)
+    assert json.load(open(out / "data.json")) == info
+    # the same sample through the public API
+    model = _model(cfg, int(g["seed_w"]))
+    torch.manual_seed(11)
+    z = torch.randn([1, 4, 16, 16], device="cuda").to(torch.bfloat16).repeat(2, 1, 1, 1)
+    feats, mask = encode(["a red cube", ""])
+    fn = Sampler(create_transport()).sample_ode(sampling_method="midpoint", num_steps=4, time_shifting_factor=4.0)
+    want = fn(z, model.forward_with_cfg, cap_feats=feats, cap_mask=mask, cfg_scale=4.0, proportional_attn=True,
+              base_seqlen=256, scale_factor=1.0, scale_watershed=1.0)[-1][:1]
+    assert torch.equal(decoded[0], want / 0.13025)

@@ -175,3 +175,64 @@ def test_sampler_dopri5_through_transport_api():
     assert traj.shape == (5, 2, 4, 4, 4)
     assert abs(float(traj[-1].flatten()[0]) - 0.36787944) < 1e-5  # exp(-1)
     assert len(calls) >= 8
+
+
+def test_mini_ode_grid_and_strength_match_reference(golden_dir):
+    """lumina_next_t2i_mini/transport.py:57-83 incl. the img2img `strength` cut - grids generated by the reference class."""
+    from lumina_t2x_amd.transport.mini import ODE
+
+    g = np.load(os.path.join(golden_dir, "mini_ode.npz"))
+    cases = json.loads(str(g["cases"]))
+    assert len(cases) >= 5
+    for k, kw in cases.items():
+        np.testing.assert_array_equal(ODE(sampler_type="euler", **kw).t.numpy(), g[k])
+    with pytest.raises(NotImplementedError):
+        ODE(10, use_sd3=True)
+
+
+def test_mini_ode_generic_callable_img2img():
+    from lumina_t2x_amd.transport.mini import ODE
+
+    o = ODE(11, "euler", strength=0.5)  # keeps grid points 5..10 -> 5 Euler steps from t = 0.5
+    assert len(o.t) == 6 and abs(float(o.t[0]) - 0.5) < 1e-6
+    seen = []
+
+    def model(x, t, **kw):
+        seen.append((float(t[0]), tuple(t.shape), kw["tag"]))
+        return torch.ones_like(x)
+
+    out = o.sample(torch.zeros(2, 4, 2, 2), model, tag="k")
+    assert out.shape == (6, 2, 4, 2, 2) and len(seen) == 5 and seen[0][1] == (2,) and seen[0][2] == "k"
+    assert abs(float(out[-1].flatten()[0]) - 0.5) < 1e-6  # integral of 1 over [0.5, 1]
+
+
+def test_sample_driver_cli_and_io(tmp_path):
+    """lumina_t2x_amd.sample: argument names / defaults of the reference's sample.py (:267-330), checkpoint file naming
+    (:134-141), resolution spec (:193-199) and the png writer."""
+    import argparse
+    import struct
+    import zlib
+
+    from safetensors.torch import save_file
+
+    from lumina_t2x_amd import sample as S
+
+    a = S.build_parser().parse_args(["--ckpt", "x", "--resolution", "1024:1024x1024", "2048:2048x1024"])
+    assert (a.cfg_scale, a.num_sampling_steps, a.seed, a.precision, a.ema, a.time_shifting_factor) == (4.0, 250, 0, "bf16", True, 1.0)
+    assert (a.sampling_method, a.path_type, a.prediction, a.scaling_method, a.scaling_watershed) == ("euler", "Linear", "velocity", "Time-aware", 0.3)
+    assert a.proportional_attn is True and a.caption_path == "prompts.txt" and a.image_save_path == "samples"
+    assert S.parse_resolution(a.resolution[1]) == (2048, 2048, 1024)
+    sd = {"w": torch.arange(6, dtype=torch.float32).reshape(2, 3)}
+    save_file(sd, str(tmp_path / "consolidated_ema.00-of-01.safetensors"))
+    torch.save(sd, str(tmp_path / "consolidated.00-of-01.pth"))
+    torch.save(argparse.Namespace(model="NextDiT_2B_patch2", qk_norm=True, image_size=1024, vae="sdxl"), str(tmp_path / "model_args.pth"))
+    assert torch.equal(S.load_checkpoint(str(tmp_path), True)["w"], sd["w"])
+    assert torch.equal(S.load_checkpoint(str(tmp_path), False)["w"], sd["w"])
+    assert S.load_train_args(str(tmp_path)).model == "NextDiT_2B_patch2"
+    with pytest.raises(FileNotFoundError):
+        S.load_checkpoint(str(tmp_path / "nope"), True)
+    img = torch.rand(3, 5, 7)
+    S.save_png(img, str(tmp_path / "a.png"))
+    raw = (tmp_path / "a.png").read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", raw[16:24]) == (7, 5)
+    assert zlib.crc32(raw[12:29]) & 0xFFFFFFFF == struct.unpack(">I", raw[29:33])[0]  # IHDR crc
