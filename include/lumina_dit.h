@@ -114,6 +114,13 @@ int lt_prepare_labels(lt_engine* e, const int32_t* labels_dev, int32_t B, void* 
 /* NextDiT.forward (model.py:836-864): x [B,C,H,W] -> out [B,C,H,W] (first in_channels kept). */
 int lt_forward(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev,
                const lt_step_args* a, void* stream);
+/* NextDiT.forward with a LIST of differently sized samples (patchify_and_embed list branch, model.py:789-834; unpatchify
+ * :757-768): x_ptrs / out_ptrs are HOST arrays of a->batch device pointers, sample b is [in_channels, H_b, W_b] with
+ * (H_b, W_b) = hw_host[2b], hw_host[2b+1] (a->latent_h / latent_w are ignored).  Sequences are padded to the longest one with
+ * pad_token; padded keys are masked; each output has its own sample's shape (sigma half dropped).  Text-conditional
+ * Next-DiT, plain forward only (the reference's forward_with_cfg takes tensors only). */
+int lt_forward_packed(lt_engine* e, const void* const* x_ptrs, const int32_t* hw_host, const float* t_dev,
+                      void* const* out_ptrs, const lt_step_args* a, void* stream);
 /* NextDiT.forward_with_cfg (model.py:866-913): duplicates the first half, CFG on cfg_channels. */
 int lt_forward_cfg(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev,
                    const lt_step_args* a, void* stream);

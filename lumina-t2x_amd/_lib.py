@@ -67,6 +67,7 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_prepare_prompt": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "lt_prepare_labels": (_i32, [_vp, _vp, _i32, _vp]),
     "lt_forward": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(LtStepArgs), _vp]),
+    "lt_forward_packed": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_i32), _vp, C.POINTER(_vp), C.POINTER(LtStepArgs), _vp]),
     "lt_forward_cfg": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(LtStepArgs), _vp]),
     "lt_sample_ode": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(_f32), _i32, _i32, _i32, _i32, C.POINTER(LtStepArgs), _vp]),
     "lt_last_nfe": (_i64, [_vp]),

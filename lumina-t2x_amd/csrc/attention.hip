@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;
 
-    const int ntile = (p.Nk + 63) / 64;
+    const int Nk_eff = p.nk_batch ? p.nk_batch[b] : p.Nk;  // packed batches: this sample's valid keys (layout stride stays p.Nk)
+    const int ntile = (Nk_eff + 63) / 64;
     const float* bias = p.bias ? p.bias + (size_t)b * p.Nkpad : nullptr;
     stage(0, 0);
     for (int t = 0; t < ntile; ++t) {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             }
         }
         float mx = -INFINITY;
-        const bool tail = (k0 + 64 > p.Nk);
+        const bool tail = (k0 + 64 > Nk_eff);
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2) {
 #pragma unroll
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = sc[kt2][4 * q4 + j] * sl2 + bv[j];
-                    if (tail && kbase + j >= p.Nk) v = -INFINITY;
+                    if (tail && kbase + j >= Nk_eff) v = -INFINITY;
                     sc[kt2][4 * q4 + j] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel_v2(AttnArgs p) {
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -1.0e30f;
 
-    const int ntile = (p.Nk + 63) / 64;
+    const int Nk_eff = p.nk_batch ? p.nk_batch[b] : p.Nk;
+    const int ntile = (Nk_eff + 63) / 64;
     const float* bias = p.bias ? p.bias + (size_t)b * p.Nkpad : nullptr;
     stage(0, 0);
     for (int t = 0; t < ntile; ++t) {
@@ -364,13 +366,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel_v2(AttnArgs p) {
                     }
                 }
         } else {
-            if (k0 + 64 > p.Nk) {  // tail tile: keys past Nk
+            if (k0 + 64 > Nk_eff) {  // tail tile: keys past Nk
 #pragma unroll
                 for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = k0 + 32 * kt2 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (key >= p.Nk) sc[kt2][r] = -INFINITY;
+                        if (key >= Nk_eff) sc[kt2][r] = -INFINITY;
                     }
             }
 #pragma unroll
@@ -576,7 +578,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     auto dma_a = [&](int tk) __attribute__((always_inline)) { dma_a_from(0, tk); };
     auto dma_b = [&](int tk, int tv) __attribute__((always_inline)) { dma_b_from(0, tk, tv); };
     auto dma_c = [&](int tv) __attribute__((always_inline)) { dma_c_from(0, tv); };
-    const int ntile = (p.Nk + 63) / 64;
+    const int Nk_eff = p.nk_batch ? p.nk_batch[b] : p.Nk;
+    const int ntile = (Nk_eff + 63) / 64;
     // prologue: K(0); K(1), V(0); K(2), V(1)  (the batches X(-3), X(-2), X(-1) would have issued; tile indices past
     // the end read zeros through the descriptor bounds and are never consumed)
     dma_a(0);
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
         for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(pa[g]));
 #endif
     };
-    auto phase_y = [&](int t) __attribute__((always_inline)) { phase_y_gen(t, t == ntile - 1 && (p.Nk & 63), p.Nk, nullptr); };
+    auto phase_y = [&](int t) __attribute__((always_inline)) { phase_y_gen(t, t == ntile - 1 && (Nk_eff & 63), Nk_eff, nullptr); };
 
     unsigned long long tr[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     if constexpr (TRACE) t0 = __builtin_amdgcn_s_memtime();

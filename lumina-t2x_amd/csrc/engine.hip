@@ -126,6 +126,8 @@ struct lt_engine {
     void *ys[2] = {nullptr, nullptr}, *ymid = nullptr, *kbuf[4] = {nullptr, nullptr, nullptr, nullptr};
     float* t_dev = nullptr;
     int t_cap = 0;
+    int* pk_dev = nullptr;     // packed batches: [0,64) token counts, [64,128) grid widths
+    int pk_host[128] = {0};
     std::vector<float> t_host;
     long long last_nfe = 0;
     // profiling
@@ -359,17 +361,44 @@ int moe_ffn(lt_engine* e, LayerW& w, int branch, int M, int N, int B, hipStream_
 //   NextDiT.forward / forward_with_cfg   lumina_next_t2i/models/model.py:836-913
 //   DiT_Llama (ImageNet)                 Next-DiT-ImageNet/models/models.py:920-974
 //   DiT_Llama (Flag-DiT)                 lumina_t2i/models/model.py:829-922
+//
+// Packed variable-resolution batch (NextDiT.patchify_and_embed list branch, model.py:789-834): sample b is its own
+// [C, H_b, W_b] tensor; sequences are padded to the longest one with `pad_token`, padded positions rotate like the sample's
+// last token, are masked as KEYS (x_mask, :407-415) and dropped again by unpatchify (:757-768).  Only the plain forward of
+// the text-conditional Next-DiT has this path in the reference.
+struct PackedDesc {
+    const void* const* x_ptrs;  // [B] device pointers
+    void* const* out_ptrs;      // [B] device pointers, each [in_channels, H_b, W_b]
+    const int32_t* hw;          // [B][2] latent (H_b, W_b), host
+};
+
 int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, const lt_step_args* a, int use_cfg,
-                hipStream_t s) {
+                hipStream_t s, const PackedDesc* pk = nullptr) {
     const lt_config& c = e->cfg;
     const VariantDesc& v = e->v;
     const int B = a->batch, p = c.patch_size;
+    if (pk) {
+        LT_REQUIRE(c.variant == LT_VARIANT_NEXT_T2I && !use_cfg, "packed batches: plain forward of the text-conditional Next-DiT only");
+        LT_REQUIRE(B >= 1 && B <= c.max_batch && B <= 64, "packed batch of %d exceeds max_batch %d (or 64)", B, c.max_batch);
+    }
     LT_REQUIRE(B >= 1 && B <= c.max_batch, "batch %d exceeds max_batch %d", B, c.max_batch);
     LT_REQUIRE(!use_cfg || B % 2 == 0, "forward_with_cfg needs an even batch (cond+uncond)");
     LT_REQUIRE(a->latent_h % p == 0 && a->latent_w % p == 0, "latent %dx%d not divisible by patch", a->latent_h, a->latent_w);
-    const int Hp = a->latent_h / p, Wp = a->latent_w / p;
+    int Hp = a->latent_h / p, Wp = a->latent_w / p;
     const int Wrow = v.eol ? Wp + 1 : Wp;  // tokens per latent row (Flag-DiT appends one eol token, model.py:779-786)
-    const int N = Hp * Wrow, M = B * N;
+    int N = Hp * Wrow;
+    int pk_ntok[64], pk_gw[64];
+    if (pk) {  // N = the longest sequence; a->latent_h / latent_w are ignored
+        N = 0; Hp = 0; Wp = 0;
+        for (int b = 0; b < B; ++b) {
+            const int hb = pk->hw[2 * b], wb = pk->hw[2 * b + 1];
+            LT_REQUIRE(hb > 0 && wb > 0 && hb % p == 0 && wb % p == 0, "packed sample %d: latent %dx%d not divisible by patch", b, hb, wb);
+            pk_ntok[b] = (hb / p) * (wb / p);
+            pk_gw[b] = wb / p;
+            N = std::max(N, pk_ntok[b]); Hp = std::max(Hp, hb / p); Wp = std::max(Wp, wb / p);
+        }
+    }
+    const int M = B * N;
     LT_REQUIRE(N <= c.max_tokens, "%d latent tokens exceed max_tokens %d", N, c.max_tokens);
     if (v.rope_1d) LT_REQUIRE(N <= e->rope_len, "sequence of %d tokens exceeds the 1-D RoPE table (%d)", N, e->rope_len);
     else LT_REQUIRE(Hp <= e->rope_len && Wp <= e->rope_len, "latent grid exceeds the RoPE table (%d)", e->rope_len);
@@ -392,11 +421,27 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
     }
 
     // patchify + x_embedder (model.py:777-779) [+ eol token per row]
-    {
+    const int *ntok_dev = nullptr, *gw_dev = nullptr;
+    if (!pk) {
         ProfScope ps(e, 2, 0, s);
         if (launch_patchify(x_in, a->io_dtype, e->patches, B, c.in_channels, a->latent_h, a->latent_w, p, e->kpad, use_cfg, Wrow, s)) return 1;
+    } else {
+        ProfScope ps(e, 2, 0, s);
+        for (int b = 0; b < B; ++b)
+            if (launch_patchify(pk->x_ptrs[b], a->io_dtype, e->patches + (size_t)b * N * e->kpad, 1, c.in_channels, pk->hw[2 * b],
+                                pk->hw[2 * b + 1], p, e->kpad, 0, 0, s)) return 1;
+        // per-sample token count / grid width for the rotary positions and the key mask
+        memcpy(e->pk_host, pk_ntok, B * sizeof(int));
+        memcpy(e->pk_host + 64, pk_gw, B * sizeof(int));
+        LT_CHECK_HIP(hipMemcpyAsync(e->pk_dev, e->pk_host, 128 * sizeof(int), hipMemcpyHostToDevice, s));
+        ntok_dev = e->pk_dev; gw_dev = e->pk_dev + 64;
     }
     if (gemm(e, e->patches, e->kpad, e->xemb_w, e->kpad, e->x, d, M, d, e->kpad, e->xemb_b, 0, s)) return 1;
+    if (pk) {  // padded positions hold the learned pad_token, not an embedded patch (model.py:811-817)
+        ProfScope ps(e, 2, 0, s);
+        for (int b = 0; b < B; ++b)
+            if (pk_ntok[b] < N && launch_fill_rows_bf16(e->x + ((size_t)b * N + pk_ntok[b]) * d, e->pad_token, N - pk_ntok[b], d, s)) return 1;
+    }
     if (v.eol) {
         ProfScope ps(e, 2, 0, s);
         if (launch_eol_fill(e->x, e->eol_token, B * Hp, Wp, d, s)) return 1;
@@ -437,6 +482,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             QkPostArgs qa;
             qa.src = e->qkv; qa.ld_src = e->qkvn; qa.B = B; qa.N = N; qa.hd = hd; qa.rope_mode = v.rope_1d ? 2 : 1;
             qa.cs = e->rope; qa.t = t_dev; qa.grid_w = Wp; qa.cs_len = e->rope_len; qa.ln_eps = 1e-5f;
+            qa.n_tok_b = ntok_dev; qa.grid_w_b = gw_dev;
             qa.watershed = c.variant == LT_VARIANT_NEXT_T2I ? a->scale_watershed : 0.f;  // other families: one table (branch 1)
             QkvPostArgs pa;
             qa.col0 = 0; qa.heads = H; qa.dst = e->q;
@@ -460,13 +506,14 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         at.q = e->q; at.k = e->k; at.vt = e->vt; at.bias = nullptr; at.out = e->attn; at.gate = nullptr; at.accumulate = 0;
         at.B = B; at.H = H; at.Hkv = Hkv; at.N = N; at.Nk = N; at.Nkpad = Npad; at.hd = hd; at.scale = sm_scale;
         at.k_prescaled = 1;
+        at.nk_batch = ntok_dev;
         const bool fuse_text = v.text && attention_fuses_text(hd);
         if (fuse_text) {  // zero-init gated text cross-attention (model.py:420-434) inside the same launch
             at.tk = w.ky; at.tvt = w.vty; at.tbias = e->txt_bias; at.tgate = w.gate; at.Tk = e->prompt_T; at.Tkpad = e->prompt_Tpad;
         }
         if (attention(e, at, s)) return 1;
         if (v.text && !fuse_text) {
-            at.k = w.ky; at.vt = w.vty; at.bias = e->txt_bias; at.gate = w.gate; at.accumulate = 1;
+            at.k = w.ky; at.vt = w.vty; at.bias = e->txt_bias; at.gate = w.gate; at.accumulate = 1; at.nk_batch = nullptr;
             at.Nk = e->prompt_T; at.Nkpad = e->prompt_Tpad; at.scale = (float)(1.0 / std::sqrt((double)hd));
             if (attention(e, at, s)) return 1;
         }
@@ -523,8 +570,14 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
     {
         ProfScope ps(e, 2, 0, s);
         const int cfg_ch = a->cfg_channels > 0 ? a->cfg_channels : 3;
-        if (launch_unpatchify_cfg(e->frows, e->nfinal, out, a->io_dtype, B, c.in_channels, c.out_channels, a->latent_h,
-                                  a->latent_w, p, use_cfg, a->cfg_scale, cfg_ch, Wrow, s)) return 1;
+        if (!pk) {
+            if (launch_unpatchify_cfg(e->frows, e->nfinal, out, a->io_dtype, B, c.in_channels, c.out_channels, a->latent_h,
+                                      a->latent_w, p, use_cfg, a->cfg_scale, cfg_ch, Wrow, s)) return 1;
+        } else {
+            for (int b = 0; b < B; ++b)  // x[i][:L] -> [C, H_b, W_b], sigma half dropped (model.py:757-768, :859-864)
+                if (launch_unpatchify_cfg(e->frows + (size_t)b * N * e->nfinal, e->nfinal, pk->out_ptrs[b], a->io_dtype, 1, c.in_channels,
+                                          c.out_channels, pk->hw[2 * b], pk->hw[2 * b + 1], p, 0, 1.0f, cfg_ch, 0, s)) return 1;
+        }
     }
     return 0;
 }
@@ -668,6 +721,7 @@ extern "C" void lt_destroy(lt_engine* e) {
     if (!e) return;
     for (auto& b : e->allocs) (void)hipFree(b.p);
     if (e->t_dev) (void)hipFree(e->t_dev);
+    if (e->pk_dev) (void)hipFree(e->pk_dev);
     for (int k = 0; k < 3; ++k)
         for (auto& pr : e->prof[k].ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete e;
@@ -751,6 +805,15 @@ extern "C" int lt_prepare_labels(lt_engine* e, const int32_t* labels_dev, int32_
 extern "C" int lt_forward(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev, const lt_step_args* a, void* stream) {
     LT_REQUIRE(e && x_dev && t_dev && out_dev && a, "lt_forward: null argument");
     return run_forward(e, x_dev, t_dev, out_dev, a, 0, (hipStream_t)stream);
+}
+
+extern "C" int lt_forward_packed(lt_engine* e, const void* const* x_ptrs, const int32_t* hw_host, const float* t_dev,
+                                 void* const* out_ptrs, const lt_step_args* a, void* stream) {
+    LT_REQUIRE(e && x_ptrs && hw_host && t_dev && out_ptrs && a, "lt_forward_packed: null argument");
+    for (int b = 0; b < a->batch; ++b) LT_REQUIRE(x_ptrs[b] && out_ptrs[b], "lt_forward_packed: null sample pointer %d", b);
+    if (!e->pk_dev) LT_CHECK_HIP(hipMalloc((void**)&e->pk_dev, 128 * sizeof(int)));
+    PackedDesc pk{x_ptrs, out_ptrs, hw_host};
+    return run_forward(e, nullptr, t_dev, nullptr, a, 0, (hipStream_t)stream, &pk);
 }
 
 extern "C" int lt_forward_cfg(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev, const lt_step_args* a, void* stream) {

@@ -64,6 +64,10 @@ struct QkPostArgs {
     int rope_mode, grid_w, cs_len;  // cs_len: positions per branch table
     float ln_eps, watershed;
     float out_scale = 1.0f;  // multiplies the result before its single bf16 rounding (folds softmax scale * log2 e into K)
+    // packed variable-resolution batches (model.py:803-831): per-sample token count and latent-grid width (device arrays or
+    // null); padded positions n >= n_tok_b[b] rotate like the sample's LAST token (item_freqs_cis[-1:] expand, :822-827)
+    const int* n_tok_b = nullptr;
+    const int* grid_w_b = nullptr;
 };
 int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream);
 int launch_v_transpose(const u16* src, int ld_src, int col0, u16* dst, int B, int N, int Npad, int kv_heads,
@@ -99,6 +103,8 @@ struct AttnArgs {
     const u16* tgate = nullptr;   // [H] bf16
     int Tk = 0, Tkpad = 0;
     unsigned long long* trace = nullptr;  // diagnostics only (lt_op_attention_trace)
+    // packed variable-resolution batches (model.py:789-834): valid keys of sample b = nk_batch[b] <= Nk (device array, or null)
+    const int* nk_batch = nullptr;
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch

@@ -63,7 +63,9 @@ __device__ __forceinline__ void qk_norm_rope_row(const QkPostArgs& p, int row, i
     if (p.t) branch = (p.t[0] < p.watershed) ? 0 : 1;
     const int nfreq = (p.rope_mode == 1) ? (p.hd >> 2) : (p.hd >> 1);
     const float* cs = p.cs ? p.cs + (size_t)branch * p.cs_len * nfreq * 2 : nullptr;
-    const int gr = n / p.grid_w, gc = n - gr * p.grid_w;
+    const int n_rot = p.n_tok_b ? min(n, p.n_tok_b[b] - 1) : n;
+    const int gw = p.grid_w_b ? p.grid_w_b[b] : p.grid_w;
+    const int gr = n_rot / gw, gc = n_rot - gr * gw;
     const f32x2 mv = {mean, mean}, rv = {rstd, rstd}, osc = {p.out_scale, p.out_scale};
 
 #pragma unroll
@@ -84,7 +86,7 @@ __device__ __forceinline__ void qk_norm_rope_row(const QkPostArgs& p, int row, i
                     const int pr = 4 * ci + j;  // complex slot inside the head
                     int pos, fi;
                     if (p.rope_mode == 1) { fi = pr >> 1; pos = (pr & 1) ? gc : gr; }
-                    else { fi = pr; pos = n; }
+                    else { fi = pr; pos = n_rot; }
                     const float2 t = *(const float2*)(cs + ((size_t)pos * nfreq + fi) * 2);
                     y = f32x2{y[0] * t.x - y[1] * t.y, y[0] * t.y + y[1] * t.x};
                 }

@@ -154,6 +154,29 @@ class DiTEngine:
         _lib.check(rc, "lt_forward_cfg" if use_cfg else "lt_forward")
         return out
 
+    def forward_packed(self, xs, t: torch.Tensor, *, scale_factor: float = 1.0, scale_watershed: float = 0.0,
+                       base_seqlen: Optional[int] = None, proportional_attn: bool = False):
+        """NextDiT.forward on a LIST of [C, H_b, W_b] latents (reference model.py:789-834): one padded batch on the engine,
+        one output tensor per sample (lt_forward_packed)."""
+        xs = [x.contiguous() for x in xs]
+        for x in xs:
+            _require_gpu(x, "x")
+            if x.dim() != 3 or x.dtype != xs[0].dtype or x.device != xs[0].device:
+                raise LuminaLibError("packed forward: every sample must be a [C, H, W] tensor of one dtype on one device")
+        B = len(xs)
+        t32 = t.to(device=xs[0].device, dtype=torch.float32).contiguous()
+        outs = [torch.empty((self.in_channels,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) for x in xs]
+        a = self._step_args(xs[0].unsqueeze(0), 1.0, scale_factor, scale_watershed, base_seqlen, proportional_attn)
+        a.batch, a.latent_h, a.latent_w = B, 0, 0
+        xp = (C.c_void_p * B)(*[x.data_ptr() for x in xs])
+        op = (C.c_void_p * B)(*[o.data_ptr() for o in outs])
+        hw = (C.c_int32 * (2 * B))(*[v for x in xs for v in x.shape[1:]])
+        with torch.cuda.device(self.device):
+            rc = self.lib.lt_forward_packed(self.handle, xp, hw, C.c_void_p(t32.data_ptr()), op, C.byref(a),
+                                            C.c_void_p(_stream_ptr(self.device)))
+        _lib.check(rc, "lt_forward_packed")
+        return outs
+
     # ---- whole trajectory -------------------------------------------------------------------------
     def sample_ode(self, z: torch.Tensor, tgrid: torch.Tensor, method: str, *, use_cfg: bool, cfg_scale: float = 1.0,
                    scale_factor: float = 1.0, scale_watershed: float = 1.0, base_seqlen: Optional[int] = None,

@@ -154,11 +154,16 @@ class NextDiT(nn.Module):
 
     def engine(self, x: torch.Tensor, text_len: int) -> DiTEngine:
         """Create / resize the engine for this call's shapes and make sure it holds the current weights."""
-        if not x.is_cuda:
+        if not (x if isinstance(x, torch.Tensor) else x[0]).is_cuda:
             raise _lib.LuminaLibError(
                 "NextDiT.forward needs tensors on a ROCm device: the MI355X engine has no CPU fallback")
-        B, _, H, W = x.shape
-        n_tok = (H // self.patch_size) * (W // self.patch_size)
+        if isinstance(x, torch.Tensor):
+            B, _, H, W = x.shape
+            n_tok = (H // self.patch_size) * (W // self.patch_size)
+        else:  # list of [C, H_b, W_b] samples: limits of the padded batch
+            B = len(x)
+            n_tok = max((xi.shape[1] // self.patch_size) * (xi.shape[2] // self.patch_size) for xi in x)
+            x = x[0]
         lim = self.engine_limits
         need = EngineLimits(max(lim.max_batch, B), max(lim.max_tokens, n_tok), max(lim.max_text, text_len))
         if self._engine is None or need != self._engine.limits or self._engine.device != x.device:
@@ -177,16 +182,19 @@ class NextDiT(nn.Module):
         return self._engine
 
     def _call(self, x, t, cap_feats, cap_mask, use_cfg, **kw):
-        if not isinstance(x, torch.Tensor):
-            raise NotImplementedError("list-of-latents (variable resolution packing, model.py:789-834) is a later round")
         eng = self.engine(x, cap_feats.shape[1])
         eng.prepare_prompt(cap_feats, cap_mask)
+        if not isinstance(x, torch.Tensor):  # variable-resolution packing (model.py:789-834): plain forward only, like the reference
+            if use_cfg:
+                raise TypeError("forward_with_cfg takes a [B, C, H, W] tensor (reference model.py:901-902)")
+            return eng.forward_packed(list(x), t, **kw)
         return eng.forward(x, t, use_cfg=use_cfg, **kw)
 
     # ---- reference call surface ---------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, x, t, cap_feats, cap_mask):
-        """reference model.py:836-864 (tensor input path)"""
+        """reference model.py:836-864; ``x`` is a [B, C, H, W] tensor or a list of [C, H_b, W_b] tensors of different sizes
+        (returns a list then)"""
         pa = self.layers[0].attention.proportional_attn if self.n_layers else False
         bs = self.layers[0].attention.base_seqlen if self.n_layers else None
         # the reference's plain forward uses the table left in self.freqs_cis; after construction that is the

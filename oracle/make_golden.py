@@ -101,6 +101,39 @@ def model_case(name, cfg, pkg, latent_hw, text_len, uncond_len, seed_w, seed_x):
     print(f"{name}.npz: N={N} T={text_len}", {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 0})
 
 
+def packed_case(name, cfg, sizes, text_len, seed_w, seed_x):
+    """NextDiT.forward on a LIST of differently sized latents (patchify_and_embed list branch, model.py:789-834) - the
+    unmodified reference, CPU fp32 (SDPA branch with the key mask, model.py:407-415)."""
+    sd = synth.synth_state_dict(cfg, seed=seed_w)
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
+        del sys.modules[m]
+    R.load_reference("lumina_next_t2i")
+    model = R.build_reference_model(cfg, sd)
+    rng = np.random.default_rng(seed_x)
+    B = len(sizes)
+    xs = [torch.from_numpy(rng.standard_normal((cfg.in_channels, h, w), dtype=np.float32)) for h, w in sizes]
+    t = torch.from_numpy(rng.uniform(0.1, 0.9, size=B).astype(np.float32))
+    cap = torch.from_numpy(rng.standard_normal((B, text_len, cfg.cap_feat_dim), dtype=np.float32))
+    mask = torch.ones(B, text_len, dtype=torch.int32)
+    for b in range(B):
+        mask[b, text_len - 3 * b:] = 0
+    out = {"config": np.array(json.dumps(cfg.to_dict())), "seed_w": seed_w, "seed_x": seed_x, "sizes": np.array(sizes, dtype=np.int32),
+           "t": _np(t), "cap": _np(cap), "mask": _np(mask)}
+    with torch.no_grad():
+        ys = model(xs, t, cap, mask)
+        assert isinstance(ys, list) and all(tuple(y.shape) == (cfg.in_channels, h, w) for y, (h, w) in zip(ys, sizes))
+        # proportional attention as forward_with_cfg would leave it on the layers (model.py:891-899)
+        for layer in model.layers:
+            layer.attention.proportional_attn, layer.attention.base_seqlen = True, 16
+        yp = model(xs, t, cap, mask)
+        # the same samples one by one as [1, C, H, W] tensors: only the proportional scale (log of the PADDED length) may differ
+        solo = [model(x[None], t[b:b + 1], cap[b:b + 1], mask[b:b + 1])[0] for b, x in enumerate(xs)]
+    for b in range(B):
+        out[f"x{b}"], out[f"y{b}"], out[f"yprop{b}"], out[f"solo_prop{b}"] = _np(xs[b]), _np(ys[b]), _np(yp[b]), _np(solo[b])
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}.npz:", sizes, {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 1})
+
+
 def _fresh_import(pkg, module):
     """import <pkg>/<module> of the reference with a clean `models` namespace (every sub-project calls its package `models`)"""
     for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
@@ -193,6 +226,7 @@ def main():
     family_case("moe_tiny", synth.TINY_MOE, (16, 16), 9, 10)
     family_case("flag_tiny", synth.TINY_FLAG, (16, 24), 11, 12)
     mini_ode_kats()
+    packed_case("nextdit_tiny_packed", synth.TINY, [(16, 16), (12, 20), (8, 24), (16, 16)], 16, 13, 14)
 
 
 if __name__ == "__main__":

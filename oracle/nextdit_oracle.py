@@ -134,8 +134,9 @@ def block(sd, i, cfg: NextDiTConfig, x, freqs_cis, y, y_mask, adaln_input, softm
 
 def forward(sd_in: Dict[str, torch.Tensor], cfg: NextDiTConfig, x, t, cap_feats, cap_mask, *, freqs_table=None,
             proportional_attn: bool = False, base_seqlen: Optional[int] = None, bf16: bool = False,
-            n_layers: Optional[int] = None, return_hidden: bool = False):
-    """NextDiT.forward, model.py:836-864 (tensor input path :774-788)."""
+            n_layers: Optional[int] = None, return_hidden: bool = False, scale_seqlen: Optional[int] = None):
+    """NextDiT.forward, model.py:836-864 (tensor input path :774-788).  ``scale_seqlen`` overrides the sequence length the
+    proportional-attention scale is computed from (the padded length of a packed batch, see forward_packed)."""
     sd = _sd(sd_in, bf16)
     p = cfg.patch_size
     B, C, H, W = x.shape
@@ -158,7 +159,7 @@ def forward(sd_in: Dict[str, torch.Tensor], cfg: NextDiTConfig, x, t, cap_feats,
     cap_emb = _linear(_r(pool, bf16), sd["cap_embedder.1.weight"], sd["cap_embedder.1.bias"], bf16)
     adaln_input = _r(te + cap_emb, bf16)
     if proportional_attn:
-        scale = math.sqrt(math.log(N, base_seqlen) / hd)  # :374
+        scale = math.sqrt(math.log(N if scale_seqlen is None else scale_seqlen, base_seqlen) / hd)  # :374
     else:
         scale = math.sqrt(1 / hd)
     L = cfg.n_layers if n_layers is None else n_layers
@@ -177,6 +178,20 @@ def forward(sd_in: Dict[str, torch.Tensor], cfg: NextDiTConfig, x, t, cap_feats,
     if cfg.learn_sigma:
         img = img.chunk(2, dim=1)[0]
     return (img, hidden) if return_hidden else img
+
+
+def forward_packed(sd, cfg: NextDiTConfig, xs, t, cap_feats, cap_mask, *, proportional_attn: bool = False,
+                   base_seqlen: Optional[int] = None, bf16: bool = False):
+    """NextDiT.forward on a LIST of [C, H_b, W_b] latents (patchify_and_embed list branch, model.py:789-834).
+    The reference pads every sequence to the longest one with ``pad_token``, lets padded positions rotate like the sample's
+    last token, masks them as keys (:407-415) and drops them in unpatchify (:757-768).  No op mixes tokens except attention,
+    where padded keys are masked, so a VALID token's output equals the sample run on its own - with one exception: the
+    proportional-attention scale sqrt(log_base(seqlen) / hd) uses the PADDED length (:373-374).  Pinned against the
+    reference's own list path in tests/golden/nextdit_tiny_packed.npz."""
+    p = cfg.patch_size
+    lmax = max((x.shape[1] // p) * (x.shape[2] // p) for x in xs)
+    return [forward(sd, cfg, x[None], t[b:b + 1], cap_feats[b:b + 1], cap_mask[b:b + 1], proportional_attn=proportional_attn,
+                    base_seqlen=base_seqlen, bf16=bf16, scale_seqlen=lmax)[0] for b, x in enumerate(xs)]
 
 
 def forward_with_cfg(sd, cfg: NextDiTConfig, x, t, cap_feats, cap_mask, cfg_scale, scale_factor=1.0,

@@ -288,3 +288,36 @@ def test_sample_driver_end_to_end_with_injected_encoder(golden_dir, tmp_path):
     want = fn(z, model.forward_with_cfg, cap_feats=feats, cap_mask=mask, cfg_scale=4.0, proportional_attn=True,
               base_seqlen=256, scale_factor=1.0, scale_watershed=1.0)[-1][:1]
     assert torch.equal(decoded[0], want / 0.13025)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_engine_packed_variable_resolution_vs_reference_list_path(golden_dir, dtype):
+    """NextDiT.forward(list of [C, H_b, W_b]) (reference model.py:789-834, unpatchify :757-768) through lt_forward_packed
+    against the unmodified reference's list path (CPU fp32 golden): mixed lengths 64 / 60 / 48 / 64 tokens, pad_token rows,
+    per-sample rotary grid width, masked padded keys, per-sample output shapes; plain and proportional attention
+    (the proportional scale uses the padded length, model.py:373-374)."""
+    g, cfg = _golden(golden_dir, "nextdit_tiny_packed")
+    model = _model(cfg, int(g["seed_w"]))
+    sizes = [tuple(int(v) for v in hw) for hw in g["sizes"]]
+    xs = [torch.from_numpy(g[f"x{b}"]).to("cuda", dtype) for b in range(len(sizes))]
+    t, cap = torch.from_numpy(g["t"]).cuda(), torch.from_numpy(g["cap"]).to("cuda", torch.bfloat16)
+    mask = torch.from_numpy(g["mask"]).cuda()
+    ys = model(xs, t, cap, mask)
+    assert isinstance(ys, list) and len(ys) == len(sizes)
+    for b, y in enumerate(ys):
+        ref = torch.from_numpy(g[f"y{b}"])
+        assert tuple(y.shape) == (cfg.in_channels,) + sizes[b] and y.dtype == dtype
+        assert rel_l2(y, ref) < TOL_FWD, (b, rel_l2(y, ref))
+    # a sample of the maximum length is bit-identical to running it alone as a [1, C, H, W] tensor (same kernels, same order)
+    solo = model(xs[0][None], t[:1], cap[:1], mask[:1])[0]
+    assert torch.equal(solo, ys[0])
+    for layer in model.layers:  # as forward_with_cfg leaves them (model.py:891-899)
+        layer.attention.proportional_attn, layer.attention.base_seqlen = True, 16
+    yp = model(xs, t, cap, mask)
+    for b, y in enumerate(yp):
+        ref = torch.from_numpy(g[f"yprop{b}"])
+        assert rel_l2(y, ref) < TOL_FWD, (b, rel_l2(y, ref))
+    short = min(range(len(sizes)), key=lambda b: sizes[b][0] * sizes[b][1])
+    assert rel_l2(yp[short], torch.from_numpy(g[f"solo_prop{short}"])) > rel_l2(yp[short], torch.from_numpy(g[f"yprop{short}"]))
+    with pytest.raises(TypeError):
+        model.forward_with_cfg(xs, t, cap, mask, 4.0)

@@ -179,3 +179,25 @@ def test_flag_oracle_matches_reference_model(golden_dir):
                                   proportional_attn=True)
     np.testing.assert_allclose(got.numpy(), g["cfg4_rope"], **tol)
     np.testing.assert_allclose(V.flag_forward_with_cfg(sd, cfg, z, t, cap, mask, 1.0).numpy(), g["cfg1_plain"], **tol)
+
+
+def test_oracle_packed_variable_resolution_matches_reference_list_path(golden_dir):
+    """NextDiT.forward(list of latents) (model.py:789-834): the oracle's statement - valid tokens are untouched by the padding,
+    only the proportional scale sees the padded length - against the unmodified reference's list path (CPU fp32)."""
+    g = _load(golden_dir, "nextdit_tiny_packed")
+    cfg = synth.NextDiTConfig(**json.loads(str(g["config"])))
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    sizes = [tuple(int(v) for v in hw) for hw in g["sizes"]]
+    assert len({h * w for h, w in sizes}) >= 3  # really mixed lengths
+    xs = [torch.from_numpy(g[f"x{b}"]) for b in range(len(sizes))]
+    t, cap, mask = torch.from_numpy(g["t"]), torch.from_numpy(g["cap"]), torch.from_numpy(g["mask"])
+    for key, kw in (("y", {}), ("yprop", dict(proportional_attn=True, base_seqlen=16))):
+        ys = O.forward_packed(sd, cfg, xs, t, cap, mask, **kw)
+        for b, y in enumerate(ys):
+            ref = torch.from_numpy(g[f"{key}{b}"])
+            assert tuple(y.shape) == (cfg.in_channels,) + sizes[b]
+            assert float((y - ref).norm() / ref.norm()) < 2e-5, (key, b)
+    # and the padded length matters where the reference says it does: a short sample alone differs in the proportional mode
+    short = min(range(len(sizes)), key=lambda b: sizes[b][0] * sizes[b][1])
+    solo, packed = torch.from_numpy(g[f"solo_prop{short}"]), torch.from_numpy(g[f"yprop{short}"])
+    assert float((solo - packed).norm() / packed.norm()) > 1e-3
