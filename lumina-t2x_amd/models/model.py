@@ -119,8 +119,12 @@ class NextDiT(nn.Module):
     def __init__(self, patch_size: int = 2, in_channels: int = 4, dim: int = 4096, n_layers: int = 32,
                  n_heads: int = 32, n_kv_heads: Optional[int] = None, multiple_of: int = 256,
                  ffn_dim_multiplier: Optional[float] = None, norm_eps: float = 1e-5, learn_sigma: bool = True,
-                 qk_norm: bool = False, cap_feat_dim: int = 5120, scale_factor: float = 1.0) -> None:
+                 qk_norm: bool = False, cap_feat_dim: int = 5120, scale_factor: float = 1.0,
+                 use_flash_attn: bool = True) -> None:
+        # use_flash_attn: constructor kwarg of the mini package (lumina_next_t2i_mini/models/nextdit.py:637; sample.py:111) -
+        # accepted so its scripts swap in unchanged; the engine has one attention path (exact softmax either way)
         super().__init__()
+        self.use_flash_attn = use_flash_attn
         assert (dim // n_heads) % 4 == 0, "2d rope needs head dim to be divisible by 4"
         self.learn_sigma = learn_sigma
         self.in_channels = in_channels
