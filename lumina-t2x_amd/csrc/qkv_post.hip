@@ -13,98 +13,138 @@
 //                 values, so the PV MFMA needs no cross-lane exchange (see attention.hip).
 #include "common.h"
 #include "kernels.h"
+#include <algorithm>
 
 namespace {
 
-// one wave per token row; compiled per chunk count (16-byte chunks per lane) so small widths keep occupancy
+// QK_ROWS consecutive token rows per workgroup (8 waves x 2 rows).  Per workgroup the LayerNorm weight / bias and the
+// rotary factors of its rows are staged in LDS once: read per row from L1 they were 2 x the row's own bytes (weights) plus
+// one 8-byte table load per bf16 pair, which made the kernel TA-bound (2.7 TB/s) instead of HBM-bound.
+// In the head-major destination one head's 8+ consecutive rows are whole 128-byte lines (16 * hd bytes, hd % 8 == 0), so no
+// line is shared between workgroups (= between XCD L2s).
+constexpr int QK_ROWS = 16, QK_WAVES = 8, QK_RPW = QK_ROWS / QK_WAVES;
+
+// LDS image: ln_w | ln_b (bf16, `width` each) | (cos, sin)[row][complex slot] fp32
 template <int MAXCH>
-__device__ __forceinline__ void qk_norm_rope_row(const QkPostArgs& p, int row, int lane) {
+__device__ __forceinline__ void qk_norm_rope_block(const QkPostArgs& p, int bid, char* smem) {
     const int rows = p.B * p.N;
-    if (row >= rows) return;
-    const int b = row / p.N, n = row - b * p.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int width = p.heads * p.hd;
     const int nch = width >> 3;
-    const int cph = p.hd >> 3;  // chunks per head
-    const u16* src = p.src + (size_t)row * p.ld_src + p.col0;
+    const int cph = p.hd >> 3;   // chunks per head
+    const int nslot = p.hd >> 1;  // complex slots per head
+    const int row0 = bid * QK_ROWS;
+    u16* sw = (u16*)smem;
+    u16* sb = sw + width;
+    float2* st = (float2*)(smem + (size_t)width * 4);
 
-    bf8_t raw[MAXCH];
+    // this wave's rows: issue the global loads first, they are the long-latency part
+    bf8_t raw[QK_RPW][MAXCH];
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) raw[i] = *(const bf8_t*)(src + c * 8);
-        else raw[i].w[0] = raw[i].w[1] = raw[i].w[2] = raw[i].w[3] = 0u;
+    for (int r = 0; r < QK_RPW; ++r) {
+        const int row = row0 + wave * QK_RPW + r;
+        const u16* src = p.src + (size_t)(row < rows ? row : rows - 1) * p.ld_src + p.col0;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) raw[r][i] = *(const bf8_t*)(src + c * 8);
+            else raw[r][i].w[0] = raw[r][i].w[1] = raw[r][i].w[2] = raw[r][i].w[3] = 0u;
+        }
     }
-    float mean = 0.f, rstd = 1.f;
-    if (p.ln_w) {  // nn.LayerNorm over the full projection width, fp32 (model.py:211-215, :361-362)
-        f32x2 s2 = {0.f, 0.f};
+    if (p.ln_w) {
+        for (int c = tid; c < nch; c += 64 * QK_WAVES) {
+            *(bf8_t*)(sw + c * 8) = *(const bf8_t*)(p.ln_w + c * 8);
+            *(bf8_t*)(sb + c * 8) = *(const bf8_t*)(p.ln_b + c * 8);
+        }
+    }
+    if (p.rope_mode != 0) {
+        // rotary table: branch 0 = linear interpolation (t < watershed), branch 1 = NTK (model.py:944-949)
+        int branch = 1;
+        if (p.t) branch = (p.t[0] < p.watershed) ? 0 : 1;
+        const int nfreq = (p.rope_mode == 1) ? (p.hd >> 2) : (p.hd >> 1);
+        const float* cs = p.cs + (size_t)branch * p.cs_len * nfreq * 2;
+        for (int i = tid; i < QK_ROWS * nslot; i += 64 * QK_WAVES) {
+            const int r = i / nslot, pr = i - r * nslot;
+            const int row = row0 + r;
+            if (row < rows) {
+                const int b = row / p.N, n = row - b * p.N;
+                const int n_rot = p.n_tok_b ? min(n, p.n_tok_b[b] - 1) : n;
+                int pos, fi;
+                if (p.rope_mode == 1) {  // complex slot 2i rotates with the ROW position, 2i+1 with the COLUMN position
+                    const int gw = p.grid_w_b ? p.grid_w_b[b] : p.grid_w;
+                    const int gr = n_rot / gw, gc = n_rot - gr * gw;
+                    fi = pr >> 1; pos = (pr & 1) ? gc : gr;
+                } else { fi = pr; pos = n_rot; }
+                st[i] = *(const float2*)(cs + ((size_t)pos * nfreq + fi) * 2);
+            }
+        }
+    }
+    __syncthreads();
+
 #pragma unroll
-        for (int i = 0; i < MAXCH; ++i)
+    for (int r = 0; r < QK_RPW; ++r) {
+        const int row = row0 + wave * QK_RPW + r;
+        if (row >= rows) continue;  // wave-uniform
+        const int b = row / p.N, n = row - b * p.N;
+        float mean = 0.f, rstd = 1.f;
+        if (p.ln_w) {  // nn.LayerNorm over the full projection width, fp32 (model.py:211-215, :361-362)
+            f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s2 += unpk_bf(raw[i].w[k]);
-        mean = wave_sum(s2[0] + s2[1]) / (float)width;
-        const f32x2 mv = {mean, mean};
-        f32x2 q2 = {0.f, 0.f};
+            for (int i = 0; i < MAXCH; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s2 += unpk_bf(raw[r][i].w[k]);
+            mean = wave_sum(s2[0] + s2[1]) / (float)width;
+            const f32x2 mv = {mean, mean};
+            f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MAXCH; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x2 dl = unpk_bf(raw[r][i].w[k]) - mv;
+                        q2 = dl * dl + q2;
+                    }
+                }
+            }
+            rstd = rsqrtf(wave_sum(q2[0] + q2[1]) / (float)width + p.ln_eps);
+        }
+        const f32x2 mv = {mean, mean}, rv = {rstd, rstd}, osc = {p.out_scale, p.out_scale};
+        const float2* strow = st + (wave * QK_RPW + r) * nslot;
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x2 dl = unpk_bf(raw[i].w[k]) - mv;
-                    q2 = dl * dl + q2;
+                const int head = c / cph, ci = c - head * cph;
+                bf8_t wv, bv, o;
+                if (p.ln_w) {
+                    wv = *(const bf8_t*)(sw + c * 8);
+                    bv = *(const bf8_t*)(sb + c * 8);
                 }
-            }
-        }
-        rstd = rsqrtf(wave_sum(q2[0] + q2[1]) / (float)width + p.ln_eps);
-    }
-
-    // rotary table: branch 0 = linear interpolation (t < watershed), branch 1 = NTK (model.py:944-949)
-    int branch = 1;
-    if (p.t) branch = (p.t[0] < p.watershed) ? 0 : 1;
-    const int nfreq = (p.rope_mode == 1) ? (p.hd >> 2) : (p.hd >> 1);
-    const float* cs = p.cs ? p.cs + (size_t)branch * p.cs_len * nfreq * 2 : nullptr;
-    const int n_rot = p.n_tok_b ? min(n, p.n_tok_b[b] - 1) : n;
-    const int gw = p.grid_w_b ? p.grid_w_b[b] : p.grid_w;
-    const int gr = n_rot / gw, gc = n_rot - gr * gw;
-    const f32x2 mv = {mean, mean}, rv = {rstd, rstd}, osc = {p.out_scale, p.out_scale};
-
-#pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-            const int head = c / cph, ci = c - head * cph;
-            bf8_t wv, bv, o;
-            if (p.ln_w) {
-                wv = *(const bf8_t*)(p.ln_w + c * 8);
-                bv = *(const bf8_t*)(p.ln_b + c * 8);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {  // one complex slot = one bf16 pair
-                f32x2 y = unpk_bf(raw[i].w[j]);
-                if (p.ln_w) y = (y - mv) * rv * unpk_bf(wv.w[j]) + unpk_bf(bv.w[j]);
+                float4 t01 = {1.f, 0.f, 1.f, 0.f}, t23 = {1.f, 0.f, 1.f, 0.f};
                 if (p.rope_mode != 0) {
-                    const int pr = 4 * ci + j;  // complex slot inside the head
-                    int pos, fi;
-                    if (p.rope_mode == 1) { fi = pr >> 1; pos = (pr & 1) ? gc : gr; }
-                    else { fi = pr; pos = n_rot; }
-                    const float2 t = *(const float2*)(cs + ((size_t)pos * nfreq + fi) * 2);
-                    y = f32x2{y[0] * t.x - y[1] * t.y, y[0] * t.y + y[1] * t.x};
+                    t01 = *(const float4*)(strow + 4 * ci);
+                    t23 = *(const float4*)(strow + 4 * ci + 2);
                 }
-                if (p.out_scale != 1.0f) y = y * osc;
-                o.w[j] = pk_bf(y);
+                const float tc[4] = {t01.x, t01.z, t23.x, t23.z}, ts[4] = {t01.y, t01.w, t23.y, t23.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // one complex slot = one bf16 pair
+                    f32x2 y = unpk_bf(raw[r][i].w[j]);
+                    if (p.ln_w) y = (y - mv) * rv * unpk_bf(wv.w[j]) + unpk_bf(bv.w[j]);
+                    if (p.rope_mode != 0) y = f32x2{y[0] * tc[j] - y[1] * ts[j], y[0] * ts[j] + y[1] * tc[j]};
+                    if (p.out_scale != 1.0f) y = y * osc;
+                    o.w[j] = pk_bf(y);
+                }
+                *(bf8_t*)(p.dst + (((size_t)b * p.heads + head) * p.N + n) * p.hd + ci * 8) = o;
             }
-            *(bf8_t*)(p.dst + (((size_t)b * p.heads + head) * p.N + n) * p.hd + ci * 8) = o;
         }
     }
 }
 
-// 8 waves = 8 consecutive token rows per workgroup: in the head-major destination one head's 8 rows are 16 * hd bytes =
-// whole 128-byte lines (hd % 8 == 0), so no line is shared between workgroups (= between XCD L2s; a line written half by
-// one XCD and half by another goes to memory twice as partial writes).
-constexpr int QK_ROWS = 8;
 template <int MAXCH>
-__global__ __launch_bounds__(64 * QK_ROWS) void qk_norm_rope_kernel(QkPostArgs p) {
-    qk_norm_rope_row<MAXCH>(p, blockIdx.x * QK_ROWS + (threadIdx.x >> 6), threadIdx.x & 63);
+__global__ __launch_bounds__(64 * QK_WAVES) void qk_norm_rope_kernel(QkPostArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    qk_norm_rope_block<MAXCH>(p, blockIdx.x, smem_raw);
 }
 
 // one block per (64-key tile, kv head, batch): V rows -> LDS (transposed, permuted) -> 128-byte rows
@@ -150,16 +190,16 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const u16* __restrict_
 // passes over the QKV GEMM output): workgroups [0, nq) take q rows, [nq, nq + nk) k rows, the rest V tiles, so the three
 // streams overlap instead of running back to back with two launch boundaries in between.
 template <int MAXCH>
-__global__ __launch_bounds__(64 * QK_ROWS) void qkv_post_kernel(QkvPostArgs p) {
+__global__ __launch_bounds__(64 * QK_WAVES) void qkv_post_kernel(QkvPostArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int bid = blockIdx.x;
     if (bid < p.nq_blocks) {
-        qk_norm_rope_row<MAXCH>(p.q, bid * QK_ROWS + (threadIdx.x >> 6), threadIdx.x & 63);
+        qk_norm_rope_block<MAXCH>(p.q, bid, smem_raw);
         return;
     }
     bid -= p.nq_blocks;
     if (bid < p.nk_blocks) {
-        qk_norm_rope_row<MAXCH>(p.k, bid * QK_ROWS + (threadIdx.x >> 6), threadIdx.x & 63);
+        qk_norm_rope_block<MAXCH>(p.k, bid, smem_raw);
         return;
     }
     bid -= p.nk_blocks;
@@ -179,14 +219,15 @@ int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
     LT_REQUIRE((a.ln_w == nullptr) == (a.ln_b == nullptr), "qk_norm_rope: LayerNorm weight and bias must come together");
     const int rows = a.B * a.N;
     const dim3 grid((rows + QK_ROWS - 1) / QK_ROWS);
+    const size_t smem = (size_t)width * 4 + (size_t)QK_ROWS * (a.hd >> 1) * 8;
     switch (((width >> 3) + 63) / 64) {
-        case 1: hipLaunchKernelGGL(qk_norm_rope_kernel<1>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL(qk_norm_rope_kernel<2>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
-        case 3: hipLaunchKernelGGL(qk_norm_rope_kernel<3>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL(qk_norm_rope_kernel<4>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
-        case 5: hipLaunchKernelGGL(qk_norm_rope_kernel<5>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
-        case 6: hipLaunchKernelGGL(qk_norm_rope_kernel<6>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
-        default: hipLaunchKernelGGL(qk_norm_rope_kernel<8>, grid, dim3(64 * QK_ROWS), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL(qk_norm_rope_kernel<1>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 2: hipLaunchKernelGGL(qk_norm_rope_kernel<2>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 3: hipLaunchKernelGGL(qk_norm_rope_kernel<3>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 4: hipLaunchKernelGGL(qk_norm_rope_kernel<4>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 5: hipLaunchKernelGGL(qk_norm_rope_kernel<5>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 6: hipLaunchKernelGGL(qk_norm_rope_kernel<6>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        default: hipLaunchKernelGGL(qk_norm_rope_kernel<8>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
     }
     LT_CHECK_HIP(hipGetLastError());
     return 0;
@@ -213,15 +254,15 @@ int launch_qkv_post(const QkvPostArgs& a0, hipStream_t stream) {
     a.nk_blocks = (a.k.B * a.k.N + QK_ROWS - 1) / QK_ROWS;
     const int nv = (a.v_Npad / 64) * a.v_kv_heads * a.v_B;
     const dim3 grid(a.nq_blocks + a.nk_blocks + nv);
-    const int smem = a.v_hd * 72 * 2;
+    const size_t smem = std::max<size_t>((size_t)a.v_hd * 72 * 2, (size_t)wq * 4 + (size_t)QK_ROWS * (a.q.hd >> 1) * 8);
     switch (((wq >> 3) + 63) / 64) {
-        case 1: hipLaunchKernelGGL(qkv_post_kernel<1>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
-        case 2: hipLaunchKernelGGL(qkv_post_kernel<2>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
-        case 3: hipLaunchKernelGGL(qkv_post_kernel<3>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
-        case 4: hipLaunchKernelGGL(qkv_post_kernel<4>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
-        case 5: hipLaunchKernelGGL(qkv_post_kernel<5>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
-        case 6: hipLaunchKernelGGL(qkv_post_kernel<6>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
-        default: hipLaunchKernelGGL(qkv_post_kernel<8>, grid, dim3(64 * QK_ROWS), smem, stream, a); break;
+        case 1: hipLaunchKernelGGL(qkv_post_kernel<1>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 2: hipLaunchKernelGGL(qkv_post_kernel<2>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 3: hipLaunchKernelGGL(qkv_post_kernel<3>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 4: hipLaunchKernelGGL(qkv_post_kernel<4>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 5: hipLaunchKernelGGL(qkv_post_kernel<5>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 6: hipLaunchKernelGGL(qkv_post_kernel<6>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        default: hipLaunchKernelGGL(qkv_post_kernel<8>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
     }
     LT_CHECK_HIP(hipGetLastError());
     return 0;
