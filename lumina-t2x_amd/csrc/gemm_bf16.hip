@@ -278,15 +278,24 @@ __device__ __forceinline__ void pp_barrier() {
 // slab instead of one per segment.  Hazards (interval k = after barrier k): slab k+1 is read in interval k (group 0) or k+1
 // (others) and every wave waited for its pieces of slab k+1 before barrier k; slab k+3 is issued in interval k into the slot
 // of slab k-1, whose last reads (other groups, interval k-1) completed before barrier k.
-template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0, int MODE = 0>
+// KS: MFMA k-steps per slab (2 = 32-deep slabs, 64-byte LDS rows; 4 = 64-deep, 128-byte rows).  The deep form halves the
+// number of barrier intervals of a K loop; the small-M tiles use it, where an interval holds only 2-4 MFMAs per wave and the
+// loop is barrier-latency bound (the 256-wide tiles cannot: 4 slots x 64 KiB exceed the LDS).
+template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0, int MODE = 0, int KS = 2>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(GemmArgs p) {
     static_assert(MODE == 0 || TAILN == 0, "rendezvous mode has no hand-over barrier");
+    static_assert(MODE != 2 || !TRACE, "the register-pipeline loop has no trace build");
+    static_assert(KS == 2 || KS == 4, "slab depth 32 or 64");
+    static_assert(TAILN == 0 || KS == 2, "tail overlap is written for 32-deep slabs");
+    constexpr int RB = KS * 32;          // bytes per LDS row
+    constexpr int RPP = 1024 / RB;       // rows per 1-KiB staging piece
+    constexpr int LPR = RB / 16;         // lanes (16-byte chunks) per row
     constexpr int NW = WM * WN, G = NW / 4;
     static_assert(NW % 4 == 0 && G >= 2 && G <= 3, "ping-pong needs 2 or 3 waves per SIMD");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    constexpr int PA = BM / 16, PW = BN / 16, NP = PA + PW;  // 1-KiB pieces (16 rows x 64 B) per slab
-    constexpr int IP = (NP + NW - 1) / NW;                   // pieces per wave per slab (same for every wave)
-    constexpr int SLAB = (BM + BN) * 64, W_OFF = BM * 64;
+    constexpr int PA = BM / RPP, PW = BN / RPP, NP = PA + PW;  // 1-KiB pieces (RPP rows x RB bytes) per slab
+    constexpr int IP = (NP + NW - 1) / NW;                     // pieces per wave per slab (same for every wave)
+    constexpr int SLAB = (BM + BN) * RB, W_OFF = BM * RB;
     static_assert(EPI == 0 || NT % 2 == 0, "SwiGLU epilogue pairs accumulator tiles");
     static_assert(IP <= 4, "staging pieces per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -319,9 +328,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 
     // staging: wave w owns pieces w, w + NW, ... (a surplus slot re-loads the wave's previous piece: same bytes
     // to the same place, so every wave issues exactly IP loads per slab and one vmcnt literal fits all).
-    // Piece q holds rows 16q..16q+15 of A (q < PA) or of W; lane -> row 16q + lane/4, 16-byte position lane%4,
-    // fetched from source chunk pos ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3).
-    const int sswz = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+    // Piece q holds rows RPP q .. RPP q + RPP - 1 of A (q < PA) or of W; lane -> row RPP q + lane / LPR, 16-byte position
+    // lane % LPR, fetched from source chunk pos ^ key(row): key = (row >> 2) & 3 for 64-byte rows, (row >> 1) & 7 for
+    // 128-byte rows (the same keys the fragment reads apply, so a 32x32x16 fragment read is bank-conflict free).
     __amdgpu_buffer_rsrc_t rs[4];
     int voff[4], ldsoff[4];
 #pragma unroll
@@ -329,25 +338,27 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         int q = wave + NW * i;
         if (q >= NP) q -= NW;
         const bool isA = q < PA;
-        const int r0 = 16 * (isA ? q : q - PA) + (lane >> 2);
+        const int r0 = RPP * (isA ? q : q - PA) + lane / LPR;
+        const int key = KS == 2 ? (r0 >> 2) & 3 : (r0 >> 1) & 7;
         rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(isA ? a_base : w_base), 0, isA ? a_bytes : w_bytes, 0x00020000);
-        voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + sswz;
+        voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + (((lane % LPR) ^ key) << 4);
         ldsoff[i] = q * 1024;
     }
     auto stage = [&](int slab) {
         char* base = smem + (slab & 3) * SLAB;
-        const int soff = slab * 64;
+        const int soff = slab * RB;
 #pragma unroll
         for (int i = 0; i < IP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i], LDS_PTR(base + ldsoff[i]), 16, voff[i], soff, 0, 0);
     };
 
-    const int fswz = (l31 >> 2) & 3;
-    const int a_row_off = (wm * MT * 32 + l31) * 64;
-    const int w_row_off = W_OFF + (wn * NT * 32 + l31) * 64;
-    int coff[2];
+    const int fswz = KS == 2 ? (l31 >> 2) & 3 : (l31 >> 1) & 7;
+    const int a_row_off = (wm * MT * 32 + l31) * RB;
+    const int w_row_off = W_OFF + (wn * NT * 32 + l31) * RB;
+    constexpr int TSTRIDE = 32 * RB;  // LDS bytes between two 32-row fragment tiles
+    int coff[KS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) coff[s] = ((2 * s + hi) ^ fswz) << 4;
+    for (int s = 0; s < KS; ++s) coff[s] = ((2 * s + hi) ^ fswz) << 4;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int ns = p.K / 32;
+    const int ns = p.K / (16 * KS);
     // prologue: slabs 0..2 in flight, slab 0 landed and visible
     stage(0);
     if (ns > 1) stage(1);
@@ -369,12 +380,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     if constexpr (MODE == 0)
         for (int g = 0; g < grp; ++g) pp_barrier();
 
-    bf16x8 wf[2][NT], af[2][MT];
+    bf16x8 wf[KS][NT], af[KS][MT];
     // TRACE build only: per-wave cycle totals of the six sub-segments of a step (s_memtime stamps)
     unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, ta = 0, tb = 0, tc = 0;
     unsigned long long tstart = 0;
     if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
-    constexpr int NM = 2 * MT * NT;  // MFMAs of one segment
+    constexpr int NM = KS * MT * NT;  // MFMAs of one segment
     static_assert(TAILN >= 0 && TAILN < MT * NT, "tail MFMAs must all belong to k-step 1");
     auto one_mfma = [&](int idx) __attribute__((always_inline)) {
         const int k = idx / (MT * NT), mt = (idx / NT) % MT, nt = idx % NT;
@@ -388,8 +399,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         constexpr bool WT = decltype(with_tail)::value && TAILN > 0;
         constexpr int R0 = NT + MT;
         auto read0 = [&](int r) __attribute__((always_inline)) {
-            if (r < NT) wf[0][r] = *(const bf16x8*)(sb + w_row_off + r * 2048 + coff[0]);
-            else af[0][r - NT] = *(const bf16x8*)(sb + a_row_off + (r - NT) * 2048 + coff[0]);
+            if (r < NT) wf[0][r] = *(const bf16x8*)(sb + w_row_off + r * TSTRIDE + coff[0]);
+            else af[0][r - NT] = *(const bf16x8*)(sb + a_row_off + (r - NT) * TSTRIDE + coff[0]);
         };
         if constexpr (WT) {
             constexpr int RPT = R0 / (TAILN > 0 ? TAILN : 1);  // k-step 0 reads per tail MFMA
@@ -415,9 +426,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
             for (int r = 0; r < R0; ++r) read0(r);
         }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wf[1][nt] = *(const bf16x8*)(sb + w_row_off + nt * 2048 + coff[1]);
+        for (int k = 1; k < KS; ++k) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[1][mt] = *(const bf16x8*)(sb + a_row_off + mt * 2048 + coff[1]);
+            for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * TSTRIDE + coff[k]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * TSTRIDE + coff[k]);
+        }
         if constexpr (TRACE) ta = __builtin_amdgcn_s_memtime();
         if (s + 2 < ns) wait_vmcnt<IP>();  // slab s+1 landed (slab s+2 may still be in flight)
         else wait_vmcnt<0>();
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         constexpr int EVERY = HEAD / IP > 0 ? HEAD / IP : 1;
         int issued = 0;
         char* base = smem + ((s + 3) & 3) * SLAB;
-        const int soff = (s + 3) * 64;
+        const int soff = (s + 3) * RB;
 #pragma unroll
         for (int i = 0; i < HEAD; ++i) {
             one_mfma(i);
@@ -499,15 +513,63 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         if (s == 0) { step(0, std::false_type{}, std::false_type{}); s = 1; }
         for (; s < ns; ++s) step(s, std::false_type{}, std::true_type{});
         for (int g = grp; g < G - 1; ++g) pp_barrier();  // equalise barrier counts before the (barrier-free) epilogue
+    } else if constexpr (MODE == 2) {
+        // MODE 2 ("register pipeline", small tiles): every wave runs the same stream, fragments double-buffered in registers -
+        // the reads of slab k+1 are issued BEFORE the MFMAs of slab k, so the LDS latency hides behind them and an interval
+        // is max(reads, MFMAs) + one barrier.  For tiles whose interval holds only 2-8 MFMAs per wave nothing is gained by
+        // giving the matrix pipe to one wave group at a time; the serial READ -> MFMA dependency per interval is what costs.
+        bf16x8 wf2[KS][NT], af2[KS][MT];
+        auto reads_to = [&](int s, bf16x8 (&w)[KS][NT], bf16x8 (&a)[KS][MT]) __attribute__((always_inline)) {
+            const char* sb = smem + (s & 3) * SLAB;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * TSTRIDE + coff[k]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * TSTRIDE + coff[k]);
+            }
+        };
+        auto body = [&](int k, bf16x8 (&wc)[KS][NT], bf16x8 (&ac)[KS][MT], bf16x8 (&wn_)[KS][NT], bf16x8 (&an)[KS][MT])
+                        __attribute__((always_inline)) {
+            if (k + 1 < ns) reads_to(k + 1, wn_, an);  // slab k+1: waited for + barrier at the end of interval k-1
+            const bool st = k + 3 < ns;
+            if (st) stage(k + 3);                      // slot of slab k-1: its reads completed before MFMA(k-1), two barriers ago
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[kk][nt], ac[kk][mt], acc[mt][nt], 0, 0, 0);
+            // the builtin (not an asm string): the compiler's own waitcnt pass must see that the next slab's fragments have
+            // landed here, otherwise it guards the next interval's MFMAs with lgkmcnt waits that drain that interval's fresh reads
+            __builtin_amdgcn_sched_barrier(0);   // keep the wait behind the MFMAs
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            if (k + 1 < ns) {
+                if (st) wait_vmcnt<IP>();  // slab k+2 landed, slab k+3 in flight
+                else wait_vmcnt<0>();
+                pp_barrier();
+            }
+        };
+        reads_to(0, wf, af);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (ns > 2) wait_vmcnt<IP>();  // slab 1 landed
+        else wait_vmcnt<0>();
+        pp_barrier();
+        for (int k = 0; k < ns; k += 2) {
+            body(k, wf, af, wf2, af2);
+            if (k + 1 < ns) body(k + 1, wf2, af2, wf, af);
+        }
     } else {
         auto reads = [&](int s) __attribute__((always_inline)) {
             const char* sb = smem + (s & 3) * SLAB;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < KS; ++k) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * 2048 + coff[k]);
+                for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * TSTRIDE + coff[k]);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * 2048 + coff[k]);
+                for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * TSTRIDE + coff[k]);
             }
         };
         const bool lead = __builtin_amdgcn_readfirstlane(grp == 0 ? 1 : 0) != 0;
@@ -593,9 +655,12 @@ template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0>(GemmArgs);  // 128 x 128, small-M problems
 template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1>(GemmArgs);  // 128 x 128 with the SwiGLU epilogue (needs NT even)
 template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0>(GemmArgs);  //  64 x 128
-template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0, false, 0, 1>(GemmArgs);  // the same three with one barrier per slab
-template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1, false, 0, 1>(GemmArgs);
-template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0, false, 0, 1>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0, false, 0, 2, 4>(GemmArgs);  // ... register-pipelined, one barrier per slab
+template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1, false, 0, 2, 4>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0, false, 0, 2, 4>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0, false, 0, 1, 4>(GemmArgs);  // ... and with one barrier per (64-deep) slab
+template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1, false, 0, 1, 4>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0, false, 0, 1, 4>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, false, 0, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true, 0, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1, false, 0, 1>(GemmArgs);
@@ -631,12 +696,12 @@ namespace {
 // ev0 / ev1 (optional): start / stop events attached to THIS dispatch packet (hipExtLaunchKernelGGL) - the timestamps come
 // from the dispatch's own completion signal, no extra barrier packets in the queue (event records around a launch cost
 // tens of microseconds of queue idle time each on this stack)
-template <int WM, int WN, int MT, int NT, int EPI, bool PP, int TAIL = 0, int MODE = 0>
+template <int WM, int WN, int MT, int NT, int EPI, bool PP, int TAIL = 0, int MODE = 0, int KS = 2>
 int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    constexpr int SMEM = PP ? 4 * (BM + BN) * 64 : 2 * (BM + BN) * 128;
+    constexpr int SMEM = PP ? 4 * (BM + BN) * 32 * KS : 2 * (BM + BN) * 128;
     const void* fn;
-    if constexpr (PP) fn = (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>;
+    if constexpr (PP) fn = (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE, KS>;
     else fn = (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -646,8 +711,8 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
     const dim3 grid(TM * TN), block(WM * WN * 64);
     if constexpr (PP) {
-        if (ev0) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>), grid, block, SMEM, stream, ev0, ev1, 0, a);
-        else hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE>), grid, block, SMEM, stream, a);
+        if (ev0) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE, KS>), grid, block, SMEM, stream, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE, KS>), grid, block, SMEM, stream, a);
     } else {
         if (ev0) hipExtLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), grid, block, SMEM, stream, ev0, ev1, 0, a);
         else hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), grid, block, SMEM, stream, a);
@@ -698,10 +763,20 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     const bool small = !a.trace && (variant == 7 || variant == 8 || (variant == 0 && g_gemm_variant == 0 && 2 * t256 <= cus));
     if (small) {
         const bool tiny = variant == 8 || (variant == 0 && 2 * t128 <= cus);
-        if (g_gemm_pipeline == 3) {  // A/B: single-barrier rendezvous loop
-            if (epilogue == 1) return launch_cfg<4, 2, 1, 2, 1, true, 0, 1>(a, stream, ev0, ev1);
-            if (tiny) return launch_cfg<2, 4, 1, 1, 0, true, 0, 1>(a, stream, ev0, ev1);
-            return launch_cfg<2, 4, 2, 1, 0, true, 0, 1>(a, stream, ev0, ev1);
+        // 64-deep slabs in every default form (half the barrier intervals of the 32-deep loop).  Measured per cfg-1 layer
+        // (profiles/r01/opbench_small_m.log): single-barrier rendezvous 72.9 us < two-barrier ping-pong 77.8 us < register-
+        // pipelined loop 84-93 us (all waves read, then all waves multiply: the LDS-DMA issue cost of 3-4 pieces per wave and
+        // interval is not covered by anything) < 32-deep ping-pong 93-100 us.  At this size the loop is bound by the
+        // L2 -> LDS staging rate of the 96-144 busy CUs, not by the matrix pipe.
+        if (g_gemm_pipeline == 2) {  // A/B: register-pipelined single-barrier loop
+            if (epilogue == 1) return launch_cfg<4, 2, 1, 2, 1, true, 0, 2, 4>(a, stream, ev0, ev1);
+            if (tiny) return launch_cfg<2, 4, 1, 1, 0, true, 0, 2, 4>(a, stream, ev0, ev1);
+            return launch_cfg<2, 4, 2, 1, 0, true, 0, 2, 4>(a, stream, ev0, ev1);
+        }
+        if (g_gemm_pipeline != 1) {  // default
+            if (epilogue == 1) return launch_cfg<4, 2, 1, 2, 1, true, 0, 1, 4>(a, stream, ev0, ev1);
+            if (tiny) return launch_cfg<2, 4, 1, 1, 0, true, 0, 1, 4>(a, stream, ev0, ev1);
+            return launch_cfg<2, 4, 2, 1, 0, true, 0, 1, 4>(a, stream, ev0, ev1);
         }
         if (epilogue == 1) return launch_cfg<4, 2, 1, 2, 1, true>(a, stream, ev0, ev1);
         if (tiny) return launch_cfg<2, 4, 1, 1, 0, true>(a, stream, ev0, ev1);
