@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -33,7 +34,9 @@ extern "C" const char* lt_version(void) { return "lumina_dit gfx950 r1"; }
 namespace {
 
 constexpr float LOG2E = 1.44269504088896340736f;
-int g_qkv_post_fused = 1;  // lt_set_option("qkv_post_fused"): one launch for q / k post-processing + V transpose (A/B knob)
+// lt_set_option("qkv_post_fused"): 1 = one launch for q / k post-processing + V transpose, 0 = three launches.  In-situ A/B
+// with the LDS-staged row kernels (profiles/r01/bench_ab_qkv_post_fused.log): three launches 0.1-0.2 ms / NFE faster.
+int g_qkv_post_fused = 0;
 
 struct DevBuf {
     void* p = nullptr;
@@ -906,8 +909,11 @@ extern "C" int64_t lt_last_nfe(lt_engine* e) { return e ? e->last_nfe : -1; }
 // ---- profiling ------------------------------------------------------------------------------------------
 extern "C" int lt_profile_enable(lt_engine* e, int32_t on) {
     LT_REQUIRE(e, "null engine");
+    // under rocprofv3 the tool intercepts every event / signal; tens of thousands of warm-up records crash it (ROCm 7.2), and
+    // its own kernel trace is what such a run is for: LT_NO_EVENT_PROFILE=1 (scripts/gpu_prof.sh) turns the engine's events off
+    if (on && getenv("LT_NO_EVENT_PROFILE")) { e->prof_on = false; e->prof_mask = 0; return 0; }
     if (on) {
-        const size_t want[3] = {8192, 4096, 16384};
+        const size_t want[3] = {2048, 512, 2048};  // launches bracketed per class before read-out scales up (lt_profile_read)
         bool created = false;
         for (int k = 0; k < 3; ++k) {
             while (e->prof[k].ev.size() < want[k]) {

@@ -2,6 +2,7 @@
 # rocprofv3 kernel-trace summary + PMC passes of the headline bench (separate runs, as the guide prescribes)
 set -u
 cd /tmp && export TMPDIR=/tmp
+export LT_NO_EVENT_PROFILE=1  # the engine's own HIP events off: rocprofv3's trace is the measurement here
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT

@@ -3,6 +3,7 @@
 set -u
 CFG=${1:-cfg1}
 cd /tmp && export TMPDIR=/tmp
+export LT_NO_EVENT_PROFILE=1
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$CFG
 rm -rf $OUT /tmp/prof_$CFG; mkdir -p $OUT
