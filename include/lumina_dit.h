@@ -89,7 +89,13 @@ const char* lt_last_error(void);
 /* library / build identification: returns e.g. "lumina_dit gfx950 r1" */
 const char* lt_version(void);
 
-/* process-wide kernel selection knobs (A/B measurements, tests): "attention_variant" 1|2, "gemm_variant" 0|1|2 */
+/* process-wide kernel selection knobs (A/B measurements, tests; defaults are the measured-best settings):
+ *   "attention_variant" 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (default; hd 72)
+ *   "gemm_variant"      0 auto tile shape (default) | 1 256x256 | 2 256x288
+ *   "gemm_pipeline"     0 auto (default) | 1 ping-pong wave groups | 2 classic double buffer (small-M tiles: register
+ *                       pipeline) | 3 single-barrier rendezvous
+ *   "gemm_pp_tail"      0 (default) | 1: tail MFMAs issued after the ping-pong hand-over barrier
+ *   "qkv_post_fused"    0 three launches (default) | 1 one launch for q / k post-processing + V transpose */
 int lt_set_option(const char* name, int32_t value);
 
 /* ---- engine lifetime ------------------------------------------------------------------------- */
@@ -151,7 +157,9 @@ int lt_profile_set_budget(lt_engine* e, int32_t klass, int64_t max_event_launche
 
 /* ---- operator-level entry points (parity tests call each kernel through these) ---------------- */
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in/out, fp32 accumulate.  K % 64 == 0.
- * epilogue 0: plain, 1: SwiGLU on 32-row interleaved W (out has N/2 columns: silu(w1 x) * (w3 x)). */
+ * epilogue 0: plain, 1: SwiGLU on 32-row interleaved W (out has N/2 columns: silu(w1 x) * (w3 x)).
+ * variant 0: what the engine uses (tile shape / pipeline picked from the problem size); 1 / 2: 256x256 / 256x288 tiles;
+ * 3 / 4: the same with the ping-pong kernel; 5 / 6: single-barrier rendezvous kernel; 7 / 8: 128x128 / 64x128 small-M tiles. */
 int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, int32_t bias_dtype,
                     void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
                     void* stream);

@@ -647,7 +647,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 1>(GemmArgs);
 template __global__ void gemm_bf16_tn<4, 3, 2, 3, 0>(GemmArgs);
-template __global__ void gemm_bf16_tn<2, 2, 2, 2, 0>(GemmArgs);  // 128 x 128 classic loop (64-deep slabs: 128-byte rows per fetch)
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0>(GemmArgs);
@@ -749,11 +748,7 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 9, "gemm: unknown variant %d", variant);
-    if (variant == 9) {  // experiment: 128 x 128 classic loop
-        LT_REQUIRE(epilogue == 0 && !a.trace, "gemm variant 9: plain epilogue only");
-        return launch_cfg<2, 2, 2, 2, 0, false>(a, stream, ev0, ev1);
-    }
+    LT_REQUIRE(variant >= 0 && variant <= 8, "gemm: unknown variant %d", variant);
     const int cus = num_cus();
     const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);

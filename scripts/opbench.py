@@ -68,8 +68,6 @@ def bench_gemm(rounds, variants, zeros=False, shapes=SHAPES_CFG2, cold=0):
             outs[v] = out
 
             def fn(v=v, out=out):
-                if epi == 1 and v == 9:
-                    return
                 rot[0] = (rot[0] + 1) % len(Ws)
                 W = Ws[rot[0]]  # "3t0" = variant 3 with the ping-pong tail overlap switched off
                 # "7p3" = variant 7 under gemm_pipeline 3 (single-barrier loop)
@@ -197,6 +195,37 @@ def bench_elem(rounds):
         print(f"elem {kname:22s}: median {med*1e3:7.1f} us  {bytes_[kname]/med/1e9:6.2f} TB/s algorithmic", flush=True)
 
 
+def bench_insitu(rounds):
+    """Does an HBM-bound row kernel cost more right after an MFMA-bound GEMM (power-managed clocks) than on its own?
+    time([gemm, grn] x n) - time([gemm] x n)  vs  time([grn] x n)."""
+    L = lib()
+    B, N, d, F_ = 2, 4096, 2304, 6144
+    M = B * N
+    g = torch.Generator(device="cuda").manual_seed(4)
+    u = torch.randn(M, F_, device="cuda", generator=g).to(torch.bfloat16)
+    w2 = (torch.randn(d, F_, device="cuda", generator=g) / math.sqrt(F_)).to(torch.bfloat16)
+    x = torch.randn(M, d, device="cuda", generator=g).to(torch.bfloat16)
+    y = torch.empty(M, d, device="cuda", dtype=torch.bfloat16)
+    h = torch.empty_like(x)
+    w = torch.ones(d, device="cuda", dtype=torch.bfloat16)
+    mod = (0.1 * torch.randn(B, 4 * d, device="cuda", generator=g)).to(torch.bfloat16)
+
+    def gemm():
+        ok(L.lt_op_gemm_bf16(P(u), P(w2), P(None), 1, P(y), M, d, F_, 0, 0, stream()))
+
+    def grn():
+        ok(L.lt_op_gated_residual_norm(P(x), P(y), P(w), P(mod), 1, 0, P(w), P(mod[:, d:]), P(None), 1, 4 * d, P(h), B, N, d,
+                                       C.c_float(1e-5), C.c_float(1e-6), 1, stream()))
+
+    def both():
+        gemm()
+        grn()
+
+    r = ab({"gemm": gemm, "gemm+grn": both, "grn": grn}, rounds)
+    print(f"insitu: gemm {r['gemm'][0]*1e3:.1f} us, gemm+grn {r['gemm+grn'][0]*1e3:.1f} us -> grn after gemm "
+          f"{(r['gemm+grn'][0]-r['gemm'][0])*1e3:.1f} us ; grn alone {r['grn'][0]*1e3:.1f} us", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["gemm", "attn", "elem"])
@@ -216,6 +245,8 @@ if __name__ == "__main__":
                    cold=a.cold)
     if "gemm_moe" in a.what:
         bench_gemm_moe(a.rounds, [int(v) for v in a.gemm_variants.split(",")], cold=a.cold)
+    if "insitu" in a.what:
+        bench_insitu(a.rounds)
     if "attn" in a.what:
         bench_attn(a.rounds, [int(v) for v in a.attn_variants.split(",")])
     if "elem" in a.what:
