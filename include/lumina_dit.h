@@ -114,6 +114,14 @@ int lt_weights_ready(lt_engine* e); /* 0 if every required tensor has been uploa
  * layer RMSNorm_y -> wk_y/wv_y -> ky_norm K/V.  cap_feats [B,T,cap_dim], cap_mask int32 [B,T]. */
 int lt_prepare_prompt(lt_engine* e, const void* cap_feats_dev, int32_t cap_dtype,
                       const int32_t* cap_mask_dev, int32_t B, int32_t T, void* stream);
+/* Compositional (regional) conditioning - lumina_next_compositional_generation/models/model.py:852-890, :422-446: Y captions
+ * [Y,T,cap_dim] with masks; captions 0..Y-2 condition regions of the COND row (the latent grid cut into h_split x w_split cells,
+ * cell (i,j) -> caption (i+1)(j+1)-1 as in the reference), caption Y-1 conditions the whole UNCOND row; the adaLN conditioning
+ * is pooled from the one-row global caption [1,Tg,cap_dim].  Steps that follow run one image (batch 2).  A later
+ * lt_prepare_prompt switches back to plain per-row captions.  Needs max_batch >= Y. */
+int lt_prepare_prompt_regional(lt_engine* e, const void* cap_feats_dev, int32_t cap_dtype, const int32_t* cap_mask_dev,
+                               int32_t Y, int32_t T, const void* global_feats_dev, const int32_t* global_mask_dev,
+                               int32_t Tg, int32_t h_split, int32_t w_split, void* stream);
 /* class-conditional variants: labels int32 [B] (null class = num_classes) */
 int lt_prepare_labels(lt_engine* e, const int32_t* labels_dev, int32_t B, void* stream);
 

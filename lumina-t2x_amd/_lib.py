@@ -65,6 +65,7 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_set_weight": (_i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32, _vp]),
     "lt_weights_ready": (_i32, [_vp]),
     "lt_prepare_prompt": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "lt_prepare_prompt_regional": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "lt_prepare_labels": (_i32, [_vp, _vp, _i32, _vp]),
     "lt_forward": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(LtStepArgs), _vp]),
     "lt_forward_packed": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_i32), _vp, C.POINTER(_vp), C.POINTER(LtStepArgs), _vp]),

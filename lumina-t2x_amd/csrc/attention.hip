@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     int qrow = qb * 128 + wave * 32 + l31;
     const bool q_ok = qrow < p.N;
     if (!q_ok) qrow = p.N - 1;
-    const u16* qptr = p.q + ((size_t)bh * p.N + qrow) * HD;
+    const u16* qptr = p.q + ((size_t)((p.q_batch_map ? p.q_batch_map[b] : b) * p.H + h) * p.N + qrow) * HD;
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel_v2(AttnArgs p) {
     int qrow = qb * 128 + wave * 32 + l31;
     const bool q_ok = qrow < p.N;
     if (!q_ok) qrow = p.N - 1;
-    const u16* qptr = p.q + ((size_t)bh * p.N + qrow) * HD;
+    const u16* qptr = p.q + ((size_t)((p.q_batch_map ? p.q_batch_map[b] : b) * p.H + h) * p.N + qrow) * HD;
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -907,6 +907,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.Nkpad % 64 == 0 && a.Nkpad >= a.Nk && a.Nk > 0 && a.N > 0, "attention: bad key counts Nk=%d Nkpad=%d", a.Nk, a.Nkpad);
     LT_REQUIRE(!a.accumulate || a.gate != nullptr, "attention: accumulate mode needs a gate");
     LT_REQUIRE(a.scale > 0.f, "attention: softmax scale must be positive");
+    LT_REQUIRE(a.q_batch_map == nullptr || a.bias != nullptr, "attention: q_batch_map is built for the masked (text) kernels only");
     const int nqb = (a.N + 127) / 128;
     dim3 grid(a.B * a.H * nqb), block(256);
 #define LAUNCH_V1(HD_) hipLaunchKernelGGL(attn_fwd_kernel<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128), stream, a)

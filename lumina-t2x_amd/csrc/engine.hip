@@ -129,6 +129,12 @@ struct lt_engine {
     void *ys[2] = {nullptr, nullptr}, *ymid = nullptr, *kbuf[4] = {nullptr, nullptr, nullptr, nullptr};
     float* t_dev = nullptr;
     int t_cap = 0;
+    // compositional (regional) text conditioning (lt_prepare_prompt_regional): Y captions, the first Y-1 belong to regions of
+    // the cond row, the last to the uncond row; 0 = off
+    int reg_Y = 0, reg_h = 1, reg_w = 1;
+    u16* reg_txt = nullptr;    // [Y, max_tokens, d] per-caption text attention outputs
+    size_t reg_txt_elems = 0;
+    int* reg_qmap = nullptr;   // [max_batch] query batch of each caption
     int* pk_dev = nullptr;     // packed batches: [0,64) token counts, [64,128) grid widths
     int pk_host[128] = {0};
     std::vector<float> t_host;
@@ -408,6 +414,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
     LT_REQUIRE(a->io_dtype == LT_BF16 || a->io_dtype == LT_F32, "io_dtype must be bf16 or f32");
     LT_REQUIRE(e->prompt_B == B, "%s was called for batch %d, step has batch %d", v.labels ? "lt_prepare_labels" : "lt_prepare_prompt",
                e->prompt_B, B);
+    LT_REQUIRE(e->reg_Y == 0 || (B == 2 && !pk), "regional captions: one image per call (batch 2 = cond + uncond row), tensor input");
     if (!e->weights_ok && lt_weights_ready(e)) return 2;
     const int d = e->d, L = e->L, H = e->H, Hkv = e->Hkv, hd = e->hd, F = e->F, dkv = e->dkv, A = e->A;
     const int Npad = round_up(N, 64);
@@ -510,12 +517,24 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         at.B = B; at.H = H; at.Hkv = Hkv; at.N = N; at.Nk = N; at.Nkpad = Npad; at.hd = hd; at.scale = sm_scale;
         at.k_prescaled = 1;
         at.nk_batch = ntok_dev;
-        const bool fuse_text = v.text && attention_fuses_text(hd);
+        const bool regional = v.text && e->reg_Y > 0;
+        const bool fuse_text = v.text && !regional && attention_fuses_text(hd);
         if (fuse_text) {  // zero-init gated text cross-attention (model.py:420-434) inside the same launch
             at.tk = w.ky; at.tvt = w.vty; at.tbias = e->txt_bias; at.tgate = w.gate; at.Tk = e->prompt_T; at.Tkpad = e->prompt_Tpad;
         }
         if (attention(e, at, s)) return 1;
-        if (v.text && !fuse_text) {
+        if (regional) {
+            // compositional Next-DiT (lumina_next_compositional_generation/models/model.py:422-446): every caption attends the
+            // queries of its row (regional captions -> cond row 0, last caption -> uncond row 1) into its own buffer, then one
+            // pass applies region masks, tanh(gate), the caption sum and the residual add with the reference's rounding points
+            AttnArgs rt = at;
+            rt.B = e->reg_Y; rt.q_batch_map = e->reg_qmap; rt.k = w.ky; rt.vt = w.vty; rt.bias = e->txt_bias; rt.gate = nullptr;
+            rt.accumulate = 0; rt.out = e->reg_txt; rt.nk_batch = nullptr;
+            rt.Nk = e->prompt_T; rt.Nkpad = e->prompt_Tpad; rt.scale = (float)(1.0 / std::sqrt((double)hd));
+            if (attention(e, rt, s)) return 1;
+            ProfScope ps(e, 2, 0, s);
+            if (launch_region_text_combine(e->attn, e->reg_txt, w.gate, e->reg_Y, N, H, hd, Hp, Wp, e->reg_h, e->reg_w, s)) return 1;
+        } else if (v.text && !fuse_text) {
             at.k = w.ky; at.vt = w.vty; at.bias = e->txt_bias; at.gate = w.gate; at.accumulate = 1; at.nk_batch = nullptr;
             at.Nk = e->prompt_T; at.Nkpad = e->prompt_Tpad; at.scale = (float)(1.0 / std::sqrt((double)hd));
             if (attention(e, at, s)) return 1;
@@ -725,6 +744,8 @@ extern "C" void lt_destroy(lt_engine* e) {
     for (auto& b : e->allocs) (void)hipFree(b.p);
     if (e->t_dev) (void)hipFree(e->t_dev);
     if (e->pk_dev) (void)hipFree(e->pk_dev);
+    if (e->reg_txt) (void)hipFree(e->reg_txt);
+    if (e->reg_qmap) (void)hipFree(e->reg_qmap);
     for (int k = 0; k < 3; ++k)
         for (auto& pr : e->prof[k].ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete e;
@@ -753,6 +774,31 @@ extern "C" int lt_weights_ready(lt_engine* e) {
     return 0;
 }
 
+// per-layer text K / V of `Bc` captions (model.py:421-422, :602): RMSNorm_y -> wk_y | wv_y -> ky_norm, V^T
+static int prepare_caption_kv(lt_engine* e, int Bc, int T, int Tpad, hipStream_t s) {
+    const lt_config& c = e->cfg;
+    const int cap = e->cap, dkv = e->dkv;
+    for (int l = 0; l < e->L; ++l) {
+        LayerW& w = e->lw[l];
+        NormModArgs n;  // attention_y_norm (model.py:602)
+        n.x = e->capb; n.w = w.y_norm; n.scale = nullptr; n.shift = nullptr; n.out = e->capn;
+        n.rows = Bc * T; n.rows_per_batch = T; n.d = cap; n.ld_mod = 0; n.eps = c.norm_eps;
+        if (launch_rmsnorm_mod(n, s)) return 1;
+        GemmArgs g;  // wk_y | wv_y (model.py:421-422)
+        g.A = e->capn; g.W = w.wkvy; g.C = e->kvy; g.bias = nullptr; g.M = Bc * T; g.N = 2 * dkv; g.K = cap;
+        g.lda = cap; g.ldw = cap; g.ldc = 2 * dkv; g.bias_dtype = -1;
+        if (launch_gemm_bf16(g, 0, 0, s)) return 1;
+        QkPostArgs qa;  // ky_norm, no rotary (model.py:421)
+        qa.src = e->kvy; qa.ld_src = 2 * dkv; qa.col0 = 0; qa.B = Bc; qa.N = T; qa.heads = e->Hkv; qa.hd = e->hd;
+        qa.rope_mode = 0; qa.cs = nullptr; qa.t = nullptr; qa.grid_w = 1; qa.cs_len = 0; qa.ln_eps = 1e-5f; qa.watershed = 0.f;
+        qa.ln_w = c.qk_norm ? w.ky_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.ky_norm_b : nullptr; qa.dst = w.ky;
+        qa.out_scale = (float)(1.0 / std::sqrt((double)e->hd)) * LOG2E;  // SDPA default scale (model.py:427-432), folded like the self-attention K
+        if (launch_qk_norm_rope(qa, s)) return 1;
+        if (launch_v_transpose(e->kvy, 2 * dkv, dkv, w.vty, Bc, T, Tpad, e->Hkv, e->hd, s)) return 1;
+    }
+    return 0;
+}
+
 extern "C" int lt_prepare_prompt(lt_engine* e, const void* cap_feats_dev, int32_t cap_dtype, const int32_t* cap_mask_dev,
                                  int32_t B, int32_t T, void* stream) {
     LT_REQUIRE(e && cap_feats_dev && cap_mask_dev, "lt_prepare_prompt: null argument");
@@ -764,32 +810,55 @@ extern "C" int lt_prepare_prompt(lt_engine* e, const void* cap_feats_dev, int32_
     LT_REQUIRE(T >= 1 && T <= Tmax, "text length %d exceeds max_text %d", T, Tmax);
     LT_REQUIRE(cap_dtype == LT_BF16 || cap_dtype == LT_F32, "cap_feats dtype must be bf16 or f32");
     if (lt_weights_ready(e)) return 2;
-    const int Tpad = round_up(T, 64), cap = e->cap, dkv = e->dkv, A = e->A;
+    const int Tpad = round_up(T, 64), cap = e->cap, A = e->A;
     ProfScope ps(e, 2, 0, s);
     if (launch_cast_to_bf16(cap_feats_dev, cap_dtype, e->capb, (long long)B * T * cap, s)) return 1;
     if (launch_mask_to_bias(cap_mask_dev, e->txt_bias, B, T, Tpad, s)) return 1;
     // adaln_input's caption half (model.py:847-850)
     if (launch_cap_pool_ln(e->capb, LT_BF16, cap_mask_dev, e->capln_w, e->capln_b, e->cap_ln, B, T, cap, s)) return 1;
     if (launch_linear_small_m(e->cap_ln, e->cape_w, e->cape_b, e->cap_emb, B, A, cap, 0, s)) return 1;
-    for (int l = 0; l < e->L; ++l) {
-        LayerW& w = e->lw[l];
-        NormModArgs n;  // attention_y_norm (model.py:602)
-        n.x = e->capb; n.w = w.y_norm; n.scale = nullptr; n.shift = nullptr; n.out = e->capn;
-        n.rows = B * T; n.rows_per_batch = T; n.d = cap; n.ld_mod = 0; n.eps = c.norm_eps;
-        if (launch_rmsnorm_mod(n, s)) return 1;
-        GemmArgs g;  // wk_y | wv_y (model.py:421-422)
-        g.A = e->capn; g.W = w.wkvy; g.C = e->kvy; g.bias = nullptr; g.M = B * T; g.N = 2 * dkv; g.K = cap;
-        g.lda = cap; g.ldw = cap; g.ldc = 2 * dkv; g.bias_dtype = -1;
-        if (launch_gemm_bf16(g, 0, 0, s)) return 1;
-        QkPostArgs qa;  // ky_norm, no rotary (model.py:421)
-        qa.src = e->kvy; qa.ld_src = 2 * dkv; qa.col0 = 0; qa.B = B; qa.N = T; qa.heads = e->Hkv; qa.hd = e->hd;
-        qa.rope_mode = 0; qa.cs = nullptr; qa.t = nullptr; qa.grid_w = 1; qa.cs_len = 0; qa.ln_eps = 1e-5f; qa.watershed = 0.f;
-        qa.ln_w = c.qk_norm ? w.ky_norm_w : nullptr; qa.ln_b = c.qk_norm ? w.ky_norm_b : nullptr; qa.dst = w.ky;
-        qa.out_scale = (float)(1.0 / std::sqrt((double)e->hd)) * LOG2E;  // SDPA default scale (model.py:427-432), folded like the self-attention K
-        if (launch_qk_norm_rope(qa, s)) return 1;
-        if (launch_v_transpose(e->kvy, 2 * dkv, dkv, w.vty, B, T, Tpad, e->Hkv, e->hd, s)) return 1;
+    if (prepare_caption_kv(e, B, T, Tpad, s)) return 1;
+    e->prompt_B = B; e->prompt_T = T; e->prompt_Tpad = Tpad; e->reg_Y = 0;
+    return 0;
+}
+
+extern "C" int lt_prepare_prompt_regional(lt_engine* e, const void* cap_feats_dev, int32_t cap_dtype, const int32_t* cap_mask_dev,
+                                          int32_t Y, int32_t T, const void* global_feats_dev, const int32_t* global_mask_dev,
+                                          int32_t Tg, int32_t h_split, int32_t w_split, void* stream) {
+    LT_REQUIRE(e && cap_feats_dev && cap_mask_dev && global_feats_dev && global_mask_dev, "lt_prepare_prompt_regional: null argument");
+    LT_REQUIRE(e->cfg.variant == LT_VARIANT_NEXT_T2I, "lt_prepare_prompt_regional: text-conditional Next-DiT only");
+    hipStream_t s = (hipStream_t)stream;
+    const lt_config& c = e->cfg;
+    const int Tmax = round_up(c.max_text > 0 ? c.max_text : 64, 64);
+    LT_REQUIRE(Y >= 2 && Y <= c.max_batch, "%d captions exceed max_batch %d (the caption buffers are sized by it)", Y, c.max_batch);
+    LT_REQUIRE(T >= 1 && T <= Tmax && Tg >= 1 && Tg <= Tmax, "text length %d / %d exceeds max_text %d", T, Tg, Tmax);
+    LT_REQUIRE(h_split >= 1 && w_split >= 1, "lt_prepare_prompt_regional: split counts must be >= 1");
+    LT_REQUIRE(cap_dtype == LT_BF16 || cap_dtype == LT_F32, "cap_feats dtype must be bf16 or f32");
+    if (lt_weights_ready(e)) return 2;
+    const int Tpad = round_up(T, 64), cap = e->cap, A = e->A;
+    ProfScope ps(e, 2, 0, s);
+    // adaLN conditioning from the GLOBAL caption, one row broadcast to the cond and the uncond row (model.py:866-870: the
+    // pooled [1, C] embedding is added to t_emb [2, A])
+    if (launch_cast_to_bf16(global_feats_dev, cap_dtype, e->capb, (long long)Tg * cap, s)) return 1;
+    if (launch_cap_pool_ln(e->capb, LT_BF16, global_mask_dev, e->capln_w, e->capln_b, e->cap_ln, 1, Tg, cap, s)) return 1;
+    if (launch_linear_small_m(e->cap_ln, e->cape_w, e->cape_b, e->cap_emb, 1, A, cap, 0, s)) return 1;
+    LT_CHECK_HIP(hipMemcpyAsync(e->cap_emb + A, e->cap_emb, (size_t)A * 2, hipMemcpyDeviceToDevice, s));
+    // the Y captions' keys / values
+    if (launch_cast_to_bf16(cap_feats_dev, cap_dtype, e->capb, (long long)Y * T * cap, s)) return 1;
+    if (launch_mask_to_bias(cap_mask_dev, e->txt_bias, Y, T, Tpad, s)) return 1;
+    if (prepare_caption_kv(e, Y, T, Tpad, s)) return 1;
+    const size_t need = (size_t)Y * c.max_tokens * e->d;
+    if (e->reg_txt_elems < need) {
+        if (e->reg_txt) LT_CHECK_HIP(hipFree(e->reg_txt));
+        LT_CHECK_HIP(hipMalloc((void**)&e->reg_txt, need * 2));
+        e->reg_txt_elems = need;
     }
-    e->prompt_B = B; e->prompt_T = T; e->prompt_Tpad = Tpad;
+    if (!e->reg_qmap) LT_CHECK_HIP(hipMalloc((void**)&e->reg_qmap, (size_t)c.max_batch * sizeof(int)));
+    std::vector<int> qmap(Y, 0);
+    qmap[Y - 1] = 1;
+    LT_CHECK_HIP(hipMemcpyAsync(e->reg_qmap, qmap.data(), (size_t)Y * sizeof(int), hipMemcpyHostToDevice, s));
+    LT_CHECK_HIP(hipStreamSynchronize(s));  // qmap is a stack temporary
+    e->prompt_B = 2; e->prompt_T = T; e->prompt_Tpad = Tpad; e->reg_Y = Y; e->reg_h = h_split; e->reg_w = w_split;
     return 0;
 }
 

@@ -105,7 +105,14 @@ struct AttnArgs {
     unsigned long long* trace = nullptr;  // diagnostics only (lt_op_attention_trace)
     // packed variable-resolution batches (model.py:789-834): valid keys of sample b = nk_batch[b] <= Nk (device array, or null)
     const int* nk_batch = nullptr;
+    // regional (compositional) text attention: key/value/bias/output batch b attends the queries of batch q_batch_map[b]
+    // (several captions share one image's queries); device array [B] or null.  Masked (bias != null) kernels only.
+    const int* q_batch_map = nullptr;
 };
+// out[b] = bf16(out[b] + bf16(sum_r region_r(n) * bf16(bf16(txt[r]) * tanh(gate[h]))))  - the caption sum of the compositional
+// Next-DiT (lumina_next_compositional_generation/models/model.py:422-446); see misc.hip
+int launch_region_text_combine(u16* out, const u16* txt, const u16* gate, int Y, int N, int H, int hd, int Hp, int Wp,
+                               int h_split, int w_split, hipStream_t stream);
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)

@@ -277,6 +277,63 @@ __global__ void fill_rows_bf16_kernel(u16* dst, const u16* row, long long rows, 
         dst[i] = row[i % d];
 }
 
+// Compositional Next-DiT text branch (lumina_next_compositional_generation/models/model.py:422-446).  txt[r] = SDPA of the
+// image's queries against caption r (r < Y-1: regional captions of the COND row, r = Y-1: the caption of the UNCOND row),
+// already rounded to bf16 as SDPA returns it under autocast.  Reference order of operations:
+//   output_y = nan_to_num(SDPA(..., y_mask & region_mask))      tokens outside region r have every key masked -> NaN -> 0
+//   output_y = output_y * tanh(gate)                            bf16 * bf16 -> bf16
+//   cond = sum(output_y[:-1], dim 0) ; uncond = output_y[-1]    fp32 accumulation inside torch.sum, one rounding
+//   output = output + output_y                                  bf16
+// region_mask (model.py:872-887): the latent grid is cut into h_split x w_split cells of (Hp / h_split) x (Wp / w_split)
+// tokens; cell (i, j) switches on caption (i + 1) * (j + 1) - 1 (the reference's formula, kept as is: cells can share a
+// caption and some captions stay empty); tokens beyond the last full cell belong to no region; the last caption covers all.
+__global__ void region_text_combine_kernel(u16* __restrict__ out, const u16* __restrict__ txt, const u16* __restrict__ gate,
+                                           int Y, int N, int H, int hd, int Hp, int Wp, int h_split, int w_split) {
+    const int d = H * hd, chunks = d >> 3;
+    const long long total = (long long)2 * N * chunks;
+    const int hps = Hp / h_split, wps = Wp / w_split;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const long long rown = i / chunks;
+        const int b = (int)(rown / N), n = (int)(rown % N);
+        const int head = (c * 8) / hd;
+        const float g = bfr(tanhf(bf2f(gate[head])));
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        if (b == 0) {
+            const int gr = n / Wp, gc = n - gr * Wp;
+            const int ci = hps > 0 ? gr / hps : h_split, cj = wps > 0 ? gc / wps : w_split;
+            const int region = (ci < h_split && cj < w_split) ? (ci + 1) * (cj + 1) - 1 : -1;
+            if (region >= 0 && region < Y - 1) {  // exactly one regional caption can be on for a token
+                const bf8_t t = *(const bf8_t*)(txt + ((size_t)region * N + n) * d + c * 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x2 v = unpk_bf(t.w[k]);
+                    acc[2 * k] = bfr(v[0] * g);
+                    acc[2 * k + 1] = bfr(v[1] * g);
+                }
+            }
+        } else {
+            const bf8_t t = *(const bf8_t*)(txt + ((size_t)(Y - 1) * N + n) * d + c * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x2 v = unpk_bf(t.w[k]);
+                acc[2 * k] = bfr(v[0] * g);
+                acc[2 * k + 1] = bfr(v[1] * g);
+            }
+        }
+        u16* o = out + ((size_t)b * N + n) * d + c * 8;
+        bf8_t cur = *(const bf8_t*)o, res;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x2 v = unpk_bf(cur.w[k]);
+            res.w[k] = pk_bf(f32x2{v[0] + acc[2 * k], v[1] + acc[2 * k + 1]});
+        }
+        *(bf8_t*)o = res;
+    }
+}
+
 inline int nblk(long long n, int bs) { return (int)((n + bs - 1) / bs); }
 
 }  // namespace
@@ -362,6 +419,16 @@ int launch_unpatchify_cfg(const u16* rows, int ld, void* out, int out_dtype, int
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(unpatchify_cfg_kernel, dim3(g), dim3(256), 0, stream, rows, ld, out, out_dtype, B, C, out_ch, H,
                        W, patch, use_cfg, cfg_scale, cfg_channels, wp_stride > 0 ? wp_stride : W / patch);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_region_text_combine(u16* out, const u16* txt, const u16* gate, int Y, int N, int H, int hd, int Hp, int Wp,
+                               int h_split, int w_split, hipStream_t stream) {
+    LT_REQUIRE(Y >= 2 && h_split >= 1 && w_split >= 1 && hd % 8 == 0, "region_text_combine: bad arguments");
+    int g = nblk((long long)2 * N * (H * hd / 8), 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(region_text_combine_kernel, dim3(g), dim3(256), 0, stream, out, txt, gate, Y, N, H, hd, Hp, Wp, h_split, w_split);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

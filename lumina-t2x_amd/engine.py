@@ -114,6 +114,30 @@ class DiTEngine:
         self._keep = (feats, mask)  # keep the temporaries alive until the stream has consumed them
         self._prompt_key = key
 
+    def prepare_prompt_regional(self, cap_feats: torch.Tensor, cap_mask: torch.Tensor, global_feats: torch.Tensor,
+                                global_mask: torch.Tensor, h_split: int, w_split: int) -> None:
+        """compositional Next-DiT: Y captions (regions of the cond row ..., uncond row) + the one-row global caption"""
+        _require_gpu(cap_feats, "cap_feats")
+        key = ("regional", cap_feats.data_ptr(), cap_feats._version, tuple(cap_feats.shape), cap_feats.dtype, cap_mask.data_ptr(),
+               cap_mask._version, global_feats.data_ptr(), global_feats._version, tuple(global_feats.shape), global_mask.data_ptr(),
+               global_mask._version, h_split, w_split)
+        if key == self._prompt_key:
+            return
+        dt = cap_feats.dtype if cap_feats.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        feats = cap_feats.to(dt).contiguous()
+        gfeats = global_feats.to(device=feats.device, dtype=dt).contiguous()
+        mask = cap_mask.to(device=feats.device, dtype=torch.int32).contiguous()
+        gmask = global_mask.to(device=feats.device, dtype=torch.int32).contiguous()
+        Y, T, _ = feats.shape
+        with torch.cuda.device(self.device):
+            rc = self.lib.lt_prepare_prompt_regional(self.handle, C.c_void_p(feats.data_ptr()), _DT[feats.dtype],
+                                                     C.c_void_p(mask.data_ptr()), Y, T, C.c_void_p(gfeats.data_ptr()),
+                                                     C.c_void_p(gmask.data_ptr()), gfeats.shape[1], int(h_split), int(w_split),
+                                                     C.c_void_p(_stream_ptr(self.device)))
+        _lib.check(rc, "lt_prepare_prompt_regional")
+        self._keep = (feats, mask, gfeats, gmask)
+        self._prompt_key = key
+
     def prepare_labels(self, y: torch.Tensor) -> None:
         """class-conditional variants: y int [B] (null class = num_classes, Next-DiT-ImageNet/sample.py:181)"""
         _require_gpu(y, "y")

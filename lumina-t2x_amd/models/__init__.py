@@ -4,6 +4,7 @@
   ``models.imagenet``        Next-DiT-ImageNet/models          DiT_Llama, DiT_Llama_600M_patch2, ... (class-conditional)
   ``models.flag_dit``        lumina_t2i/models                 DiT_Llama, DiT_Llama_5B_patch2 (Flag-DiT)
   ``models.moe``             Next-DiT-MoE/models (models2.py)  DiT_Llama, DiT_Llama_600M_patch2_Both (time + space MoE)
+  ``models.compositional``   lumina_next_compositional_generation/models   NextDiT with regional text cross-attention
 """
-from . import flag_dit, imagenet, moe  # noqa: F401
+from . import compositional, flag_dit, imagenet, moe  # noqa: F401
 from .model import NextDiT, NextDiT_2B_GQA_patch2, NextDiT_2B_patch2  # noqa: F401

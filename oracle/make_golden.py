@@ -134,6 +134,44 @@ def packed_case(name, cfg, sizes, text_len, seed_w, seed_x):
     print(f"{name}.npz:", sizes, {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 1})
 
 
+def compositional_case(name, cfg, latent_hw, splits, text_len, seed_w, seed_x):
+    """lumina_next_compositional_generation NextDiT (regional cross-attention, models/model.py:422-446, :852-955): the
+    unmodified reference on CPU fp32.  Y = regions + 1 captions, global caption separate (demo.py:208-228)."""
+    sd = synth.synth_state_dict(cfg, seed=seed_w)
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
+        del sys.modules[m]
+    R.load_reference("lumina_next_compositional_generation")
+    M = importlib.import_module("models.model")
+    assert "compositional" in M.__file__
+    model = M.NextDiT(**cfg.ctor_kwargs()).eval()
+    model.load_state_dict(sd, strict=True)
+    rng = np.random.default_rng(seed_x)
+    h_split, w_split = splits
+    n_reg = h_split * w_split
+    Y = n_reg + 1
+    H, W = latent_hw
+    z = torch.from_numpy(rng.standard_normal((1, cfg.in_channels, H, W), dtype=np.float32)).repeat(2, 1, 1, 1)
+    t = torch.full((2,), 0.45, dtype=torch.float32)
+    cap = torch.from_numpy(rng.standard_normal((Y, text_len, cfg.cap_feat_dim), dtype=np.float32))
+    mask = torch.ones(Y, text_len, dtype=torch.int32)
+    for r in range(Y):
+        mask[r, text_len - (2 * r) % 7:] = 0 if (2 * r) % 7 else 1
+    mask[Y - 1, 8:] = 0  # negative / empty caption
+    gcap = torch.from_numpy(rng.standard_normal((1, text_len + 8, cfg.cap_feat_dim), dtype=np.float32))
+    gmask = torch.ones(1, text_len + 8, dtype=torch.int32)
+    gmask[0, -5:] = 0
+    out = {"config": np.array(json.dumps(cfg.to_dict())), "seed_w": seed_w, "seed_x": seed_x, "splits": np.array(splits, dtype=np.int32),
+           "z": _np(z), "t": _np(t), "cap": _np(cap), "mask": _np(mask), "gcap": _np(gcap), "gmask": _np(gmask)}
+    kw = dict(global_cap_feats=gcap, global_cap_mask=gmask.bool(), h_split_num=h_split, w_split_num=w_split)
+    with torch.no_grad():
+        out["cfg4_prop"] = _np(model.forward_with_cfg(z, t, cap, mask.bool(), 4.0, scale_factor=1.0, scale_watershed=1.0,
+                                                      base_seqlen=16, proportional_attn=True, **kw))
+        out["cfg1_plain"] = _np(model.forward_with_cfg(z, t, cap, mask.bool(), 1.0, **kw))
+        out["forward"] = _np(model(z, t, cap, mask.bool(), gcap, gmask.bool(), h_split, w_split))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}.npz:", {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 1})
+
+
 def _fresh_import(pkg, module):
     """import <pkg>/<module> of the reference with a clean `models` namespace (every sub-project calls its package `models`)"""
     for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
@@ -227,6 +265,8 @@ def main():
     family_case("flag_tiny", synth.TINY_FLAG, (16, 24), 11, 12)
     mini_ode_kats()
     packed_case("nextdit_tiny_packed", synth.TINY, [(16, 16), (12, 20), (8, 24), (16, 16)], 16, 13, 14)
+    compositional_case("compositional_tiny", synth.TINY, (16, 24), (2, 2), 16, 15, 16)
+    compositional_case("compositional_tiny_1x3", synth.TINY, (12, 24), (1, 3), 13, 17, 18)
 
 
 if __name__ == "__main__":

@@ -69,8 +69,10 @@ def _sd(sd: Dict[str, torch.Tensor], bf16: bool) -> Dict[str, torch.Tensor]:
     return {k: _r(v.float(), bf16) for k, v in sd.items()}
 
 
-def attention(sd, p, cfg: NextDiTConfig, x, freqs_cis, y, y_mask, softmax_scale, bf16):
-    """Attention.forward, model.py:337-438 (mask all ones; fp32 SDPA branch :407-418; text branch :420-434)."""
+def attention(sd, p, cfg: NextDiTConfig, x, freqs_cis, y, y_mask, softmax_scale, bf16, region_mask=None):
+    """Attention.forward, model.py:337-438 (mask all ones; fp32 SDPA branch :407-418; text branch :420-434).
+    ``region_mask`` [Y, N] bool switches on the compositional text branch
+    (lumina_next_compositional_generation/models/model.py:422-446)."""
     B, N, _ = x.shape
     H, Hkv, hd = cfg.n_heads, cfg.kv_heads, cfg.head_dim
     xq = _linear(x, sd[p + "wq.weight"], None, bf16)
@@ -89,7 +91,26 @@ def attention(sd, p, cfg: NextDiTConfig, x, freqs_cis, y, y_mask, softmax_scale,
     q_ = xq.permute(0, 2, 1, 3)
     out = F.scaled_dot_product_attention(q_, kk.permute(0, 2, 1, 3), vv.permute(0, 2, 1, 3), scale=softmax_scale)
     out = _r(out.permute(0, 2, 1, 3), bf16)
-    if (p + "wk_y.weight") in sd:
+    if (p + "wk_y.weight") in sd and region_mask is not None:
+        # Y captions for ONE image (B = 2 rows): captions 0..Y-2 attend the cond row's queries inside their regions, the
+        # last caption the uncond row's; fully masked query rows give NaN -> nan_to_num -> 0; gate; sum over the cond captions
+        Y, T = y.shape[0], y.shape[1]
+        qy = torch.cat([q_[0:1].expand(Y - 1, -1, -1, -1), q_[-1:]], dim=0)
+        yk = _linear(y, sd[p + "wk_y.weight"], None, bf16)
+        if cfg.qk_norm:
+            yk = F.layer_norm(yk, (Hkv * hd,), sd[p + "ky_norm.weight"], sd[p + "ky_norm.bias"], 1e-5)
+        yk = _r(yk, bf16).view(Y, T, Hkv, hd)
+        yv = _linear(y, sd[p + "wv_y.weight"], None, bf16).view(Y, T, Hkv, hd)
+        if rep > 1:
+            yk, yv = yk.repeat_interleave(rep, dim=2), yv.repeat_interleave(rep, dim=2)
+        m = y_mask.bool().view(Y, 1, 1, T).expand(Y, H, N, T) & region_mask.view(Y, 1, N, 1)
+        oy = F.scaled_dot_product_attention(qy, yk.permute(0, 2, 1, 3), yv.permute(0, 2, 1, 3), m)
+        oy = torch.nan_to_num(_r(oy.permute(0, 2, 1, 3), bf16))
+        gate = _r(torch.tanh(sd[p + "gate"]), bf16).view(1, 1, -1, 1)
+        oy = _r(oy * gate, bf16)
+        oy = torch.cat([_r(oy[:-1].sum(dim=0, keepdim=True), bf16), oy[-1:]], dim=0)
+        out = _r(out + oy, bf16)
+    elif (p + "wk_y.weight") in sd:
         T = y.shape[1]
         yk = _linear(y, sd[p + "wk_y.weight"], None, bf16)
         if cfg.qk_norm:
@@ -113,7 +134,7 @@ def feed_forward(sd, p, x, bf16):
     return _linear(_r(_r(F.silu(a), bf16) * b, bf16), sd[p + "w2.weight"], None, bf16)
 
 
-def block(sd, i, cfg: NextDiTConfig, x, freqs_cis, y, y_mask, adaln_input, softmax_scale, bf16):
+def block(sd, i, cfg: NextDiTConfig, x, freqs_cis, y, y_mask, adaln_input, softmax_scale, bf16, region_mask=None):
     """TransformerBlock.forward, model.py:573-624 (adaLN branch)."""
     p = f"layers.{i}."
     mod = _linear(_r(F.silu(adaln_input), bf16), sd[p + "adaLN_modulation.1.weight"], sd[p + "adaLN_modulation.1.bias"], bf16)
@@ -125,7 +146,7 @@ def block(sd, i, cfg: NextDiTConfig, x, freqs_cis, y, y_mask, adaln_input, softm
     eps = cfg.norm_eps
     yn = rmsnorm(y, sd[p + "attention_y_norm.weight"], eps, bf16)
     a = attention(sd, p + "attention.", cfg, modulate(rmsnorm(x, sd[p + "attention_norm1.weight"], eps, bf16), scale_msa),
-                  freqs_cis, yn, y_mask, softmax_scale, bf16)
+                  freqs_cis, yn, y_mask, softmax_scale, bf16, region_mask)
     x = _r(x + _r(_r(torch.tanh(gate_msa), bf16).unsqueeze(1) * rmsnorm(a, sd[p + "attention_norm2.weight"], eps, bf16), bf16), bf16)
     f = feed_forward(sd, p + "feed_forward.", modulate(rmsnorm(x, sd[p + "ffn_norm1.weight"], eps, bf16), scale_mlp), bf16)
     x = _r(x + _r(_r(torch.tanh(gate_mlp), bf16).unsqueeze(1) * rmsnorm(f, sd[p + "ffn_norm2.weight"], eps, bf16), bf16), bf16)
@@ -134,9 +155,12 @@ def block(sd, i, cfg: NextDiTConfig, x, freqs_cis, y, y_mask, adaln_input, softm
 
 def forward(sd_in: Dict[str, torch.Tensor], cfg: NextDiTConfig, x, t, cap_feats, cap_mask, *, freqs_table=None,
             proportional_attn: bool = False, base_seqlen: Optional[int] = None, bf16: bool = False,
-            n_layers: Optional[int] = None, return_hidden: bool = False, scale_seqlen: Optional[int] = None):
+            n_layers: Optional[int] = None, return_hidden: bool = False, scale_seqlen: Optional[int] = None,
+            regional: Optional[dict] = None):
     """NextDiT.forward, model.py:836-864 (tensor input path :774-788).  ``scale_seqlen`` overrides the sequence length the
-    proportional-attention scale is computed from (the padded length of a packed batch, see forward_packed)."""
+    proportional-attention scale is computed from (the padded length of a packed batch, see forward_packed).
+    ``regional`` = dict(global_cap_feats [1,Tg,C], global_cap_mask [1,Tg], h_split_num, w_split_num) runs the compositional
+    variant (lumina_next_compositional_generation/models/model.py:852-899): cap_feats then holds Y captions for the B = 2 rows."""
     sd = _sd(sd_in, bf16)
     p = cfg.patch_size
     B, C, H, W = x.shape
@@ -153,8 +177,21 @@ def forward(sd_in: Dict[str, torch.Tensor], cfg: NextDiTConfig, x, t, cap_feats,
     te = _linear(tf, sd["t_embedder.mlp.0.weight"], sd["t_embedder.mlp.0.bias"], bf16)
     te = _linear(_r(F.silu(te), bf16), sd["t_embedder.mlp.2.weight"], sd["t_embedder.mlp.2.bias"], bf16)
     cf = _r(cap_feats.float(), bf16)
-    mf = cap_mask.float().unsqueeze(-1)
-    pool = _r((cf * mf).sum(dim=1) / mf.sum(dim=1), bf16)
+    region_mask = None
+    if regional is None:
+        pool_f, mf = cf, cap_mask.float().unsqueeze(-1)
+    else:  # pooled conditioning from the global caption (:866-870); region masks (:872-887, the reference's region-id formula)
+        pool_f, mf = _r(regional["global_cap_feats"].float(), bf16), regional["global_cap_mask"].float().unsqueeze(-1)
+        hs, ws = int(regional["h_split_num"]), int(regional["w_split_num"])
+        Y = cap_feats.shape[0]
+        rm = torch.zeros(Y, H // p, W // p)
+        hps, wps = H // hs // p, W // ws // p
+        for i in range(hs):
+            for j in range(ws):
+                rm[(i + 1) * (j + 1) - 1, hps * i: hps * (i + 1), wps * j: wps * (j + 1)] = 1
+        rm[-1] = 1
+        region_mask = rm.flatten(1, 2) > 0.5
+    pool = _r((pool_f * mf).sum(dim=1) / mf.sum(dim=1), bf16)
     pool = F.layer_norm(pool, (cfg.cap_feat_dim,), sd["cap_embedder.0.weight"], sd["cap_embedder.0.bias"], 1e-5)
     cap_emb = _linear(_r(pool, bf16), sd["cap_embedder.1.weight"], sd["cap_embedder.1.bias"], bf16)
     adaln_input = _r(te + cap_emb, bf16)
@@ -165,7 +202,7 @@ def forward(sd_in: Dict[str, torch.Tensor], cfg: NextDiTConfig, x, t, cap_feats,
     L = cfg.n_layers if n_layers is None else n_layers
     hidden = []
     for i in range(L):
-        h = block(sd, i, cfg, h, freqs_cis, cf, cap_mask, adaln_input, scale, bf16)
+        h = block(sd, i, cfg, h, freqs_cis, cf, cap_mask, adaln_input, scale, bf16, region_mask)
         if return_hidden:
             hidden.append(h)
     # final layer (:657-662): affine-free LayerNorm eps 1e-6 in fp32, modulate in fp32, Linear in bf16
@@ -195,13 +232,13 @@ def forward_packed(sd, cfg: NextDiTConfig, xs, t, cap_feats, cap_mask, *, propor
 
 
 def forward_with_cfg(sd, cfg: NextDiTConfig, x, t, cap_feats, cap_mask, cfg_scale, scale_factor=1.0,
-                     scale_watershed=1.0, base_seqlen=None, proportional_attn=False, bf16=False, n_layers=None):
-    """NextDiT.forward_with_cfg, model.py:866-913 (RoPE table chosen from t[0], CFG on channels [:3])."""
+                     scale_watershed=1.0, base_seqlen=None, proportional_attn=False, bf16=False, n_layers=None, regional=None):
+    """NextDiT.forward_with_cfg, model.py:866-913 (RoPE table chosen from t[0], CFG on channels [:3]); ``regional``: see forward."""
     table = rope_table(cfg.head_dim, 384, scale_factor=scale_factor, scale_watershed=scale_watershed,
                        timestep=float(t[0]))
     half = x[: len(x) // 2]
     out = forward(sd, cfg, torch.cat([half, half], dim=0), t, cap_feats, cap_mask, freqs_table=table,
-                  proportional_attn=proportional_attn, base_seqlen=base_seqlen, bf16=bf16, n_layers=n_layers)
+                  proportional_attn=proportional_attn, base_seqlen=base_seqlen, bf16=bf16, n_layers=n_layers, regional=regional)
     eps, rest = out[:, :3], out[:, 3:]
     cond, uncond = torch.split(eps, len(eps) // 2, dim=0)
     half_eps = _r(uncond + _r(cfg_scale * _r(cond - uncond, bf16), bf16), bf16)

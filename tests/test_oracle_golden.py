@@ -201,3 +201,29 @@ def test_oracle_packed_variable_resolution_matches_reference_list_path(golden_di
     short = min(range(len(sizes)), key=lambda b: sizes[b][0] * sizes[b][1])
     solo, packed = torch.from_numpy(g[f"solo_prop{short}"]), torch.from_numpy(g[f"yprop{short}"])
     assert float((solo - packed).norm() / packed.norm()) > 1e-3
+
+
+@pytest.mark.parametrize("name", ["compositional_tiny", "compositional_tiny_1x3"])
+def test_oracle_compositional_regional_attention_matches_reference(golden_dir, name):
+    """lumina_next_compositional_generation NextDiT (regional text cross-attention, models/model.py:422-446, :852-955): oracle
+    vs the unmodified reference (CPU fp32) - region masks incl. the reference's region-id formula, per-caption attention of
+    the cond row, nan_to_num of fully masked rows, caption sum, global-caption adaLN conditioning."""
+    g = _load(golden_dir, name)
+    cfg = _cfg(g)
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    z, t, cap, mask = (torch.from_numpy(g[k]) for k in ("z", "t", "cap", "mask"))
+    hs, ws = (int(v) for v in g["splits"])
+    reg = dict(global_cap_feats=torch.from_numpy(g["gcap"]), global_cap_mask=torch.from_numpy(g["gmask"]), h_split_num=hs, w_split_num=ws)
+    assert cap.shape[0] == hs * ws + 1
+    cases = {"cfg4_prop": dict(cfg_scale=4.0, scale_factor=1.0, scale_watershed=1.0, base_seqlen=16, proportional_attn=True),
+             "cfg1_plain": dict(cfg_scale=1.0)}
+    for key, kw in cases.items():
+        got = O.forward_with_cfg(sd, cfg, z, t, cap, mask, regional=reg, **kw)
+        ref = torch.from_numpy(g[key])
+        assert float((got - ref).norm() / ref.norm()) < 2e-5, key
+    got = O.forward(sd, cfg, z, t, cap, mask, regional=reg)
+    ref = torch.from_numpy(g["forward"])
+    assert float((got - ref).norm() / ref.norm()) < 2e-5
+    # the regions matter: the plain model on (first regional caption, negative caption) gives something else
+    plain = O.forward(sd, cfg, z, t, cap[[0, -1]], mask[[0, -1]])
+    assert float((plain - ref).norm() / ref.norm()) > 1e-2
