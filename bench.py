@@ -116,10 +116,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine A/B knob name=value (lt_set_option), repeatable")
-    ap.add_argument("--event-steps", type=int, default=1,
+    ap.add_argument("--event-steps", type=float, default=0.5,
                     help="NFEs of the timed region whose GEMM launches carry HIP start/stop events (0 = all).  A timed launch "
                          "costs ~0.1 ms of queue idle time on this stack (the host waits on the dispatch signal), so the default "
-                         "samples one NFE = 98 launches = every GEMM shape x 24 layers; all NFEs have the same launch mix")
+                         "samples the first half NFE = 49 launches = embedder + every GEMM shape x 12 layers (every layer and "
+                         "every NFE has the same four shapes): 5 ms in the timed region instead of 10")
     ap.add_argument("--profile-classes", type=int, default=1,
                     help="bit mask of kernel classes bracketed by HIP events IN THE TIMED REGION: 1 GEMM (the roofline kernel, "
                          "default), 2 attention, 4 other.  Every bracketed launch costs two event packets (all classes: +4 %% "
@@ -178,7 +179,8 @@ def main():
     # HIP start/stop events on the GEMM dispatches of the first --event-steps NFE of the timed region (every NFE has the
     # same launch mix; timing all of them costs ~2.5 ms per NFE of queue idle time, which would be charged to `value`)
     gemm_launches_per_nfe = 4 * model.n_layers + 2
-    eng.profile_set_budget(0, -1 if args.event_steps <= 0 else args.event_steps * gemm_launches_per_nfe)
+    event_launches = -1 if args.event_steps <= 0 else max(1, int(round(args.event_steps * gemm_launches_per_nfe)))
+    eng.profile_set_budget(0, event_launches)
     eng.profile_reset()
     parallel.barrier()
     torch.cuda.synchronize()
@@ -233,7 +235,7 @@ def main():
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
                 "traffic_source": traffic_src,
                 "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
-                "event_bracketed_launches": (gemm_n if args.event_steps <= 0 else min(gemm_n, args.event_steps * gemm_launches_per_nfe)),
+                "event_bracketed_launches": (gemm_n if event_launches < 0 else min(gemm_n, event_launches)),
                 "algorithmic_flops_per_launch": gemm_fl / max(gemm_n, 1),
             },
             "kernel_time_ms_per_step": dict(breakdown, note=f"untimed pass of {nb} NFE with events around every launch"),
