@@ -147,6 +147,121 @@ __global__ __launch_bounds__(64 * QK_WAVES) void qk_norm_rope_kernel(QkPostArgs 
     qk_norm_rope_block<MAXCH>(p, blockIdx.x, smem_raw);
 }
 
+// Persistent form (stand-alone launches): about two workgroups per CU, each wave walks rows with a grid stride and keeps the
+// NEXT row's loads in flight while it works on the current one.  With one workgroup per 16 rows the whole grid was resident at
+// once and ran in lock step - everybody loads, then everybody computes, then everybody stores - which left the memory system
+// idle between the phases (2.8 TB/s); staggered waves stream continuously.  LayerNorm weights are staged once per workgroup;
+// each wave stages its own row's rotary factors (36 x 8 bytes) in its private LDS strip.
+template <int MAXCH>
+__global__ __launch_bounds__(64 * QK_WAVES) void qk_norm_rope_persistent_kernel(QkPostArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rows = p.B * p.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int width = p.heads * p.hd;
+    const int nch = width >> 3;
+    const int cph = p.hd >> 3;
+    const int nslot = p.hd >> 1;
+    u16* sw = (u16*)smem;
+    u16* sb = sw + width;
+    float2* st = (float2*)(smem + (size_t)width * 4) + wave * nslot;  // this wave's strip
+    const int stride = gridDim.x * QK_WAVES;
+    int row = blockIdx.x * QK_WAVES + wave;
+
+    auto load_row = [&](int r, bf8_t (&raw)[MAXCH]) __attribute__((always_inline)) {
+        const u16* src = p.src + (size_t)(r < rows ? r : rows - 1) * p.ld_src + p.col0;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) raw[i] = *(const bf8_t*)(src + c * 8);
+            else raw[i].w[0] = raw[i].w[1] = raw[i].w[2] = raw[i].w[3] = 0u;
+        }
+    };
+    bf8_t cur[MAXCH], nxt[MAXCH];
+    load_row(row, cur);
+    if (p.ln_w) {
+        for (int c = tid; c < nch; c += 64 * QK_WAVES) {
+            *(bf8_t*)(sw + c * 8) = *(const bf8_t*)(p.ln_w + c * 8);
+            *(bf8_t*)(sb + c * 8) = *(const bf8_t*)(p.ln_b + c * 8);
+        }
+    }
+    int branch = 1;
+    if (p.rope_mode != 0 && p.t) branch = (p.t[0] < p.watershed) ? 0 : 1;
+    const int nfreq = (p.rope_mode == 1) ? (p.hd >> 2) : (p.hd >> 1);
+    const float* cs = p.rope_mode != 0 ? p.cs + (size_t)branch * p.cs_len * nfreq * 2 : nullptr;
+    __syncthreads();  // the only workgroup barrier: weights staged (every wave passes it exactly once)
+
+    for (; row < rows; row += stride) {
+        load_row(row + stride, nxt);  // clamped inside; the extra load of the last iteration is discarded
+        const int b = row / p.N, n = row - b * p.N;
+        if (p.rope_mode != 0 && lane < nslot) {  // this row's rotary factors -> the wave's LDS strip
+            const int pr = lane;
+            const int n_rot = p.n_tok_b ? min(n, p.n_tok_b[b] - 1) : n;
+            int pos, fi;
+            if (p.rope_mode == 1) {
+                const int gw = p.grid_w_b ? p.grid_w_b[b] : p.grid_w;
+                const int gr = n_rot / gw, gc = n_rot - gr * gw;
+                fi = pr >> 1; pos = (pr & 1) ? gc : gr;
+            } else { fi = pr; pos = n_rot; }
+            st[pr] = *(const float2*)(cs + ((size_t)pos * nfreq + fi) * 2);
+        }
+        float mean = 0.f, rstd = 1.f;
+        if (p.ln_w) {
+            f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MAXCH; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s2 += unpk_bf(cur[i].w[k]);
+            mean = wave_sum(s2[0] + s2[1]) / (float)width;
+            const f32x2 mv = {mean, mean};
+            f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MAXCH; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x2 dl = unpk_bf(cur[i].w[k]) - mv;
+                        q2 = dl * dl + q2;
+                    }
+                }
+            }
+            rstd = rsqrtf(wave_sum(q2[0] + q2[1]) / (float)width + p.ln_eps);
+        }
+        const f32x2 mv = {mean, mean}, rv = {rstd, rstd}, osc = {p.out_scale, p.out_scale};
+        __builtin_amdgcn_wave_barrier();  // the strip is written and read by this wave only: LDS ops of one wave stay in order
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const int head = c / cph, ci = c - head * cph;
+                bf8_t wv, bv, o;
+                if (p.ln_w) {
+                    wv = *(const bf8_t*)(sw + c * 8);
+                    bv = *(const bf8_t*)(sb + c * 8);
+                }
+                float4 t01 = {1.f, 0.f, 1.f, 0.f}, t23 = {1.f, 0.f, 1.f, 0.f};
+                if (p.rope_mode != 0) {
+                    t01 = *(const float4*)(st + 4 * ci);
+                    t23 = *(const float4*)(st + 4 * ci + 2);
+                }
+                const float tc[4] = {t01.x, t01.z, t23.x, t23.z}, ts[4] = {t01.y, t01.w, t23.y, t23.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 y = unpk_bf(cur[i].w[j]);
+                    if (p.ln_w) y = (y - mv) * rv * unpk_bf(wv.w[j]) + unpk_bf(bv.w[j]);
+                    if (p.rope_mode != 0) y = f32x2{y[0] * tc[j] - y[1] * ts[j], y[0] * ts[j] + y[1] * tc[j]};
+                    if (p.out_scale != 1.0f) y = y * osc;
+                    o.w[j] = pk_bf(y);
+                }
+                *(bf8_t*)(p.dst + (((size_t)b * p.heads + head) * p.N + n) * p.hd + ci * 8) = o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // all reads of the strip issued before the next row overwrites it
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) cur[i] = nxt[i];
+    }
+}
+
 // one block per (64-key tile, kv head, batch): V rows -> LDS (transposed, permuted) -> 128-byte rows
 __device__ __forceinline__ void v_transpose_tile(const u16* __restrict__ src, int ld_src, int col0, u16* __restrict__ dst,
                                                  int N, int Npad, int kv_heads, int hd, int bx, int kvh, int b,
@@ -218,16 +333,30 @@ int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.rope_mode != 1 || (a.hd % 4 == 0 && a.grid_w > 0), "qk_norm_rope: 2-D rope needs hd %% 4 == 0");
     LT_REQUIRE((a.ln_w == nullptr) == (a.ln_b == nullptr), "qk_norm_rope: LayerNorm weight and bias must come together");
     const int rows = a.B * a.N;
-    const dim3 grid((rows + QK_ROWS - 1) / QK_ROWS);
-    const size_t smem = (size_t)width * 4 + (size_t)QK_ROWS * (a.hd >> 1) * 8;
+    // persistent grid: ~2 workgroups (16 waves) per CU, never more workgroups than rows / 8
+    int cus = 256;
+    {
+        static int cached = 0;
+        if (!cached) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cached = prop.multiProcessorCount;
+            else cached = 256;
+        }
+        cus = cached;
+    }
+    const int max_blocks = (rows + QK_WAVES - 1) / QK_WAVES;
+    const dim3 grid(std::min(max_blocks, 2 * cus));
+    const size_t smem = (size_t)width * 4 + (size_t)QK_WAVES * (a.hd >> 1) * 8;
     switch (((width >> 3) + 63) / 64) {
-        case 1: hipLaunchKernelGGL(qk_norm_rope_kernel<1>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
-        case 2: hipLaunchKernelGGL(qk_norm_rope_kernel<2>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
-        case 3: hipLaunchKernelGGL(qk_norm_rope_kernel<3>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
-        case 4: hipLaunchKernelGGL(qk_norm_rope_kernel<4>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
-        case 5: hipLaunchKernelGGL(qk_norm_rope_kernel<5>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
-        case 6: hipLaunchKernelGGL(qk_norm_rope_kernel<6>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
-        default: hipLaunchKernelGGL(qk_norm_rope_kernel<8>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 1: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<1>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 2: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<2>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 3: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<3>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 4: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<4>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 5: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<5>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 6: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<6>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        default: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<8>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
     }
     LT_CHECK_HIP(hipGetLastError());
     return 0;
