@@ -57,6 +57,11 @@ def test_null_arguments_are_errors_not_crashes(lib):
     assert lib.lt_forward(None, None, None, None, None, None) != 0
     assert lib.lt_op_gemm_bf16(None, None, None, -1, None, 1, 8, 64, 0, 0, None) != 0
     assert lib.lt_weights_ready(None) != 0
+    assert lib.lt_forward_packed(None, None, None, None, None, None, None) != 0
+    assert lib.lt_prepare_prompt_regional(None, None, 1, None, 3, 16, None, None, 16, 1, 2, None) != 0
+    assert lib.lt_op_gemm_grouped(None, None, None, 0, None, 256, 8, 64, 0, 0, None) != 0
+    assert b"null" in lib.lt_last_error()
+    assert lib.lt_set_option(b"no_such_knob", 1) != 0 and b"no_such_knob" in lib.lt_last_error()
 
 
 def test_product_path_never_imports_the_oracle():
