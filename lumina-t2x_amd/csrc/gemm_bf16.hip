@@ -22,6 +22,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <hip/hip_ext.h>
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -643,6 +644,191 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     }
 }
 
+// ---- persistent ping-pong kernel -------------------------------------------------------------------------
+// The two-barrier ping-pong loop of gemm_bf16_pp (MODE 0, 32-deep slabs, 8 waves, 256x256 tile), but one workgroup per CU
+// walks SEVERAL tiles and the 4-slot LDS ring never restarts: the LDS-DMA of the next tile's first three slabs is issued during
+// the last three MFMA segments of the current tile, so the ~4.6 k-cycle cold prologue (3 slabs of DMA latency with an idle
+// matrix pipe) is paid once per workgroup instead of once per tile, and each wave group's epilogue (pack + 8-16 global stores
+// per wave, no barriers) overlaps the OTHER group's last / first MFMA segment.  For GEMMs with several tile rounds per CU
+// (SwiGLU: 6) the per-tile prologue + epilogue was ~10 % of the kernel (profiles/r01/gemm_pingpong_cycle_trace.log).
+// MEASURED (profiles/r01/opbench_gemm_persistent.log): 398.4 us vs 400.2 us on the SwiGLU GEMM - no gain.  Removing idle
+// time from a kernel that already runs against the power-managed clock buys nothing; kept as variant 9 /
+// option "gemm_persist" (parity-tested), not the default.
+// vmcnt bookkeeping: loads and stores retire in issue order on gfx9 (one counter, the compiler relies on it too), so after an
+// epilogue the NST stores of this wave sit between the prefetched slabs and the new tile's own LDS-DMA; the two READ segments
+// that follow allow NST more outstanding operations.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_persist(GemmArgs p) {
+    constexpr int WM = 2, WN = 4, MT = 4, NT = 2, NW = 8;
+    constexpr int BM = 256, BN = 256;
+    constexpr int PA = BM / 16, NP = (BM + BN) / 16, IP = NP / NW;  // 32 pieces of 1 KiB per slab, 4 per wave
+    constexpr int SLAB = (BM + BN) * 64, W_OFF = BM * 64;
+    constexpr int NM = 2 * MT * NT;
+    constexpr int NST = EPI == 0 ? MT * NT * 2 : MT * (NT / 2) * 2;  // global stores per wave and tile (store_tile)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    const int ntiles = TM * TN;
+    const int ns = p.K / 32;
+
+    // staging: wave w copies pieces w, w + 8 (A rows 16 w.., 16 (w + 8)..) and w + 16, w + 24 (the same rows of W); the
+    // per-lane offsets do not depend on the tile - a tile only changes the two buffer descriptors (base = the tile's first row,
+    // num_records = bytes left => rows past M / N read as zero)
+    const int sswz = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+    const int srow = 16 * wave + (lane >> 2);
+    int voff[IP], ldsoff[IP];
+    voff[0] = srow * p.lda * 2 + sswz;
+    voff[1] = (srow + 128) * p.lda * 2 + sswz;
+    voff[2] = srow * p.ldw * 2 + sswz;
+    voff[3] = (srow + 128) * p.ldw * 2 + sswz;
+#pragma unroll
+    for (int i = 0; i < IP; ++i) ldsoff[i] = (wave + NW * i) * 1024;
+    static_assert(IP == 4 && PA == 16, "piece map above");
+    auto setup = [&](int v, __amdgpu_buffer_rsrc_t& rA, __amdgpu_buffer_rsrc_t& rW, int& m0, int& n0) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_coords(v, ntiles, TM, TN, tm, tn);
+        m0 = tm * BM; n0 = tn * BN;
+        const long long a_left = (long long)(p.M - m0) * p.lda * 2;
+        const long long w_left = (long long)(p.N - n0) * p.ldw * 2;
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
+        rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * p.ldw), 0, (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left), 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t rAC, rWC, rAN, rWN;
+    int m0 = 0, n0 = 0, m0n = 0, n0n = 0;
+
+    const int fswz = (l31 >> 2) & 3;
+    const int a_row_off = (wm * MT * 32 + l31) * 64;
+    const int w_row_off = W_OFF + (wn * NT * 32 + l31) * 64;
+    int coff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) coff[k] = ((2 * k + hi) ^ fswz) << 4;
+
+    f32x16 acc[MT][NT];
+    bf16x8 wf[2][NT], af[2][MT];
+
+    int v = blockIdx.x;
+    if (v >= ntiles) return;  // uniform
+    const int my_tiles = (ntiles - 1 - v) / gridDim.x + 1;
+    const int total = my_tiles * ns;  // slabs this workgroup consumes
+    setup(v, rAC, rWC, m0, n0);
+    bool has_next = v + (int)gridDim.x < ntiles;
+    // no next tile: the last three segments still issue their LDS-DMA (one code path), from empty descriptors - every lane is
+    // out of range, the ring slots they zero-fill hold slabs that were consumed already
+    const __amdgpu_buffer_rsrc_t r_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+    if (has_next) setup(v + gridDim.x, rAN, rWN, m0n, n0n);
+    else { rAN = r_null; rWN = r_null; }
+
+    auto stage_from = [&](int g, int slab_in_tile, __amdgpu_buffer_rsrc_t rA, __amdgpu_buffer_rsrc_t rW) __attribute__((always_inline)) {
+        char* base = smem + (g & 3) * SLAB;
+        const int soff = slab_in_tile * 64;
+#pragma unroll
+        for (int i = 0; i < IP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < 2 ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, voff[i], soff, 0, 0);
+    };
+    // prologue (once per workgroup): global slabs 0..2 = this tile's slabs 0..2 (ns >= 3 is required by the launcher)
+    stage_from(0, 0, rAC, rWC);
+    stage_from(1, 1, rAC, rWC);
+    stage_from(2, 2, rAC, rWC);
+    wait_vmcnt_n<2 * IP>();
+    pp_barrier();
+    for (int g_ = 0; g_ < grp; ++g_) pp_barrier();
+
+    int g = 0;                // global slab index of this wave's stream
+    int since_epilogue = 2;   // READ segments since the last epilogue (< 2: NST stores may still be counted ahead of our DMA)
+    auto read_seg = [&]() __attribute__((always_inline)) {
+        const char* sb = smem + (g & 3) * SLAB;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * 2048 + coff[k]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * 2048 + coff[k]);
+        }
+        // slab g+1 landed (slab g+2 - and, right after an epilogue, this wave's NST stores - may still be outstanding)
+        // (the null-descriptor DMAs of the last tile count like real ones, so the counts are uniform to the very end)
+        if (since_epilogue < 2) wait_vmcnt_n<IP + NST>();
+        else wait_vmcnt_n<IP>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pp_barrier();
+        ++since_epilogue;
+    };
+    auto mfma_all = [&](auto do_stage, int slab_in_tile, __amdgpu_buffer_rsrc_t rA, __amdgpu_buffer_rsrc_t rW) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int EVERY = NM / IP;
+        char* base = smem + ((g + 3) & 3) * SLAB;
+        const int soff = slab_in_tile * 64;
+        int issued = 0;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int k = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], af[k][mt], acc[mt][nt], 0, 0, 0);
+            if constexpr (decltype(do_stage)::value) {
+                if ((i + 1) % EVERY == 0 && issued < IP) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(issued < 2 ? rA : rW, LDS_PTR(base + ldsoff[issued]), 16, voff[issued], soff, 0, 0);
+                    ++issued;
+                }
+            }
+        }
+        if constexpr (decltype(do_stage)::value) {
+#pragma unroll
+            for (int i = 0; i < IP; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, EVERY, 0);
+                __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto handover = [&]() __attribute__((always_inline)) {
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    for (int t = 0; t < my_tiles; ++t) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        int s = 0;
+        for (; s + 3 < ns; ++s) {  // LDS-DMA of this tile's slab s+3
+            read_seg();
+            mfma_all(std::true_type{}, s + 3, rAC, rWC);
+            handover();
+            ++g;
+        }
+        for (; s < ns; ++s) {      // last three segments: the next tile's slabs 0..2 (if there is a next tile)
+            read_seg();
+            mfma_all(std::true_type{}, s + 3 - ns, rAN, rWN);
+            if (g + 1 < total) handover();
+            else __builtin_amdgcn_s_setprio(0);
+            ++g;
+        }
+        store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
+        since_epilogue = 0;
+        if (has_next) {
+            rAC = rAN; rWC = rWN;
+            m0 = m0n; n0 = n0n;
+            v += gridDim.x;
+            has_next = v + (int)gridDim.x < ntiles;
+            if (has_next) setup(v + gridDim.x, rAN, rWN, m0n, n0n);
+            else { rAN = r_null; rWN = r_null; }
+        }
+    }
+    wait_vmcnt_n<0>();  // no LDS-DMA (the null ones of the last segments included) may outlive the workgroup's LDS allocation
+    for (int g_ = grp; g_ < 1; ++g_) pp_barrier();  // group 0 passes the barrier group 1 still executes after its last READ
+}
+
 // explicit instantiations (hipcc 7.2 does not emit the kernel body for address-only uses inside another template)
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 1>(GemmArgs);
@@ -651,6 +837,8 @@ template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true>(GemmArgs);
+template __global__ void gemm_bf16_pp_persist<0>(GemmArgs);
+template __global__ void gemm_bf16_pp_persist<1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0>(GemmArgs);  // 128 x 128, small-M problems
 template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1>(GemmArgs);  // 128 x 128 with the SwiGLU epilogue (needs NT even)
 template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0>(GemmArgs);  //  64 x 128
@@ -674,6 +862,7 @@ template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0, true>(GemmArgs);
 namespace {
 using lt_gemm::gemm_bf16_tn;
 using lt_gemm::gemm_bf16_pp;
+using lt_gemm::gemm_bf16_pp_persist;
 
 // w1/w3 -> 32-row interleaved packed weight (row P: block = P/64; P%64 < 32 -> w1 else w3)
 __global__ void pack_w13_kernel(const u16* __restrict__ w1, const u16* __restrict__ w3, u16* __restrict__ out,
@@ -720,6 +909,23 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     return 0;
 }
 
+int num_cus();
+template <int EPI>
+int launch_persist(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    constexpr int SMEM = 4 * 512 * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp_persist<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_done = true;
+    }
+    const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const dim3 grid(std::min(ntiles, num_cus())), block(512);
+    if (ev0) hipExtLaunchKernelGGL((gemm_bf16_pp_persist<EPI>), grid, block, SMEM, stream, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((gemm_bf16_pp_persist<EPI>), grid, block, SMEM, stream, a);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -736,6 +942,8 @@ static int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto,
 static int g_gemm_pipeline = 0;  // variant <= 2: 0 auto (ping-pong for the SwiGLU GEMM, classic elsewhere), 1 ping-pong, 2 classic, 3 rendezvous
 void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
 void lt_set_gemm_pipeline(int v) { g_gemm_pipeline = v; }
+static int g_gemm_persist = 0;   // 1: SwiGLU GEMMs with >= 2 tile rounds per CU run on the persistent ping-pong kernel
+void lt_set_gemm_persist(int v) { g_gemm_persist = v; }
 static int g_gemm_pp_tail = 0;   // 8-wave ping-pong kernel: 1 = tail MFMAs issued after the hand-over (TAILN = 3; measured no gain), 0 = plain
 void lt_set_gemm_pp_tail(int v) { g_gemm_pp_tail = v; }
 
@@ -748,7 +956,13 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 8, "gemm: unknown variant %d", variant);
+    LT_REQUIRE(variant >= 0 && variant <= 9, "gemm: unknown variant %d", variant);
+    if (variant == 9 || (variant == 0 && g_gemm_persist && epilogue == 1 && !a.tile_expert && !a.trace && a.K >= 96 &&
+                         (long long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 2LL * num_cus())) {
+        // persistent ping-pong kernel (256x256 tiles, several tiles per CU, LDS ring and DMA prefetch carried across tiles)
+        LT_REQUIRE(!a.tile_expert && !a.trace && a.K >= 96, "gemm variant 9: dense problems with K >= 96 only");
+        return epilogue == 1 ? launch_persist<1>(a, stream, ev0, ev1) : launch_persist<0>(a, stream, ev0, ev1);
+    }
     const int cus = num_cus();
     const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);

@@ -45,12 +45,14 @@ def test_gemm_plain(M, N, K):
     assert max_abs(out, ref) < 0.04 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 2304), (300, 576, 128), (1024, 6912, 2304), (256, 288, 64), (257, 296, 192),
                                    (512, 512, 6144)])
 def test_gemm_tile_variants(variant, M, N, K):
     """both tile shapes (256x256 / 8 waves, 256x288 / 12 waves) x both pipelines (classic double buffer, ping-pong wave
     groups = variants 3 / 4) on tile-multiple and ragged problems; K = 64 ... 6144 covers 2 ... 192 ring slabs"""
+    if variant == 9 and K < 96:
+        pytest.skip("the persistent kernel carries a 3-slab prefetch across tiles: K >= 96")
     g = torch.Generator(device="cpu").manual_seed(M + N + K + variant)
     A = bf(torch.randn(M, K, generator=g))
     W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
@@ -61,7 +63,7 @@ def test_gemm_tile_variants(variant, M, N, K):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_identity_asymmetric(variant):
     """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
     K, N = 320, 576
@@ -101,6 +103,28 @@ def test_gemm_swiglu(M, F_, K, pipeline):
     b = r16(A.float() @ w3.float().t())
     ref = r16(r16(F.silu(a)) * b)
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(8192, 12288, 2304, 1), (8300, 6912, 2304, 0), (2100, 1280, 128, 1), (16384, 2304, 6144, 0)])
+def test_gemm_persistent_pingpong(M, N, K, epi):
+    """persistent ping-pong kernel (variant 9): several 256x256 tiles per workgroup with the LDS ring, the DMA prefetch and the
+    vmcnt bookkeeping carried across tile boundaries (stores of the previous tile's epilogue in flight); uneven tile counts
+    per workgroup, ragged M / N edges, a K of only 4 slabs, both epilogues - against the classic kernel bit for bit
+    (same MFMA order) and against fp32."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    out = _gemm(A, W, None, epi, variant=9)
+    ref = _gemm(A, W, None, epi, variant=1)
+    assert torch.equal(out, ref), rel_l2(out, ref)
+    if epi == 0:
+        assert rel_l2(out, A.float() @ W.float().t()) < 4e-3
+    # and through the process-wide switch the engine uses
+    set_option("gemm_persist", 1)
+    try:
+        assert torch.equal(_gemm(A, W, None, epi), ref)
+    finally:
+        set_option("gemm_persist", 0)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 3, 7])
