@@ -244,19 +244,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_tn(G
 //        READ(s+1), interval G*s+G+g' > G*s+g for all g, g'  -> a barrier every wave has passed lies between.
 //   WAR  slab s+4 reuses the slot of slab s; it is issued in MFMA(s+1), interval G*s+G+g+1, while the last
 //        read of slab s completed (lgkmcnt(0) before the barrier) in interval G*s+g' <= G*s+G-1.
-#define LT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 8, "vmcnt literal table");
-    if constexpr (N == 0) LT_WAIT_VM(0);
-    else if constexpr (N == 1) LT_WAIT_VM(1);
-    else if constexpr (N == 2) LT_WAIT_VM(2);
-    else if constexpr (N == 3) LT_WAIT_VM(3);
-    else if constexpr (N == 4) LT_WAIT_VM(4);
-    else if constexpr (N == 5) LT_WAIT_VM(5);
-    else if constexpr (N == 6) LT_WAIT_VM(6);
-    else if constexpr (N == 7) LT_WAIT_VM(7);
-    else LT_WAIT_VM(8);
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
@@ -292,13 +283,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     constexpr int RPP = 1024 / RB;       // rows per 1-KiB staging piece
     constexpr int LPR = RB / 16;         // lanes (16-byte chunks) per row
     constexpr int NW = WM * WN, G = NW / 4;
-    static_assert(NW % 4 == 0 && G >= 2 && G <= 3, "ping-pong needs 2 or 3 waves per SIMD");
+    static_assert(NW % 4 == 0 && ((G >= 2 && G <= 3) || (MODE == 2 && G == 1)), "ping-pong needs 2 or 3 waves per SIMD");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int PA = BM / RPP, PW = BN / RPP, NP = PA + PW;  // 1-KiB pieces (RPP rows x RB bytes) per slab
     constexpr int IP = (NP + NW - 1) / NW;                     // pieces per wave per slab (same for every wave)
     constexpr int SLAB = (BM + BN) * RB, W_OFF = BM * RB;
     static_assert(EPI == 0 || NT % 2 == 0, "SwiGLU epilogue pairs accumulator tiles");
-    static_assert(IP <= 4, "staging pieces per wave");
+    static_assert(IP <= 8, "staging pieces per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long t_entry = 0;
     if constexpr (TRACE) t_entry = __builtin_amdgcn_s_memtime();
@@ -332,8 +323,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     // Piece q holds rows RPP q .. RPP q + RPP - 1 of A (q < PA) or of W; lane -> row RPP q + lane / LPR, 16-byte position
     // lane % LPR, fetched from source chunk pos ^ key(row): key = (row >> 2) & 3 for 64-byte rows, (row >> 1) & 7 for
     // 128-byte rows (the same keys the fragment reads apply, so a 32x32x16 fragment read is bank-conflict free).
-    __amdgpu_buffer_rsrc_t rs[4];
-    int voff[4], ldsoff[4];
+    __amdgpu_buffer_rsrc_t rs[8];  // fixed size: a dependent bound here breaks host-side substitution (hipcc 7.2)
+    int voff[8], ldsoff[8];
 #pragma unroll
     for (int i = 0; i < IP; ++i) {
         int q = wave + NW * i;
@@ -553,12 +544,58 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
                 pp_barrier();
             }
         };
+        // Large wave tiles (one wave per SIMD, e.g. 2x2 waves of 128x128): the interval's work must be ONE interleaved stream -
+        // a burst of 16 ds_reads + 8 LDS-DMA issues in front of 32 MFMAs would leave the matrix pipe idle for hundreds of
+        // cycles - so the steady-state body pins "2 MFMA, 1 fragment read, 2 MFMA, 1 fragment read, 1 LDS-DMA" groups.
+        constexpr int RD = KS * (MT + NT);
+        constexpr bool PINNED = (G == 1) && (NM == 4 * IP) && (RD == 2 * IP);
+        auto body_pinned = [&](int k, bf16x8 (&wc)[KS][NT], bf16x8 (&ac)[KS][MT], bf16x8 (&wn_)[KS][NT], bf16x8 (&an)[KS][MT])
+                               __attribute__((always_inline)) {
+            // steady state only: slabs k+1 (read) and k+3 (staged) exist
+            const char* sb = smem + ((k + 1) & 3) * SLAB;
+            char* db = smem + ((k + 3) & 3) * SLAB;
+            const int soff = (k + 3) * RB;
+            auto rd = [&](int r) __attribute__((always_inline)) {  // fragment read r of slab k+1, k-step major
+                const int kk = r / (MT + NT), j = r % (MT + NT);
+                if (j < NT) wn_[kk][j] = *(const bf16x8*)(sb + w_row_off + j * TSTRIDE + coff[kk]);
+                else an[kk][j - NT] = *(const bf16x8*)(sb + a_row_off + (j - NT) * TSTRIDE + coff[kk]);
+            };
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const int kk = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[kk][nt], ac[kk][mt], acc[mt][nt], 0, 0, 0);
+                if (i % 2 == 1) rd(i / 2);
+                if (i % 4 == 3)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i / 4], LDS_PTR(db + ldsoff[i / 4]), 16, voff[i / 4], soff, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < IP; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): slab k+1's fragments are in registers
+            wait_vmcnt<IP>();                    // slab k+2 landed, slab k+3 in flight
+            pp_barrier();
+        };
         reads_to(0, wf, af);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         if (ns > 2) wait_vmcnt<IP>();  // slab 1 landed
         else wait_vmcnt<0>();
         pp_barrier();
-        for (int k = 0; k < ns; k += 2) {
+        int k = 0;
+        if constexpr (PINNED) {
+            for (; k + 4 < ns; k += 2) {  // both bodies of the pair are steady state: k + 1 + 3 < ns
+                body_pinned(k, wf, af, wf2, af2);
+                body_pinned(k + 1, wf2, af2, wf, af);
+            }
+        }
+        for (; k < ns; k += 2) {
             body(k, wf, af, wf2, af2);
             if (k + 1 < ns) body(k + 1, wf2, af2, wf, af);
         }
@@ -658,9 +695,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 // epilogue the NST stores of this wave sit between the prefetched slabs and the new tile's own LDS-DMA; the two READ segments
 // that follow allow NST more outstanding operations.
 template <int N>
-__device__ __forceinline__ void wait_vmcnt_n() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+__device__ __forceinline__ void wait_vmcnt_n() { wait_vmcnt<N>(); }
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_persist(GemmArgs p) {
@@ -837,6 +872,8 @@ template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1>(GemmArgs);
 template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 2, 4, 4, 0, false, 0, 2, 2>(GemmArgs);  // 4 waves x (128 x 128): one wave per SIMD
+template __global__ void gemm_bf16_pp<2, 2, 4, 4, 1, false, 0, 2, 2>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<0>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0>(GemmArgs);  // 128 x 128, small-M problems
@@ -956,7 +993,11 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 9, "gemm: unknown variant %d", variant);
+    LT_REQUIRE(variant >= 0 && variant <= 10, "gemm: unknown variant %d", variant);
+    if (variant == 10) {  // 256x256 tile, 4 waves of 128x128 (one wave per SIMD, 256 accumulator registers), register-pipelined loop
+        LT_REQUIRE(!a.trace, "gemm variant 10: no trace build");
+        return epilogue == 1 ? launch_cfg<2, 2, 4, 4, 1, true, 0, 2, 2>(a, stream, ev0, ev1) : launch_cfg<2, 2, 4, 4, 0, true, 0, 2, 2>(a, stream, ev0, ev1);
+    }
     if (variant == 9 || (variant == 0 && g_gemm_persist && epilogue == 1 && !a.tile_expert && !a.trace && a.K >= 96 &&
                          (long long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 2LL * num_cus())) {
         // persistent ping-pong kernel (256x256 tiles, several tiles per CU, LDS ring and DMA prefetch carried across tiles)

@@ -94,6 +94,35 @@ def bench_gemm(rounds, variants, zeros=False, shapes=SHAPES_CFG2, cold=0):
         print(f"gemm per-layer total variant {v}: {tot[v]*1e3:8.1f} us  -> {fl_layer/tot[v]/1e9:7.1f} TF/s")
 
 
+def bench_gemm_vendor(rounds):
+    """The same four GEMM shapes and random operands through the vendor library (torch.matmul -> hipBLASLt / rocBLAS), next to
+    the engine's default kernels: where the practical ceiling of this part sits for bf16 GEMMs on non-trivial data.  Plain
+    GEMMs only (the SwiGLU GEMM is timed without its epilogue on both sides here)."""
+    L = lib()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for name, M, N, K, _ in SHAPES_CFG2:
+        A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        out2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        Wt = W.t()
+
+        def ours():
+            ok(L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(out), M, N, K, 0, 0, stream()))
+
+        def vendor():
+            torch.matmul(A, Wt, out=out2)
+
+        def vendor_linear():
+            torch.nn.functional.linear(A, W)
+
+        r = ab({"engine (auto)": ours, "torch.matmul(A, W^T)": vendor, "F.linear(A, W)": vendor_linear}, rounds)
+        fl = 2.0 * M * N * K
+        for k, (med, mn) in r.items():
+            print(f"vendor-cmp {name:4s} M{M} N{N} K{K} {k:22s}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s (best {fl/mn/1e9:7.1f})", flush=True)
+        print(f"   max |engine - vendor| = {float((out.float() - out2.float()).abs().max()):.4f}", flush=True)
+
+
 def bench_gemm_moe(rounds, variants, cold=0):
     """BASELINE cfg 5 expert GEMMs: 512 tokens x top-2 over 4 experts = 8 segments of 256 expert-sorted rows (two per expert,
     the worst case of the plan), each streaming its own expert's weights; dense GEMMs of the same shape for comparison."""
@@ -252,6 +281,8 @@ if __name__ == "__main__":
     if "gemm_small" in a.what:
         bench_gemm(a.rounds, [v if ("t" in v or "p" in v) else int(v) for v in a.gemm_variants.split(",")], shapes=SHAPES_CFG1,
                    cold=a.cold)
+    if "gemm_vendor" in a.what:
+        bench_gemm_vendor(a.rounds)
     if "gemm_moe" in a.what:
         bench_gemm_moe(a.rounds, [int(v) for v in a.gemm_variants.split(",")], cold=a.cold)
     if "insitu" in a.what:
