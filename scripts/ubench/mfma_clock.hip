@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void mfma_loop(const unsigned* seed, unsigned 
             for (int r = 0; r < 4; ++r) c4[i][r] = 0.f;
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) c4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i + (i >> 2)) & 3], c4[i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i)  // in-place accumulators (the builtin form made hipcc rotate overlapping AGPR tuples)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c4[i]) : "v"(a[i & 3]), "v"(b[(i + (i >> 2)) & 3]));
         }
         for (int i = 0; i < 8; ++i)
             for (int r = 0; r < 4; ++r) acc[i & 3][r] += c4[i][r];
