@@ -10,7 +10,10 @@ def create_transport(path_type="Linear", prediction="velocity", loss_weight=None
                      snr_type="uniform"):
     """Build the Transport state.  Model prediction defaults to velocity; eps defaults follow the reference:
     VP -> (1e-5, 1e-3); GVP/Linear with a non-velocity model -> (1e-3, 1e-3); velocity on GVP/Linear -> (0, 0)
-    (note the reference derives BOTH defaults from ``train_eps is None`` - kept)."""
+    The reference tests ``train_eps is None`` a second time AFTER assigning train_eps (__init__.py:47-57), which leaves
+    sample_eps = None whenever only the defaults are used on VP / non-velocity models, and its check_interval then fails on
+    ``1 - None``; here both defaults are taken when train_eps is unset (what the reference evidently intends).  With explicit
+    eps values the behaviour is identical (tests/golden/transport_kat.npz)."""
     model_type = _PREDICTION.get(prediction, ModelType.VELOCITY)
     loss_type = _LOSS.get(loss_weight, WeightType.NONE)
     ptype = _PATH[path_type]

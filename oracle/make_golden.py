@@ -172,6 +172,65 @@ def compositional_case(name, cfg, latent_hw, splits, text_len, seed_w, seed_x):
     print(f"{name}.npz:", {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 1})
 
 
+def transport_kats():
+    """Everything in transport/ that is the reference's own code (no torchdiffeq inside): SDE samplers (Euler-Maruyama / Heun,
+    every diffusion form and last-step rule, integrators.py:27-76, transport.py:197-344), the three path plans (path.py) and
+    the training loss (transport.py:95-164), run from the unmodified modules with a fixed torch seed and a toy model callable."""
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
+        del sys.modules[m]
+    _, T = R.load_reference("lumina_next_t2i")
+    d = {}
+
+    def model(x, t, **kw):  # smooth, time dependent, sample dependent
+        return -x * (0.5 + t.view(-1, 1, 1, 1)) + 0.1 * torch.cos(3.0 * x)
+
+    x0 = torch.linspace(-1.0, 1.0, 2 * 3 * 4 * 4).view(2, 3, 4, 4).clone()
+    cases = []
+    # explicit eps where the reference's own defaulting leaves sample_eps = None (it tests `train_eps is None` AFTER assigning
+    # train_eps, __init__.py:47-57) and then fails in check_interval
+    for path_type, prediction, eps in (("Linear", "velocity", (None, None)), ("GVP", "velocity", (None, None)),
+                                       ("VP", "score", (1e-5, 1e-3)), ("Linear", "noise", (1e-3, 1e-3))):
+        tr = T.create_transport(path_type, prediction, None, eps[0], eps[1])
+        for method in ("Euler", "Heun"):
+            # ("constant" returns a Python float and makes th.sqrt fail inside the reference's own step - not a usable form;
+            #  "inccreasing-decreasing" is the reference's spelling, path.py:62)
+            for form in ("SBDM", "sigma", "linear", "decreasing", "inccreasing-decreasing"):
+                for last in ("Mean", "Tweedie", "Euler", None):
+                    if (form, last) not in (("SBDM", "Mean"), ("sigma", "Tweedie"), ("linear", "Euler"), ("decreasing", None),
+                                            ("inccreasing-decreasing", "Mean")):
+                        continue
+                    key = f"sde_{path_type}_{prediction}_{method}_{form}_{last}"
+                    torch.manual_seed(1234)
+                    fn = T.Sampler(tr).sample_sde(sampling_method=method, diffusion_form=form, diffusion_norm=0.7, last_step=last,
+                                                  last_step_size=0.04, num_steps=7)
+                    xs = fn(x0.clone(), model)
+                    d[key] = _np(torch.stack(xs))
+                    cases.append([key, path_type, prediction, method, form, last, eps[0], eps[1]])
+        # training loss with fixed noise / time draws
+        torch.manual_seed(99)
+        try:
+            terms = tr.training_losses(model, x0.clone())
+            d[f"loss_{path_type}_{prediction}"] = _np(terms["loss"])
+        except AssertionError:  # the reference's Transport.sample is "not implemented" off the (0, 1) interval (transport.py:107)
+            pass
+        # path plan functions on a fixed (t, x)
+        tt = torch.tensor([0.13, 0.77])
+        plan = tr.path_sampler
+        xt = x0 * 0.3
+        vel = torch.sin(x0)
+        tag = f"plan_{path_type}_{prediction}"
+        drift_mean, drift_var = plan.compute_drift(xt, tt)
+        for nm, val in (("drift_mean", drift_mean), ("drift_var", drift_var), ("score", plan.get_score_from_velocity(vel, xt, tt)),
+                        ("noise", plan.get_noise_from_velocity(vel, xt, tt)), ("vel_from_score", plan.get_velocity_from_score(vel, xt, tt)),
+                        ("diff_sbdm", plan.compute_diffusion(xt, tt, form="SBDM", norm=0.7)),
+                        ("diff_dec", plan.compute_diffusion(xt, tt, form="decreasing", norm=0.7))):
+            d[f"{tag}_{nm}"] = _np(val * torch.ones(1))
+    d["x0"] = _np(x0)
+    d["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(OUT, "transport_kat.npz"), **d)
+    print("transport_kat.npz:", len(cases), "sde cases")
+
+
 def _fresh_import(pkg, module):
     """import <pkg>/<module> of the reference with a clean `models` namespace (every sub-project calls its package `models`)"""
     for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
@@ -264,6 +323,7 @@ def main():
     family_case("moe_tiny", synth.TINY_MOE, (16, 16), 9, 10)
     family_case("flag_tiny", synth.TINY_FLAG, (16, 24), 11, 12)
     mini_ode_kats()
+    transport_kats()
     packed_case("nextdit_tiny_packed", synth.TINY, [(16, 16), (12, 20), (8, 24), (16, 16)], 16, 13, 14)
     compositional_case("compositional_tiny", synth.TINY, (16, 24), (2, 2), 16, 15, 16)
     compositional_case("compositional_tiny_1x3", synth.TINY, (12, 24), (1, 3), 13, 17, 18)
