@@ -31,6 +31,40 @@ def test_header_symbols_exported(lib):
     assert sorted(_lib._SIGNATURES) == declared
 
 
+def test_binding_table_matches_header_prototypes():
+    """argument COUNT and coarse kind (pointer / 32-bit / 64-bit / float) of every ctypes signature against the prototype in
+    include/lumina_dit.h - an ABI drift between the header and the Python binding would otherwise only show up as memory
+    corruption on the GPU box."""
+    text = open(os.path.join(REPO, "include", "lumina_dit.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = dict(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    assert set(protos) == set(_lib._SIGNATURES)
+
+    def kind_of_c(param):
+        p = " ".join(param.split())
+        if p in ("void", ""):
+            return None
+        if "*" in p:
+            return "ptr"
+        if p.startswith("int64_t"):
+            return "i64"
+        if p.startswith("float"):
+            return "f32"
+        if p.startswith(("int32_t", "uint32_t", "int ")):
+            return "i32"
+        raise AssertionError(f"unclassified C parameter '{p}'")
+
+    def kind_of_ctype(t):
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents"):
+            return "ptr"
+        return {C.c_int32: "i32", C.c_uint32: "i32", C.c_int64: "i64", C.c_float: "f32"}[t]
+
+    for name, params in protos.items():
+        want = [k for k in (kind_of_c(p) for p in params.split(",")) if k]
+        got = [kind_of_ctype(t) for t in _lib._SIGNATURES[name][1]]
+        assert got == want, (name, got, want)
+
+
 def test_version_and_error_channel(lib):
     assert lib.lt_version().decode().startswith("lumina_dit gfx950")
     cfg = _lib.LtConfig(variant=0, dim=100, n_layers=1, n_heads=3, n_kv_heads=3, ffn_hidden=256, patch_size=2,
