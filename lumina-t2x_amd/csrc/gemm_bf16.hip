@@ -273,7 +273,10 @@ __device__ __forceinline__ void pp_barrier() {
 // KS: MFMA k-steps per slab (2 = 32-deep slabs, 64-byte LDS rows; 4 = 64-deep, 128-byte rows).  The deep form halves the
 // number of barrier intervals of a K loop; the small-M tiles use it, where an interval holds only 2-4 MFMAs per wave and the
 // loop is barrier-latency bound (the 256-wide tiles cannot: 4 slots x 64 KiB exceed the LDS).
-template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0, int MODE = 0, int KS = 2>
+// AGPR: issue the MFMAs as inline assembly with the accumulators constrained to the AGPR file.  (The builtin lets the compiler
+// use the unified-VGPR form whenever the kernel fits 256 registers, which the 8-wave kernels do; the vendor library's kernels
+// keep their accumulators in AGPRs and run ~25 % faster clocks on the same problem - profiles/r01/vendor_vs_engine_pmc.log.)
+template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0, int MODE = 0, int KS = 2, bool AGPR = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(GemmArgs p) {
     static_assert(MODE == 0 || TAILN == 0, "rendezvous mode has no hand-over barrier");
     static_assert(MODE != 2 || !TRACE, "the register-pipeline loop has no trace build");
@@ -381,7 +384,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     static_assert(TAILN >= 0 && TAILN < MT * NT, "tail MFMAs must all belong to k-step 1");
     auto one_mfma = [&](int idx) __attribute__((always_inline)) {
         const int k = idx / (MT * NT), mt = (idx / NT) % MT, nt = idx % NT;
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], af[k][mt], acc[mt][nt], 0, 0, 0);
+        if constexpr (AGPR)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wf[k][nt]), "v"(af[k][mt]));
+        else
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], af[k][mt], acc[mt][nt], 0, 0, 0);
     };
     // READ(s).  with_tail: the last TAILN MFMAs of the previous slab (k-step 1 fragments, registers only) are issued here,
     // AFTER the hand-over barrier, interleaved with the k-step 0 fragment reads of slab s - so the barrier's release latency
@@ -874,6 +880,8 @@ template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 2, 4, 4, 0, false, 0, 2, 2>(GemmArgs);  // 4 waves x (128 x 128): one wave per SIMD
 template __global__ void gemm_bf16_pp<2, 2, 4, 4, 1, false, 0, 2, 2>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, false, 0, 0, 2, true>(GemmArgs);  // AGPR accumulators (variant 11)
+template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1, false, 0, 0, 2, true>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<0>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0>(GemmArgs);  // 128 x 128, small-M problems
@@ -921,12 +929,12 @@ namespace {
 // ev0 / ev1 (optional): start / stop events attached to THIS dispatch packet (hipExtLaunchKernelGGL) - the timestamps come
 // from the dispatch's own completion signal, no extra barrier packets in the queue (event records around a launch cost
 // tens of microseconds of queue idle time each on this stack)
-template <int WM, int WN, int MT, int NT, int EPI, bool PP, int TAIL = 0, int MODE = 0, int KS = 2>
+template <int WM, int WN, int MT, int NT, int EPI, bool PP, int TAIL = 0, int MODE = 0, int KS = 2, bool AGPR = false>
 int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int SMEM = PP ? 4 * (BM + BN) * 32 * KS : 2 * (BM + BN) * 128;
     const void* fn;
-    if constexpr (PP) fn = (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE, KS>;
+    if constexpr (PP) fn = (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE, KS, AGPR>;
     else fn = (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -936,8 +944,8 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
     const dim3 grid(TM * TN), block(WM * WN * 64);
     if constexpr (PP) {
-        if (ev0) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE, KS>), grid, block, SMEM, stream, ev0, ev1, 0, a);
-        else hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE, KS>), grid, block, SMEM, stream, a);
+        if (ev0) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE, KS, AGPR>), grid, block, SMEM, stream, ev0, ev1, 0, a);
+        else hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, TAIL, MODE, KS, AGPR>), grid, block, SMEM, stream, a);
     } else {
         if (ev0) hipExtLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), grid, block, SMEM, stream, ev0, ev1, 0, a);
         else hipLaunchKernelGGL((gemm_bf16_tn<WM, WN, MT, NT, EPI>), grid, block, SMEM, stream, a);
@@ -993,7 +1001,12 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 10, "gemm: unknown variant %d", variant);
+    LT_REQUIRE(variant >= 0 && variant <= 11, "gemm: unknown variant %d", variant);
+    if (variant == 11) {  // ping-pong 256x256 with the accumulators held in AGPRs
+        LT_REQUIRE(!a.trace, "gemm variant 11: no trace build");
+        return epilogue == 1 ? launch_cfg<2, 4, 4, 2, 1, true, 0, 0, 2, true>(a, stream, ev0, ev1)
+                             : launch_cfg<2, 4, 4, 2, 0, true, 0, 0, 2, true>(a, stream, ev0, ev1);
+    }
     if (variant == 10) {  // 256x256 tile, 4 waves of 128x128 (one wave per SIMD, 256 accumulator registers), register-pipelined loop
         LT_REQUIRE(!a.trace, "gemm variant 10: no trace build");
         return epilogue == 1 ? launch_cfg<2, 2, 4, 4, 1, true, 0, 2, 2>(a, stream, ev0, ev1) : launch_cfg<2, 2, 4, 4, 0, true, 0, 2, 2>(a, stream, ev0, ev1);

@@ -45,7 +45,7 @@ def test_gemm_plain(M, N, K):
     assert max_abs(out, ref) < 0.04 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 2304), (300, 576, 128), (1024, 6912, 2304), (256, 288, 64), (257, 296, 192),
                                    (512, 512, 6144)])
 def test_gemm_tile_variants(variant, M, N, K):
@@ -63,7 +63,7 @@ def test_gemm_tile_variants(variant, M, N, K):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_gemm_identity_asymmetric(variant):
     """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
     K, N = 320, 576
@@ -118,6 +118,7 @@ def test_gemm_persistent_pingpong(M, N, K, epi):
     ref = _gemm(A, W, None, epi, variant=1)
     assert torch.equal(out, ref), rel_l2(out, ref)
     assert torch.equal(_gemm(A, W, None, epi, variant=10), ref)  # 4 waves x (128 x 128), one wave per SIMD
+    assert torch.equal(_gemm(A, W, None, epi, variant=11), ref)  # ping-pong with AGPR accumulators
     if epi == 0:
         assert rel_l2(out, A.float() @ W.float().t()) < 4e-3
     # and through the process-wide switch the engine uses
