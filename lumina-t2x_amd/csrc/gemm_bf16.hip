@@ -571,16 +571,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
             for (int i = 0; i < NM; ++i) {
                 const int kk = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[kk][nt], ac[kk][mt], acc[mt][nt], 0, 0, 0);
-                if (i % 2 == 1) rd(i / 2);
+                // all fragment reads of the next slab in the FIRST half of the MFMA stream (one per MFMA): by the end of the
+                // stream they have landed, so the lgkmcnt(0) in front of the barrier does not expose an LDS round trip
+                if (i < RD) rd(i);
                 if (i % 4 == 3)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i / 4], LDS_PTR(db + ldsoff[i / 4]), 16, voff[i / 4], soff, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < IP; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (4 * j < RD) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                }
                 __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
             }
             __builtin_amdgcn_s_setprio(0);
