@@ -877,6 +877,180 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_persist(GemmArgs p) {
     for (int g_ = grp; g_ < 1; ++g_) pp_barrier();  // group 0 passes the barrier group 1 still executes after its last READ
 }
 
+// ---- 4-wave kernel with VGPR staging (EXPERIMENTAL, variant 12 - written at the end of round 1, NOT yet run on hardware) ---
+// Why: the PMC comparison with the vendor library shows that kernels with 4 waves per workgroup run ~25 % higher
+// clocks than the 8 / 12-wave kernels at the same MFMA work, and that our 4-wave loop (variant 10) loses that again to a 58 %
+// duty cycle - with one wave per SIMD every slow-issuing instruction is a matrix-pipe bubble, and a `buffer_load ... lds` costs
+// its wave 60-180 cycles, eight times per slab.  This kernel keeps the 2x2 waves of 128x128 (32 MFMAs per 32-deep slab, AGPR
+// accumulators) but stages global -> VGPR -> LDS with plain buffer loads (cheap to issue) and ds_write_b128:
+//   * three staging register sets: the loads of slab s+4 are issued right after slab s+1 left its set for the LDS, i.e. about
+//     2.5 slabs (~2500 cycles) before they are needed;
+//   * two LDS buffers of 32 KiB; ONE barrier per slab, in the middle of it:
+//       H0(k): MFMAs of k-step 0 | fragment reads of (k, k-step 1) | wait for slab k+1's loads, ds_write it to buffer (k+1)&1
+//              lgkmcnt(0), s_barrier  -> slab k+1 visible, every wave done with buffer (k+1)&1's previous content (slab k-1)
+//       H1(k): MFMAs of k-step 1 | fragment reads of (k+1, k-step 0) | buffer loads of slab k+4
+//     so the fragments of the next k-step are always read while the current one multiplies, the barrier's stall is the only
+//     bubble, and the LDS write of a slab never races a read of the same buffer:
+//       WAR  buffer (k+1)&1 held slab k-1, read in H1(k-2) and H0(k-1); every wave waited lgkmcnt(0) before B(k-1).
+//       RAW  fragments of (k+1, 0) are read in H1(k), after B(k), which follows every wave's ds_write of slab k+1.
+//   * LDS image, swizzle and fragment reads are those of gemm_bf16_pp (64-byte rows, chunk c of row r at position c ^ ((r>>2)&3)).
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4s(GemmArgs p) {
+    constexpr int MT = 4, NT = 4, BM = 256, BN = 256;
+    constexpr int BUF = (BM + BN) * 64, W_OFF = BM * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, TM, TN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const long long a_left = (long long)(p.M - m0) * p.lda * 2;
+    const long long w_left = (long long)(p.N - n0) * p.ldw * 2;
+    // buffer descriptors as plain SGPR quads (base, stride 0, num_records = bytes left in the panel => rows past M / N read 0):
+    // the loads below are inline assembly, so that the compiler's waitcnt pass does not see them - it guarded the ds_writes of
+    // the staged data with vmcnt(0), i.e. it drained the two younger slabs every iteration; the waits are counted by hand
+    auto make_desc = [](const void* base, long long left) __attribute__((always_inline)) {
+        const unsigned long long a = (unsigned long long)base;
+        u32x4 d;
+        d[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+        d[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+        d[2] = __builtin_amdgcn_readfirstlane((unsigned)(left > 0x7fffffffLL ? 0x7fffffffLL : (left < 0 ? 0 : left)));
+        d[3] = 0x00020000u;
+        return d;
+    };
+    const u32x4 rA = make_desc(p.A + (size_t)m0 * p.lda, a_left);
+    const u32x4 rW = make_desc(p.W + (size_t)n0 * p.ldw, w_left);
+
+    // staging: thread t moves chunk (row = t/4 + 64 i, c = t%4) of A (i = 0..3) and of W (i = 0..3) of every slab
+    const int srow = tid >> 2, sc = tid & 3;
+    const int ga = srow * p.lda * 2 + sc * 16, gw = srow * p.ldw * 2 + sc * 16;   // byte offsets inside the tile panels
+    const int ga_step = 64 * p.lda * 2, gw_step = 64 * p.ldw * 2;
+    const int lds_w = srow * 64 + ((sc ^ ((srow >> 2) & 3)) << 4);                 // (row + 64 i) keeps (row >> 2) & 3
+    u32x4 st[3][8];
+    int gvo[8];  // per-lane byte offsets of the eight chunks inside the A / W panels
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { gvo[i] = ga + i * ga_step; gvo[4 + i] = gw + i * gw_step; }
+    auto gload1 = [&](int slab, u32x4 (&s)[8], int i) __attribute__((always_inline)) {
+        const int soff = __builtin_amdgcn_readfirstlane(slab * 64);
+        if (i < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(s[i]) : "v"(gvo[i]), "s"(rA), "s"(soff) : "memory");
+        else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(s[i]) : "v"(gvo[i]), "s"(rW), "s"(soff) : "memory");
+    };
+    auto gload = [&](int slab, u32x4 (&s)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gload1(slab, s, i);
+    };
+    auto lwrite1 = [&](int slab, const u32x4 (&s)[8], int i) __attribute__((always_inline)) {
+        char* b = smem + (slab & 1) * BUF + lds_w;
+        if (i < 4) *(u32x4*)(b + i * 64 * 64) = s[i];
+        else *(u32x4*)(b + W_OFF + (i - 4) * 64 * 64) = s[i];
+    };
+    auto lwrite = [&](int slab, const u32x4 (&s)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lwrite1(slab, s, i);
+    };
+
+    // fragment reads (as gemm_bf16_pp, KS = 2)
+    const int fswz = (l31 >> 2) & 3;
+    const int a_row_off = (wm * MT * 32 + l31) * 64;
+    const int w_row_off = W_OFF + (wn * NT * 32 + l31) * 64;
+    int coff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) coff[k] = ((2 * k + hi) ^ fswz) << 4;
+    bf16x8 wf[2][NT], af[2][MT];  // [k-step parity]
+    auto fread1 = [&](int slab, int ks, int j) __attribute__((always_inline)) {  // j = 0..3: W fragments, 4..7: A fragments
+        const char* sb = smem + (slab & 1) * BUF;
+        if (j < NT) wf[ks][j] = *(const bf16x8*)(sb + w_row_off + j * 2048 + coff[ks]);
+        else af[ks][j - NT] = *(const bf16x8*)(sb + a_row_off + (j - NT) * 2048 + coff[ks]);
+    };
+    auto fread = [&](int slab, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fread1(slab, ks, j);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // MFMA i (0..15) of k-step ks, in place on AGPR accumulators (inline assembly: the builtin form let the register
+    // allocator rotate the 256 accumulator registers through copies under this kernel's pressure)
+    auto mfma1 = [&](int ks, int i) __attribute__((always_inline)) {
+        const int mt = i / NT, nt = i % NT;
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wf[ks][nt]), "v"(af[ks][mt]));
+    };
+    auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };  // pins the written order
+
+    const int ns = p.K / 32;
+    // prologue: slabs 0..2 on their way, slab 0 in LDS and visible, slab 3 requested, fragments (0, k-step 0) in registers
+    gload(0, st[0]);
+    if (ns > 1) gload(1, st[1]);
+    if (ns > 2) gload(2, st[2]);
+    if (ns > 2) wait_vmcnt<16>();
+    else if (ns > 1) wait_vmcnt<8>();
+    else wait_vmcnt<0>();
+    lwrite(0, st[0]);
+    if (ns > 3) gload(3, st[0]);
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    pp_barrier();
+    fread(0, 0);
+
+    // one slab; snext = the staging set that holds slab k+1 (written to the LDS here, refilled with slab k+4).
+    // steady = std::true_type: slabs k+1 .. k+4 all exist (no branches in the stream)
+    auto slab_step = [&](int k, u32x4 (&snext)[8], auto steady) __attribute__((always_inline)) {
+        constexpr bool ST = decltype(steady)::value;
+        // ---- H0(k): first 8 MFMAs beside the 8 fragment reads of (k, 1); last 8 beside the 8 ds_writes of slab k+1
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mfma1(0, j);
+            fread1(k, 1, j);
+            fence();
+        }
+        // slab k+1 has arrived: its loads are older than those of slabs k+2, k+3 (8 each); slab k+4 is requested in H1(k)
+        if (ST || k + 3 < ns) wait_vmcnt<16>();
+        else if (k + 2 < ns) wait_vmcnt<8>();
+        else wait_vmcnt<0>();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mfma1(0, 8 + j);
+            if (ST || k + 1 < ns) lwrite1(k + 1, snext, j);
+            fence();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): fragments (k, 1) in registers, this wave's ds_writes done
+        pp_barrier();
+        // ---- H1(k): 16 MFMAs beside the 8 fragment reads of (k+1, 0) and the 8 buffer loads of slab k+4
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            mfma1(1, j);
+            if ((j & 1) == 0) { if (ST || k + 1 < ns) fread1(k + 1, 0, j >> 1); }
+            else if (ST || k + 4 < ns) gload1(k + 4, snext, j >> 1);
+            fence();
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    int k = 0;
+    for (; k + 6 < ns; k += 3) {  // steady state: the last step of the triple (k + 2) still has slab k + 6 to request
+        slab_step(k, st[1], std::true_type{});      // staging sets rotate with period 3: slab s lives in set s % 3
+        slab_step(k + 1, st[2], std::true_type{});
+        slab_step(k + 2, st[0], std::true_type{});
+    }
+    for (; k < ns; k += 3) {
+        slab_step(k, st[1], std::false_type{});
+        if (k + 1 < ns) slab_step(k + 1, st[2], std::false_type{});
+        if (k + 2 < ns) slab_step(k + 2, st[0], std::false_type{});
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
+}
+
 // explicit instantiations (hipcc 7.2 does not emit the kernel body for address-only uses inside another template)
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 0>(GemmArgs);
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 1>(GemmArgs);
@@ -889,6 +1063,8 @@ template __global__ void gemm_bf16_pp<2, 2, 4, 4, 0, false, 0, 2, 2>(GemmArgs); 
 template __global__ void gemm_bf16_pp<2, 2, 4, 4, 1, false, 0, 2, 2>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, false, 0, 0, 2, true>(GemmArgs);  // AGPR accumulators (variant 11)
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1, false, 0, 0, 2, true>(GemmArgs);
+template __global__ void gemm_bf16_w4s<0>(GemmArgs);
+template __global__ void gemm_bf16_w4s<1>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<0>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0>(GemmArgs);  // 128 x 128, small-M problems
@@ -915,6 +1091,7 @@ namespace {
 using lt_gemm::gemm_bf16_tn;
 using lt_gemm::gemm_bf16_pp;
 using lt_gemm::gemm_bf16_pp_persist;
+using lt_gemm::gemm_bf16_w4s;
 
 // w1/w3 -> 32-row interleaved packed weight (row P: block = P/64; P%64 < 32 -> w1 else w3)
 __global__ void pack_w13_kernel(const u16* __restrict__ w1, const u16* __restrict__ w3, u16* __restrict__ out,
@@ -963,6 +1140,20 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
 
 int num_cus();
 template <int EPI>
+int launch_w4s(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    constexpr int SMEM = 2 * 512 * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4s<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_done = true;
+    }
+    const dim3 grid(((a.M + 255) / 256) * ((a.N + 255) / 256)), block(256);
+    if (ev0) hipExtLaunchKernelGGL((gemm_bf16_w4s<EPI>), grid, block, SMEM, stream, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((gemm_bf16_w4s<EPI>), grid, block, SMEM, stream, a);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int EPI>
 int launch_persist(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int SMEM = 4 * 512 * 64;
     static bool attr_done = false;
@@ -1008,7 +1199,11 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 11, "gemm: unknown variant %d", variant);
+    LT_REQUIRE(variant >= 0 && variant <= 12, "gemm: unknown variant %d", variant);
+    if (variant == 12) {  // EXPERIMENTAL: 4 waves, VGPR-staged (see gemm_bf16_w4s); not part of the parity suite yet
+        LT_REQUIRE(!a.trace && !a.tile_expert, "gemm variant 12: dense problems, no trace build");
+        return epilogue == 1 ? launch_w4s<1>(a, stream, ev0, ev1) : launch_w4s<0>(a, stream, ev0, ev1);
+    }
     if (variant == 11) {  // ping-pong 256x256 with the accumulators held in AGPRs
         LT_REQUIRE(!a.trace, "gemm variant 11: no trace build");
         return epilogue == 1 ? launch_cfg<2, 4, 4, 2, 1, true, 0, 0, 2, true>(a, stream, ev0, ev1)

@@ -5,6 +5,7 @@ Tolerances (stated here, justified in DESIGN.md): GEMM / attention outputs are b
 max-abs error of a few ulp of the largest output.  Pure data-movement kernels must be bit exact.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -127,6 +128,18 @@ def test_gemm_persistent_pingpong(M, N, K, epi):
         assert torch.equal(_gemm(A, W, None, epi), ref)
     finally:
         set_option("gemm_persist", 0)
+
+
+@pytest.mark.skipif(os.environ.get("LUMINA_EXPERIMENTAL") != "1",
+                    reason="variant 12 (4 waves, VGPR-staged) was written after the last GPU minute of round 1: not yet run on hardware")
+@pytest.mark.parametrize("M,N,K,epi", [(8192, 12288, 2304, 1), (8300, 6912, 2304, 0), (2100, 1280, 128, 1), (512, 512, 64, 0),
+                                       (300, 576, 192, 0), (16384, 2304, 6144, 0)])
+def test_gemm_experimental_4wave_vgpr_staged(M, N, K, epi):
+    """gemm_bf16_w4s: same MFMA order as every other kernel -> bit-identical to variant 1"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    assert torch.equal(_gemm(A, W, None, epi, variant=12), _gemm(A, W, None, epi, variant=1))
 
 
 @pytest.mark.parametrize("variant", [0, 1, 3, 7])
