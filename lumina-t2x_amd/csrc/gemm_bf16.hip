@@ -877,7 +877,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_persist(GemmArgs p) {
     for (int g_ = grp; g_ < 1; ++g_) pp_barrier();  // group 0 passes the barrier group 1 still executes after its last READ
 }
 
-// ---- 4-wave kernel with VGPR staging (EXPERIMENTAL, variant 12 - written at the end of round 1, NOT yet run on hardware) ---
+// ---- 4-wave kernel with VGPR staging (EXPERIMENTAL, variant 12 - written at the end of round 1; first hardware run:
+//      bit-identical to variant 1 on 6 shapes, 9 % SLOWER than the 8-wave ping-pong: profiles/r01/opbench_gemm_vgpr_staged.log) ---
 // Why: the PMC comparison with the vendor library shows that kernels with 4 waves per workgroup run ~25 % higher
 // clocks than the 8 / 12-wave kernels at the same MFMA work, and that our 4-wave loop (variant 10) loses that again to a 58 %
 // duty cycle - with one wave per SIMD every slow-issuing instruction is a matrix-pipe bubble, and a `buffer_load ... lds` costs

@@ -131,7 +131,8 @@ def test_gemm_persistent_pingpong(M, N, K, epi):
 
 
 @pytest.mark.skipif(os.environ.get("LUMINA_EXPERIMENTAL") != "1",
-                    reason="variant 12 (4 waves, VGPR-staged) was written after the last GPU minute of round 1: not yet run on hardware")
+                    reason="variant 12 (4 waves, VGPR-staged): ran once on hardware at the very end of round 1 (6 / 6 bit-identical, "
+                           "profiles/r01/opbench_gemm_vgpr_staged.log); kept out of the default suite until it has seen a full run")
 @pytest.mark.parametrize("M,N,K,epi", [(8192, 12288, 2304, 1), (8300, 6912, 2304, 0), (2100, 1280, 128, 1), (512, 512, 64, 0),
                                        (300, 576, 192, 0), (16384, 2304, 6144, 0)])
 def test_gemm_experimental_4wave_vgpr_staged(M, N, K, epi):
