@@ -895,9 +895,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_persist(GemmArgs p) {
 //       WAR  buffer (k+1)&1 held slab k-1, read in H1(k-2) and H0(k-1); every wave waited lgkmcnt(0) before B(k-1).
 //       RAW  fragments of (k+1, 0) are read in H1(k), after B(k), which follows every wave's ds_write of slab k+1.
 //   * LDS image, swizzle and fragment reads are those of gemm_bf16_pp (64-byte rows, chunk c of row r at position c ^ ((r>>2)&3)).
-template <int EPI>
+// TRACE build (lt_op_gemm_trace, variant 12): s_memtime stamps T0 | 8 MFMA + 8 fragment reads | Tv0 | vmcnt wait | Tv1 | 8 MFMA +
+// 8 ds_write | T1 | lgkmcnt(0) | T2 | barrier | T3 | H1 | next T0.  The stamps are inline assembly (invisible to the compiler's
+// waitcnt pass, so its counted LDS waits stay as in the product build) and are only consumed behind this kernel's own
+// lgkmcnt(0): those of the first half of a slab right after the barrier, those behind it one slab later.
+template <int EPI, bool TRACE = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4s(GemmArgs p) {
     constexpr int MT = 4, NT = 4, BM = 256, BN = 256;
+    unsigned long long t_entry = 0;
+    if constexpr (TRACE) t_entry = __builtin_amdgcn_s_memtime();
     constexpr int BUF = (BM + BN) * 64, W_OFF = BM * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -988,6 +994,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4s(GemmArgs p) {
     auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };  // pins the written order
 
     const int ns = p.K / 32;
+    unsigned tr[6] = {0, 0, 0, 0, 0, 0};              // TRACE: h0a, vm, h0b, lgkm, bar, h1 cycle totals of this wave
+    unsigned long long s0 = 0, sv0 = 0, sv1 = 0, s1 = 0, s2 = 0, s3 = 0;
+    unsigned q1 = 0;                                  // low word of the previous slab's T1
+    auto mt = [](unsigned long long& t) __attribute__((always_inline)) {
+        if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t));
+    };
     // prologue: slabs 0..2 on their way, slab 0 in LDS and visible, slab 3 requested, fragments (0, k-step 0) in registers
     gload(0, st[0]);
     if (ns > 1) gload(1, st[1]);
@@ -1006,6 +1018,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4s(GemmArgs p) {
     auto slab_step = [&](int k, u32x4 (&snext)[8], auto steady) __attribute__((always_inline)) {
         constexpr bool ST = decltype(steady)::value;
         // ---- H0(k): first 8 MFMAs beside the 8 fragment reads of (k, 1); last 8 beside the 8 ds_writes of slab k+1
+        mt(s0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1013,10 +1026,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4s(GemmArgs p) {
             fread1(k, 1, j);
             fence();
         }
+        mt(sv0);
         // slab k+1 has arrived: its loads are older than those of slabs k+2, k+3 (8 each); slab k+4 is requested in H1(k)
         if (ST || k + 3 < ns) wait_vmcnt<16>();
         else if (k + 2 < ns) wait_vmcnt<8>();
         else wait_vmcnt<0>();
+        mt(sv1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             mfma1(0, 8 + j);
@@ -1024,8 +1039,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4s(GemmArgs p) {
             fence();
         }
         __builtin_amdgcn_s_setprio(0);
+        mt(s1);
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): fragments (k, 1) in registers, this wave's ds_writes done
+        fence();
+        // TRACE: T0 .. T1 of this slab and T2, T3 of the previous one have all returned (they are older than the wait above)
+        const unsigned c0 = (unsigned)s0, cv0 = (unsigned)sv0, cv1 = (unsigned)sv1, c1 = (unsigned)s1, c2 = (unsigned)s2, c3 = (unsigned)s3;
+        mt(s2);
         pp_barrier();
+        mt(s3);
         // ---- H1(k): 16 MFMAs beside the 8 fragment reads of (k+1, 0) and the 8 buffer loads of slab k+4
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1033,10 +1054,19 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4s(GemmArgs p) {
             mfma1(1, j);
             if ((j & 1) == 0) { if (ST || k + 1 < ns) fread1(k + 1, 0, j >> 1); }
             else if (ST || k + 4 < ns) gload1(k + 4, snext, j >> 1);
+            if constexpr (TRACE) {
+                if (j == 1) {  // scalar bookkeeping under the MFMAs
+                    tr[0] += cv0 - c0; tr[1] += cv1 - cv0; tr[2] += c1 - cv1;
+                    tr[3] += c2 - q1; tr[4] += c3 - c2; tr[5] += c0 - c3;  // previous slab's second half (first slab: ~0)
+                    q1 = c1;
+                }
+            }
             fence();
         }
         __builtin_amdgcn_s_setprio(0);
     };
+    unsigned long long tstart = 0;
+    if constexpr (TRACE) { tstart = __builtin_amdgcn_s_memtime(); s2 = tstart; s3 = tstart; q1 = (unsigned)tstart; }
     int k = 0;
     for (; k + 6 < ns; k += 3) {  // steady state: the last step of the triple (k + 2) still has slab k + 6 to request
         slab_step(k, st[1], std::true_type{});      // staging sets rotate with period 3: slab s lives in set s % 3
@@ -1049,7 +1079,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4s(GemmArgs p) {
         if (k + 2 < ns) slab_step(k + 2, st[0], std::false_type{});
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    unsigned long long t_loop_end = 0;
+    if constexpr (TRACE) t_loop_end = __builtin_amdgcn_s_memtime();
     store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
+    if constexpr (TRACE) {  // same record as gemm_bf16_pp's trace build (scripts/gemm_trace.py)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (p.trace && lane == 0 && (blockIdx.x & 63) == 5) {
+            unsigned long long* o = p.trace + ((size_t)(blockIdx.x >> 6) * 4 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] = tr[i];
+            o[6] = ((unsigned long long)ns << 32) | (unsigned)(tstart - t_entry);
+            o[7] = ((t_loop_end - tstart) << 20) | ((t_end - t_loop_end) & 0xfffff);
+        }
+    }
 }
 
 // explicit instantiations (hipcc 7.2 does not emit the kernel body for address-only uses inside another template)
@@ -1066,6 +1109,7 @@ template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, false, 0, 0, 2, true>(GemmA
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1, false, 0, 0, 2, true>(GemmArgs);
 template __global__ void gemm_bf16_w4s<0>(GemmArgs);
 template __global__ void gemm_bf16_w4s<1>(GemmArgs);
+template __global__ void gemm_bf16_w4s<0, true>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<0>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0>(GemmArgs);  // 128 x 128, small-M problems
@@ -1140,17 +1184,17 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
 }
 
 int num_cus();
-template <int EPI>
+template <int EPI, bool TRACE = false>
 int launch_w4s(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int SMEM = 2 * 512 * 64;
     static bool attr_done = false;
     if (!attr_done) {
-        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4s<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4s<EPI, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_done = true;
     }
     const dim3 grid(((a.M + 255) / 256) * ((a.N + 255) / 256)), block(256);
-    if (ev0) hipExtLaunchKernelGGL((gemm_bf16_w4s<EPI>), grid, block, SMEM, stream, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL((gemm_bf16_w4s<EPI>), grid, block, SMEM, stream, a);
+    if (ev0) hipExtLaunchKernelGGL((gemm_bf16_w4s<EPI, TRACE>), grid, block, SMEM, stream, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((gemm_bf16_w4s<EPI, TRACE>), grid, block, SMEM, stream, a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1202,7 +1246,11 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
     LT_REQUIRE(variant >= 0 && variant <= 12, "gemm: unknown variant %d", variant);
     if (variant == 12) {  // EXPERIMENTAL: 4 waves, VGPR-staged (see gemm_bf16_w4s); not part of the parity suite yet
-        LT_REQUIRE(!a.trace && !a.tile_expert, "gemm variant 12: dense problems, no trace build");
+        LT_REQUIRE(!a.tile_expert, "gemm variant 12: dense problems only");
+        if (a.trace) {
+            LT_REQUIRE(epilogue == 0, "gemm trace: plain epilogue");
+            return launch_w4s<0, true>(a, stream, ev0, ev1);
+        }
         return epilogue == 1 ? launch_w4s<1>(a, stream, ev0, ev1) : launch_w4s<0>(a, stream, ev0, ev1);
     }
     if (variant == 11) {  // ping-pong 256x256 with the accumulators held in AGPRs

@@ -24,7 +24,7 @@ for name, M, N, K in shapes:
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     for _ in range(6):
         torch.nn.functional.linear(A, W)
-    for variant in (1, 3, 10):  # classic 256x256, ping-pong 256x256, 4-wave 128x128-per-wave
+    for variant in (1, 3, 10, 12):  # classic 256x256, ping-pong 256x256, 4-wave LDS-DMA, 4-wave VGPR-staged
         for _ in range(6):
             ok(L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(out), M, N, K, 0, variant, stream()))
     torch.cuda.synchronize()
