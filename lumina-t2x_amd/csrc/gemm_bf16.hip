@@ -279,7 +279,6 @@ __device__ __forceinline__ void pp_barrier() {
 template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0, int MODE = 0, int KS = 2, bool AGPR = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(GemmArgs p) {
     static_assert(MODE == 0 || TAILN == 0, "rendezvous mode has no hand-over barrier");
-    static_assert(MODE != 2 || !TRACE, "the register-pipeline loop has no trace build");
     static_assert(KS == 2 || KS == 4, "slab depth 32 or 64");
     static_assert(TAILN == 0 || KS == 2, "tail overlap is written for 32-deep slabs");
     constexpr int RB = KS * 32;          // bytes per LDS row
@@ -592,9 +591,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(ta));   // T1: MFMA stream issued
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): slab k+1's fragments are in registers
+            if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(tb));   // T2
             wait_vmcnt<IP>();                    // slab k+2 landed, slab k+3 in flight
+            if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(tc));   // T3
             pp_barrier();
+            if constexpr (TRACE) {  // buckets: 0 = MFMA / read / DMA stream, 2 = lgkmcnt wait, 1 = vmcnt wait, 3 = barrier
+                unsigned long long td;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td));  // T4 (the wait is the trace build's overhead)
+                tr[0] += ta - tprev; tr[2] += tb - ta; tr[1] += tc - tb; tr[3] += td - tc;
+                tprev = td;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         reads_to(0, wf, af);
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -602,6 +611,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         else wait_vmcnt<0>();
         pp_barrier();
         int k = 0;
+        if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); }
         if constexpr (PINNED) {
             for (; k + 4 < ns; k += 2) {  // both bodies of the pair are steady state: k + 1 + 3 < ns
                 body_pinned(k, wf, af, wf2, af2);
@@ -1105,6 +1115,7 @@ template __global__ void gemm_bf16_pp<4, 3, 2, 3, 0>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, true>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 2, 4, 4, 0, false, 0, 2, 2>(GemmArgs);  // 4 waves x (128 x 128): one wave per SIMD
 template __global__ void gemm_bf16_pp<2, 2, 4, 4, 1, false, 0, 2, 2>(GemmArgs);
+template __global__ void gemm_bf16_pp<2, 2, 4, 4, 0, true, 0, 2, 2>(GemmArgs);  // ... its trace build
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0, false, 0, 0, 2, true>(GemmArgs);  // AGPR accumulators (variant 11)
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1, false, 0, 0, 2, true>(GemmArgs);
 template __global__ void gemm_bf16_w4s<0>(GemmArgs);
@@ -1259,7 +1270,18 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
                              : launch_cfg<2, 4, 4, 2, 0, true, 0, 0, 2, true>(a, stream, ev0, ev1);
     }
     if (variant == 10) {  // 256x256 tile, 4 waves of 128x128 (one wave per SIMD, 256 accumulator registers), register-pipelined loop
-        LT_REQUIRE(!a.trace, "gemm variant 10: no trace build");
+        if (a.trace) {
+            LT_REQUIRE(epilogue == 0, "gemm trace: plain epilogue");
+            constexpr int S10 = 4 * 512 * 64;
+            static bool done10 = false;
+            if (!done10) {
+                LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp<2, 2, 4, 4, 0, true, 0, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, S10));
+                done10 = true;
+            }
+            hipLaunchKernelGGL((gemm_bf16_pp<2, 2, 4, 4, 0, true, 0, 2, 2>), dim3(((a.M + 255) / 256) * ((a.N + 255) / 256)), dim3(256), S10, stream, a);
+            LT_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
         return epilogue == 1 ? launch_cfg<2, 2, 4, 4, 1, true, 0, 2, 2>(a, stream, ev0, ev1) : launch_cfg<2, 2, 4, 4, 0, true, 0, 2, 2>(a, stream, ev0, ev1);
     }
     if (variant == 9 || (variant == 0 && g_gemm_persist && epilogue == 1 && !a.tile_expert && !a.trace && a.K >= 96 &&
