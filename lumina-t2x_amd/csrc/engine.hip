@@ -622,6 +622,10 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     LT_REQUIRE(cfg->variant != LT_VARIANT_NEXT_MOE || (cfg->num_experts >= 2 && cfg->num_experts <= 8),
                "lt_create: the MoE variant needs 2..8 experts (top-2 routing), got %d", cfg->num_experts);
     const VariantDesc vd = variant_desc(cfg->variant);
+    LT_REQUIRE(cfg->dim > 0 && cfg->n_layers >= 1 && cfg->n_heads >= 1 && cfg->n_kv_heads >= 1 && cfg->ffn_hidden > 0 && cfg->adaln_dim > 0,
+               "lt_create: dim, n_layers, n_heads, n_kv_heads, ffn_hidden and adaln_dim must be positive");
+    LT_REQUIRE(cfg->patch_size >= 1 && cfg->in_channels >= 1 && cfg->out_channels >= 1 && cfg->max_tokens >= 1 && cfg->max_text >= 0,
+               "lt_create: patch_size, in_channels, out_channels, max_tokens must be positive (max_text >= 0)");
     LT_REQUIRE(cfg->dim % cfg->n_heads == 0, "dim %% n_heads != 0");
     LT_REQUIRE(cfg->n_heads % cfg->n_kv_heads == 0, "n_heads %% n_kv_heads != 0");
     const int hd = cfg->dim / cfg->n_heads;
@@ -754,6 +758,8 @@ extern "C" void lt_destroy(lt_engine* e) {
 extern "C" int lt_set_weight(lt_engine* e, const char* key, const void* src_dev, int32_t dtype, const int64_t* shape,
                              int32_t ndim, void* stream) {
     LT_REQUIRE(e && key && src_dev && shape, "lt_set_weight: null argument");
+    LT_REQUIRE(ndim >= 1 && ndim <= 8, "lt_set_weight: ndim %d outside 1..8", ndim);
+    for (int i = 0; i < ndim; ++i) LT_REQUIRE(shape[i] > 0, "weight '%s': shape[%d] = %lld", key, i, (long long)shape[i]);
     Slot s;
     if (find_slot(e, key, &s)) return 2;
     long long n = 1;
@@ -882,6 +888,7 @@ extern "C" int lt_forward(lt_engine* e, const void* x_dev, const float* t_dev, v
 extern "C" int lt_forward_packed(lt_engine* e, const void* const* x_ptrs, const int32_t* hw_host, const float* t_dev,
                                  void* const* out_ptrs, const lt_step_args* a, void* stream) {
     LT_REQUIRE(e && x_ptrs && hw_host && t_dev && out_ptrs && a, "lt_forward_packed: null argument");
+    LT_REQUIRE(a->batch >= 1 && a->batch <= e->cfg.max_batch, "lt_forward_packed: batch %d outside 1..max_batch %d", a->batch, e->cfg.max_batch);
     for (int b = 0; b < a->batch; ++b) LT_REQUIRE(x_ptrs[b] && out_ptrs[b], "lt_forward_packed: null sample pointer %d", b);
     if (!e->pk_dev) LT_CHECK_HIP(hipMalloc((void**)&e->pk_dev, 128 * sizeof(int)));
     PackedDesc pk{x_ptrs, out_ptrs, hw_host};
@@ -901,6 +908,14 @@ extern "C" int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, vo
     LT_REQUIRE(method >= LT_ODE_EULER && method <= LT_ODE_RK4, "lt_sample_ode: unknown method %d", method);
     hipStream_t s = (hipStream_t)stream;
     const int B = a->batch;
+    // the state buffers were sized by lt_create for max_batch x max_tokens; check before the first copy into them (the model
+    // calls below validate the same things, but only after z has been copied)
+    LT_REQUIRE(B >= 1 && B <= e->cfg.max_batch, "lt_sample_ode: batch %d outside 1..max_batch %d", B, e->cfg.max_batch);
+    LT_REQUIRE(a->latent_h > 0 && a->latent_w > 0 && a->latent_h % e->cfg.patch_size == 0 && a->latent_w % e->cfg.patch_size == 0 &&
+                   (long long)(a->latent_h / e->cfg.patch_size) * (a->latent_w / e->cfg.patch_size) <= e->cfg.max_tokens,
+               "lt_sample_ode: latent %dx%d is not a positive multiple of the patch size or exceeds max_tokens %d", a->latent_h, a->latent_w,
+               e->cfg.max_tokens);
+    LT_REQUIRE(a->io_dtype == LT_BF16 || a->io_dtype == LT_F32, "io_dtype must be bf16 or f32");
     const int stages = method == LT_ODE_EULER ? 1 : (method == LT_ODE_MIDPOINT ? 2 : 4);
     const int ncalls = (n_grid - 1) * stages;
     const long long n = (long long)B * e->cfg.in_channels * a->latent_h * a->latent_w;

@@ -30,6 +30,31 @@ def _require_gpu(t: torch.Tensor, name: str) -> None:
         )
 
 
+class _SourceCache:
+    """Remembers WHICH tensors the engine's conditioning was prepared from, so that the per-step calls of an ODE solve (same
+    ``model_kwargs`` objects every step) do not redo the caption work.  A hit needs the very same tensor objects, unmodified
+    (``_version``); the cache keeps them referenced, so their storage cannot be freed and handed to a different prompt that
+    would then look identical by address."""
+
+    def __init__(self):
+        self._src = None
+        self._key = None
+
+    @staticmethod
+    def _describe(tensors, extra):
+        return (tuple((t._version, tuple(t.shape), t.dtype, t.device) for t in tensors), tuple(extra))
+
+    def hit(self, tensors, extra=()) -> bool:
+        return (self._src is not None and len(self._src) == len(tensors) and all(a is b for a, b in zip(self._src, tensors))
+                and self._key == self._describe(tensors, extra))
+
+    def store(self, tensors, extra=()) -> None:
+        self._src, self._key = tuple(tensors), self._describe(tensors, extra)
+
+    def clear(self) -> None:
+        self._src = self._key = None
+
+
 @dataclass
 class EngineLimits:
     max_batch: int = 2
@@ -64,7 +89,7 @@ class DiTEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.lt_create(C.byref(cfg), C.byref(handle)), "lt_create")
         self.handle = handle
-        self._prompt_key = None
+        self._prompt = _SourceCache()
         self.num_classes = num_classes
 
     def __del__(self):
@@ -99,9 +124,7 @@ class DiTEngine:
     # ---- prompt ----------------------------------------------------------------------------------
     def prepare_prompt(self, cap_feats: torch.Tensor, cap_mask: torch.Tensor) -> None:
         _require_gpu(cap_feats, "cap_feats")
-        key = (cap_feats.data_ptr(), cap_feats._version, tuple(cap_feats.shape), cap_feats.dtype,
-               cap_mask.data_ptr(), cap_mask._version)
-        if key == self._prompt_key:
+        if self._prompt.hit((cap_feats, cap_mask), ("prompt",)):
             return
         feats = cap_feats if cap_feats.dtype in (torch.float32, torch.bfloat16) else cap_feats.float()
         feats = feats.contiguous()
@@ -112,16 +135,14 @@ class DiTEngine:
                                             C.c_void_p(mask.data_ptr()), B, T, C.c_void_p(_stream_ptr(self.device)))
         _lib.check(rc, "lt_prepare_prompt")
         self._keep = (feats, mask)  # keep the temporaries alive until the stream has consumed them
-        self._prompt_key = key
+        self._prompt.store((cap_feats, cap_mask), ("prompt",))
 
     def prepare_prompt_regional(self, cap_feats: torch.Tensor, cap_mask: torch.Tensor, global_feats: torch.Tensor,
                                 global_mask: torch.Tensor, h_split: int, w_split: int) -> None:
         """compositional Next-DiT: Y captions (regions of the cond row ..., uncond row) + the one-row global caption"""
         _require_gpu(cap_feats, "cap_feats")
-        key = ("regional", cap_feats.data_ptr(), cap_feats._version, tuple(cap_feats.shape), cap_feats.dtype, cap_mask.data_ptr(),
-               cap_mask._version, global_feats.data_ptr(), global_feats._version, tuple(global_feats.shape), global_mask.data_ptr(),
-               global_mask._version, h_split, w_split)
-        if key == self._prompt_key:
+        src, extra = (cap_feats, cap_mask, global_feats, global_mask), ("regional", int(h_split), int(w_split))
+        if self._prompt.hit(src, extra):
             return
         dt = cap_feats.dtype if cap_feats.dtype in (torch.float32, torch.bfloat16) else torch.float32
         feats = cap_feats.to(dt).contiguous()
@@ -136,20 +157,19 @@ class DiTEngine:
                                                      C.c_void_p(_stream_ptr(self.device)))
         _lib.check(rc, "lt_prepare_prompt_regional")
         self._keep = (feats, mask, gfeats, gmask)
-        self._prompt_key = key
+        self._prompt.store(src, extra)
 
     def prepare_labels(self, y: torch.Tensor) -> None:
         """class-conditional variants: y int [B] (null class = num_classes, Next-DiT-ImageNet/sample.py:181)"""
         _require_gpu(y, "y")
-        key = ("labels", y.data_ptr(), y._version, tuple(y.shape))
-        if key == self._prompt_key:
+        if self._prompt.hit((y,), ("labels",)):
             return
         lab = y.to(dtype=torch.int32).contiguous()
         with torch.cuda.device(self.device):
             rc = self.lib.lt_prepare_labels(self.handle, C.c_void_p(lab.data_ptr()), lab.numel(), C.c_void_p(_stream_ptr(self.device)))
         _lib.check(rc, "lt_prepare_labels")
         self._keep = (lab,)
-        self._prompt_key = key
+        self._prompt.store((y,), ("labels",))
 
     # ---- one model evaluation --------------------------------------------------------------------
     def _step_args(self, x: torch.Tensor, cfg_scale: float, scale_factor: float, scale_watershed: float,

@@ -87,6 +87,21 @@ def test_bad_variant_rejected(lib):
     assert b"variant" in lib.lt_last_error()
 
 
+@pytest.mark.parametrize("field,value,needle", [("n_heads", 0, b"positive"), ("n_kv_heads", 0, b"positive"), ("n_layers", 0, b"positive"),
+                                                ("patch_size", 0, b"positive"), ("max_tokens", 0, b"positive"), ("dim", -64, b"positive"),
+                                                ("max_batch", 9, b"max_batch"), ("cap_feat_dim", 100, b"cap_feat_dim")])
+def test_degenerate_configs_rejected_before_any_allocation(lib, field, value, needle):
+    """A zero head count used to reach `dim % n_heads`; every degenerate field is an error message now, not a SIGFPE."""
+    kw = dict(variant=0, dim=576, n_layers=1, n_heads=8, n_kv_heads=8, ffn_hidden=1536, patch_size=2, in_channels=4, out_channels=8,
+              cap_feat_dim=128, adaln_dim=576, qk_norm=1, num_classes=0, norm_eps=1e-5, max_batch=2, max_tokens=64, max_text=64,
+              rope_table_len=384)
+    kw[field] = value
+    cfg = _lib.LtConfig(**kw)
+    handle = C.c_void_p()
+    assert lib.lt_create(C.byref(cfg), C.byref(handle)) != 0 and not handle.value
+    assert needle in lib.lt_last_error(), lib.lt_last_error()
+
+
 def test_null_arguments_are_errors_not_crashes(lib):
     assert lib.lt_forward(None, None, None, None, None, None) != 0
     assert lib.lt_op_gemm_bf16(None, None, None, -1, None, 1, 8, 64, 0, 0, None) != 0

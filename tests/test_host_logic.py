@@ -281,3 +281,29 @@ def test_sde_samplers_paths_and_losses_match_reference(golden_dir):
                "diff_dec": plan.compute_diffusion(xt, tt, form="decreasing", norm=0.7)}
         for nm, val in got.items():
             torch.testing.assert_close(val * torch.ones(1), torch.from_numpy(g[f"{tag}_{nm}"]), rtol=1e-5, atol=1e-6, msg=f"{tag}_{nm}")
+
+
+def test_prompt_cache_needs_the_same_unmodified_tensor_objects():
+    """The engine skips the caption work when a step passes the tensors it was prepared from.  An address-based key would
+    also 'hit' on a NEW prompt whose storage happens to reuse a freed block; identity + version + a kept reference cannot."""
+    import importlib
+
+    eng = importlib.import_module("lumina_t2x_amd.engine")
+    cache = eng._SourceCache()
+    feats, mask = torch.randn(2, 8, 16), torch.ones(2, 8, dtype=torch.int32)
+    assert not cache.hit((feats, mask), ("prompt",))
+    cache.store((feats, mask), ("prompt",))
+    assert cache.hit((feats, mask), ("prompt",))
+    assert not cache.hit((feats, mask), ("regional", 1, 2))          # other kind of conditioning
+    assert not cache.hit((feats.clone(), mask), ("prompt",))          # equal content, different object
+    feats.mul_(2.0)                                                   # in-place edit bumps _version
+    assert not cache.hit((feats, mask), ("prompt",))
+    cache.store((feats, mask), ("prompt",))
+    # the cache holds its sources: dropping the caller's names cannot free the storage for a look-alike successor
+    import weakref
+
+    ref = weakref.ref(feats)
+    del feats
+    assert ref() is not None
+    cache.clear()
+    assert ref() is None
