@@ -179,9 +179,13 @@ int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, 
  * marks a padding segment whose output rows are left untouched.  M % 256 == 0; tile_expert_dev: int32 [M / 256]. */
 int lt_op_gemm_grouped(const void* A_dev, const void* W_dev, const void* tile_expert_dev, int64_t w_expert_stride,
                        void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* stream);
-/* diagnostics: the ping-pong GEMM (variant 3 | 4) built with s_memtime stamps; trace_dev receives, for every 64th
- * workgroup and each of its waves, 8 x uint64: cycle totals of {fragment-read issue, vmcnt wait, lgkmcnt wait,
- * pre-MFMA barrier, MFMA segment, post-MFMA barrier}, the slab count and the end stamp. */
+/* diagnostics: a GEMM built with s_memtime stamps (variant 3 | 4 ping-pong, 5 rendezvous, 10 four-wave LDS-DMA, 12 four-wave
+ * VGPR-staged; plain epilogue); trace_dev (>= 64 * waves * 8 uint64, zeroed by the caller) receives, for every 64th workgroup
+ * and each of its waves, 8 x uint64: six per-wave tick totals - variant 3 / 4 / 5: {fragment-read issue, vmcnt wait, lgkmcnt
+ * wait, pre-MFMA barrier, MFMA segment, post-MFMA barrier}; 10: {MFMA / read / DMA stream, vmcnt wait, lgkmcnt wait, barrier,
+ * 0, 0} over the steady-state slabs; 12: {8 MFMA + reads, vmcnt wait, 8 MFMA + ds_write, lgkmcnt wait, barrier, second
+ * half} - then (slab count << 32 | prologue ticks) and (main-loop ticks << 20 | epilogue ticks).  Readers:
+ * scripts/gemm_trace.py, scripts/ubench/gemm_trace_native.cpp. */
 int lt_op_gemm_trace(const void* A_dev, const void* W_dev, void* C_dev, int32_t M, int32_t N, int32_t K,
                      int32_t variant, void* trace_dev, void* stream);
 /* interleave w1[F,K], w3[F,K] into the packed [2F,K] layout epilogue 1 expects */
