@@ -187,6 +187,55 @@ def bench_attn(rounds, variants):
     set_option("attention_variant", 3)
 
 
+def bench_attn_vendor(rounds):
+    """What does the library attention reach on this chip?  torch's scaled_dot_product_attention (flash / mem-efficient / math
+    back ends as the build offers them) on the engine's shape - head_dim 72 as is and zero-padded to 80 / 96 / 128 (what a
+    generic kernel would run), plus head_dim 64 and 128 at the same token count for scale - next to the engine's kernel.
+    FLOPs are counted on the TRUE head_dim (72) for the padded runs, so the TF/s column is comparable with the engine's."""
+    import torch.nn.functional as F
+
+    L = lib()
+    B, H, N = 2, 32, 4096
+    g = torch.Generator(device="cuda").manual_seed(3)
+
+    def sdpa_case(hd_true, hd_run):
+        q = torch.randn(B, H, N, hd_true, device="cuda", generator=g).to(torch.bfloat16)
+        k = torch.randn(B, H, N, hd_true, device="cuda", generator=g).to(torch.bfloat16)
+        v = torch.randn(B, H, N, hd_true, device="cuda", generator=g).to(torch.bfloat16)
+        if hd_run != hd_true:
+            q, k, v = (F.pad(t, (0, hd_run - hd_true)) for t in (q, k, v))
+        scale = 1.0 / math.sqrt(hd_true)
+        return lambda: F.scaled_dot_product_attention(q, k, v, scale=scale)
+
+    cases = {}
+    for hd_true, hd_run in ((72, 72), (72, 80), (72, 96), (72, 128), (64, 64), (128, 128)):
+        fn = sdpa_case(hd_true, hd_run)
+        try:
+            fn()
+            torch.cuda.synchronize()
+            cases[f"sdpa hd{hd_true} run as {hd_run}"] = (fn, hd_true)
+        except Exception as exc:  # a back end may refuse a head_dim
+            print(f"sdpa hd{hd_true} run as {hd_run}: not available ({type(exc).__name__}: {str(exc)[:80]})", flush=True)
+    hd = 72
+    qkv = torch.randn(B * N, 3 * H * hd, device="cuda", generator=g).to(torch.bfloat16)
+    q = torch.empty(B, H, N, hd, device="cuda", dtype=torch.bfloat16)
+    k = torch.empty_like(q)
+    vt = torch.empty(B, H, hd, N, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(B, N, H * hd, device="cuda", dtype=torch.bfloat16)
+    ok(L.lt_op_qk_norm_rope(P(qkv), 3 * H * hd, 0, P(None), P(None), C.c_float(1e-5), P(q), B, N, H, hd, 0, P(None), 64, 1.0, stream()))
+    ok(L.lt_op_qk_norm_rope(P(qkv), 3 * H * hd, H * hd, P(None), P(None), C.c_float(1e-5), P(k), B, N, H, hd, 0, P(None), 64, 1.0, stream()))
+    ok(L.lt_op_v_transpose(P(qkv), 3 * H * hd, 2 * H * hd, P(vt), B, N, N, H, hd, stream()))
+
+    def ours():
+        ok(L.lt_op_attention(P(q), P(k), P(vt), None, P(out), P(None), 0, B, H, H, N, N, N, hd, C.c_float(1.0 / math.sqrt(hd)), 0, stream()))
+    cases["engine hd72 (attention_variant 3)"] = (ours, 72)
+    r = ab({name: fn for name, (fn, _) in cases.items()}, rounds)
+    for name, (_, hd_true) in cases.items():
+        med, mn = r[name]
+        fl = 4.0 * B * H * N * N * hd_true
+        print(f"attn B{B} H{H} N{N} {name}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s (best {fl/mn/1e9:7.1f})", flush=True)
+
+
 def bench_elem(rounds):
     L = lib()
     B, N, d = 2, 4096, 2304
@@ -289,5 +338,7 @@ if __name__ == "__main__":
         bench_insitu(a.rounds)
     if "attn" in a.what:
         bench_attn(a.rounds, [int(v) for v in a.attn_variants.split(",")])
+    if "attn_vendor" in a.what:
+        bench_attn_vendor(a.rounds)
     if "elem" in a.what:
         bench_elem(a.rounds)
