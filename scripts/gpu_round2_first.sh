@@ -1,5 +1,5 @@
 #!/bin/bash
-# First GPU call of round 2 (~6 GPU-minutes): the three measurements DESIGN.md 5.1 asks for before any more GEMM code is written.
+# First GPU call of round 2 (~10 GPU-minutes): the three measurements DESIGN.md 5.1 asks for before any more GEMM code is written.
 #   1. scripts/ubench/gemm_energy.hip  - what each main-loop ingredient costs under the power-managed clock, 1 vs 2 waves per SIMD
 #   2. scripts/gemm_trace.py           - s_memtime breakdown of the 4-wave VGPR-staged kernel (variant 12) next to the 8-wave ping-pong
 #   3. scripts/opbench.py attn_vendor - library attention (torch SDPA) on the engine's shape, next to attention_variant 3
