@@ -171,7 +171,8 @@ int lt_profile_set_budget(lt_engine* e, int32_t klass, int64_t max_event_launche
  * 9: persistent ping-pong; 10: 4 waves x 128x128 (LDS-DMA); 11: ping-pong with AGPR accumulators (A/B variants, parity-tested);
  * 12: experimental 4-wave VGPR-staged kernel (bit-identical in its first hardware run; tests gated by LUMINA_EXPERIMENTAL=1);
  * 13: experimental persistent 4-wave kernel (variant 10's loop carried across tile boundaries; K % 64 == 0, K >= 128, no bias;
- *     compiled and ISA-checked, not yet run on hardware; tests gated by LUMINA_EXPERIMENTAL=1). */
+ *     compiled and ISA-checked, not yet run on hardware; tests gated by LUMINA_EXPERIMENTAL=1); 14: the same with a tile's
+ *     epilogue issued from inside the next tile's first slab. */
 int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, int32_t bias_dtype,
                     void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
                     void* stream);

@@ -1115,7 +1115,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4s(GemmArgs p) {
 //     that has to let them pass (first body after a boundary) is exact - a branchy `if (m < M)` store could issue fewer and
 //     the wait would then be too weak;
 //   * slabs are consumed in pairs (fragment register sets alternate), so K % 64 == 0; K >= 128.  No bias epilogue.
-template <int EPI>
+//   * OVL (variant 14): a tile's epilogue is not a phase of its own but rides in the FIRST body of the next tile - that body's
+//     k-step-0 MFMAs take the constant 0 as accumulator input, each right after the old contents of its 32x32 accumulator tile
+//     were copied out, and the pack / store of that tile issues behind the MFMA.  Only the workgroup's last tile stores the plain way.
+template <int EPI, bool OVL = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmArgs p) {
     constexpr int MT = 4, NT = 4, NW = 4, BM = 256, BN = 256, IP = 8;
     constexpr int SLAB = (BM + BN) * 64, W_OFF = BM * 64, TSTRIDE = 2048;
@@ -1233,23 +1236,30 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             const int kk = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[kk][nt], ac[kk][mt], acc[mt][nt], 0, 0, 0);
+            // OVL: every MFMA of the kernel is the in-place inline-assembly form, so that the accumulators stay in one fixed set
+            // of AGPRs through the boundary body as well (mixing it with the builtin made the allocator move them around the
+            // loop); the written order is pinned by scheduling fences instead of sched_group_barrier masks
+            if constexpr (OVL) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wc[kk][nt]), "v"(ac[kk][mt]));
+            else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[kk][nt], ac[kk][mt], acc[mt][nt], 0, 0, 0);
             if (i < RD) rd(i);
             if (i % 4 == 3)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(i / 4 < 4 ? rA : rW, LDS_PTR(db + ldsoff[i / 4]), 16, voff[i / 4], soff, 0, 0);
+            if constexpr (OVL) __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (!OVL) {
 #pragma unroll
-        for (int j = 0; j < IP; ++j) {
-            if (4 * j < RD) {
+            for (int j = 0; j < IP; ++j) {
+                if (4 * j < RD) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
                 }
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1262,62 +1272,139 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmArgs p) {
         pp_barrier();
         ++g;
     };
-    // epilogue through the tile's C descriptor: lane holds, per 32x32 MFMA tile, row l31 and columns 8 q + 4 hi + j (as store_tile)
+    // epilogue through the tile's C descriptor: lane holds, per 32x32 MFMA tile, row l31 and columns 8 q + 4 hi + j (as store_tile).
+    // emit: the two 16-byte stores of output group (mt, ng) - EPI 0: accumulator tile (mt, ng) in `x`; EPI 1: silu(x) * y of the
+    // tile pair (mt, 2 ng), (mt, 2 ng + 1)
+    auto emit = [&](__amdgpu_buffer_rsrc_t rC, int n0_, int mt, int ng, const f32x16& x, const f32x16& y) __attribute__((always_inline)) {
+        const int row_off = (wm * MT * 32 + mt * 32 + l31) * p.ldc * 2;  // bytes from the tile's first C row (< 2^31: launcher)
+        const int cbase = EPI == 0 ? n0_ + wn * NT * 32 + ng * 32 : (n0_ + wn * NT * 32 + ng * 64) / 2;
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            float vv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (EPI == 0) {
+                    vv[j] = x[8 * qp + j];
+                } else {  // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
+                    const float a = bfr(x[8 * qp + j]);
+                    const float b = bfr(y[8 * qp + j]);
+                    vv[j] = bfr(silu_f(a)) * b;
+                }
+            }
+            unsigned ax = pack2bf(vv[0], vv[1]), ay = pack2bf(vv[2], vv[3]);
+            unsigned bx = pack2bf(vv[4], vv[5]), by = pack2bf(vv[6], vv[7]);
+            auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            const int col = cbase + 16 * qp + 8 * hi;
+            const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+            // columns past the end: an offset no descriptor covers (the store is issued and dropped)
+            const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(o, rC, off, 0, 0);
+        }
+    };
     auto store_out = [&](const Tile& t) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)t.c, 0, t.c_bytes, 0x00020000);
-        const int n0_ = t.n0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int row_off = (wm * MT * 32 + mt * 32 + l31) * p.ldc * 2;  // bytes from the tile's first C row (< 2^31: launcher)
             constexpr int NG = EPI == 0 ? NT : NT / 2;
 #pragma unroll
             for (int ng = 0; ng < NG; ++ng) {
-                const int cbase = EPI == 0 ? n0_ + wn * NT * 32 + ng * 32 : (n0_ + wn * NT * 32 + ng * 64) / 2;
-#pragma unroll
-                for (int qp = 0; qp < 2; ++qp) {
-                    float vv[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if constexpr (EPI == 0) {
-                            vv[j] = acc[mt][ng][8 * qp + j];
-                        } else {  // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
-                            const float a = bfr(acc[mt][2 * ng][8 * qp + j]);
-                            const float b = bfr(acc[mt][2 * ng + 1][8 * qp + j]);
-                            vv[j] = bfr(silu_f(a)) * b;
-                        }
-                    }
-                    unsigned ax = pack2bf(vv[0], vv[1]), ay = pack2bf(vv[2], vv[3]);
-                    unsigned bx = pack2bf(vv[4], vv[5]), by = pack2bf(vv[6], vv[7]);
-                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                    const int col = cbase + 16 * qp + 8 * hi;
-                    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                    // columns past the end: an offset no descriptor covers (the store is issued and dropped)
-                    const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rC, off, 0, 0);
-                }
+                if constexpr (EPI == 0) emit(rC, t.n0, mt, ng, acc[mt][ng], acc[mt][ng]);
+                else emit(rC, t.n0, mt, ng, acc[mt][2 * ng], acc[mt][2 * ng + 1]);
             }
         }
     };
+    // OVL: first body of a tile whose predecessor `done` still sits in the accumulators (see the kernel comment)
+    auto body_first = [&](const Tile& done, bf16x8 (&wc)[2][NT], bf16x8 (&ac)[2][MT], bf16x8 (&wn_)[2][NT], bf16x8 (&an)[2][MT]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)cur.a, 0, cur.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)cur.w, 0, cur.w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)done.c, 0, done.c_bytes, 0x00020000);
+        const char* sb = smem + ((g + 1) & 3) * SLAB;
+        char* db = smem + ((g + 3) & 3) * SLAB;
+        const int soff = 3 * 64;  // this tile's slab 3 (ns >= 4)
+        f32x16 keep;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep[r] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int kk = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
+            if (kk == 0) {
+                // copy-out, pinned in front of its MFMA by an empty volatile asm that wants the copy in VGPRs right here (left to
+                // itself the allocator hoisted the reads of eleven tiles to the top of the body and spilled around them)
+                f32x16 old = acc[mt][nt];
+                asm volatile("" : "+v"(old));
+                // in place ("+a": same registers in and out, although the instruction only writes them) - the builtin form let
+                // the allocator put the new tile into a different register tuple, and the loop then paid for rotating them back
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "+a"(acc[mt][nt]) : "v"(wc[0][nt]), "v"(ac[0][mt]));
+                if constexpr (EPI == 0) {
+                    emit(rC, done.n0, mt, nt, old, old);
+                } else {
+                    if ((nt & 1) == 0) keep = old;
+                    else emit(rC, done.n0, mt, nt >> 1, keep, old);
+                }
+            } else {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wc[kk][nt]), "v"(ac[kk][mt]));
+            }
+            if (i < RD) {
+                const int rk = i / (MT + NT), j = i % (MT + NT);
+                if (j < NT) wn_[rk][j] = *(const bf16x8*)(sb + w_row_off + j * TSTRIDE + coff[rk]);
+                else an[rk][j - NT] = *(const bf16x8*)(sb + a_row_off + (j - NT) * TSTRIDE + coff[rk]);
+            }
+            if (i % 4 == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(i / 4 < 4 ? rA : rW, LDS_PTR(db + ldsoff[i / 4]), 16, voff[i / 4], soff, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // one accumulator tile at a time (register budget), in this order
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        wait_vmcnt<IP + NST>();  // slab g+2 landed; younger: this body's 8 DMAs and NST stores, in whatever interleaving
+        pp_barrier();
+        ++g;
+    };
 
-    for (int t = 0; t < my_tiles; ++t) {
+    auto clear_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int s = 0; s < ns; s += 2) {  // slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
-            body(s + 3, wf, af, wf2, af2);
-            body(s + 4, wf2, af2, wf, af);
-        }
-        store_out(cur);
-        after_epilogue = true;
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
         if (has_next) {
             cur = nxt;
             v += gridDim.x;
             has_next = v + (int)gridDim.x < ntiles;
             nxt = has_next ? setup(v + gridDim.x) : t_null;
+        }
+    };
+    if constexpr (OVL) {
+        clear_acc();
+        // ONE code path for every tile (two copies of the loop made the allocator permute the accumulator tuples between them): the
+        // first tile runs the boundary body too, "storing" the cleared accumulators through the empty descriptor of t_null
+        Tile done = t_null;
+        for (int t = 0; t < my_tiles; ++t) {
+            body_first(done, wf, af, wf2, af2);
+            body(4, wf2, af2, wf, af);
+            for (int s = 2; s < ns; s += 2) {
+                body(s + 3, wf, af, wf2, af2);
+                body(s + 4, wf2, af2, wf, af);
+            }
+            done = cur;
+            advance();
+        }
+        store_out(done);  // the workgroup's last tile
+    } else {
+        for (int t = 0; t < my_tiles; ++t) {
+            clear_acc();
+            for (int s = 0; s < ns; s += 2) {  // slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
+                body(s + 3, wf, af, wf2, af2);
+                body(s + 4, wf2, af2, wf, af);
+            }
+            store_out(cur);
+            after_epilogue = true;
+            advance();
         }
     }
     wait_vmcnt<0>();  // no LDS-DMA (the null ones of the last bodies included) may outlive the workgroup's LDS allocation
@@ -1341,6 +1428,8 @@ template __global__ void gemm_bf16_w4s<1>(GemmArgs);
 template __global__ void gemm_bf16_w4s<0, true>(GemmArgs);
 template __global__ void gemm_bf16_w4p<0>(GemmArgs);
 template __global__ void gemm_bf16_w4p<1>(GemmArgs);
+template __global__ void gemm_bf16_w4p<0, true>(GemmArgs);
+template __global__ void gemm_bf16_w4p<1, true>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<0>(GemmArgs);
 template __global__ void gemm_bf16_pp_persist<1>(GemmArgs);
 template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0>(GemmArgs);  // 128 x 128, small-M problems
@@ -1430,19 +1519,19 @@ int launch_w4s(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
-template <int EPI>
+template <int EPI, bool OVL = false>
 int launch_w4p(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int SMEM = 4 * 512 * 64;
     static bool attr_done = false;
     if (!attr_done) {
-        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4p<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4p<EPI, OVL>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_done = true;
     }
     const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
     const int cus = num_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(256);
-    if (ev0) hipExtLaunchKernelGGL((gemm_bf16_w4p<EPI>), grid, block, SMEM, stream, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL((gemm_bf16_w4p<EPI>), grid, block, SMEM, stream, a);
+    if (ev0) hipExtLaunchKernelGGL((gemm_bf16_w4p<EPI, OVL>), grid, block, SMEM, stream, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((gemm_bf16_w4p<EPI, OVL>), grid, block, SMEM, stream, a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1492,11 +1581,13 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
     LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue == 0 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 13, "gemm: unknown variant %d", variant);
-    if (variant == 13) {  // EXPERIMENTAL: persistent 4-wave kernel (see gemm_bf16_w4p); not part of the parity suite yet
-        LT_REQUIRE(!a.tile_expert && !a.trace && a.bias_dtype < 0, "gemm variant 13: dense problems without bias, no trace build");
-        LT_REQUIRE(a.K % 64 == 0 && a.K >= 128, "gemm variant 13: K=%d must be a multiple of 64, >= 128 (slabs are consumed in pairs)", a.K);
-        LT_REQUIRE(255LL * a.ldc * 2 + (long long)a.N * 2 < 0x7fffffffLL, "gemm variant 13: C row stride too large for 32-bit tile offsets");
+    LT_REQUIRE(variant >= 0 && variant <= 14, "gemm: unknown variant %d", variant);
+    if (variant == 13 || variant == 14) {  // EXPERIMENTAL: persistent 4-wave kernel (see gemm_bf16_w4p; 14 = epilogue inside the next
+                                           // tile's first body); not part of the parity suite yet
+        LT_REQUIRE(!a.tile_expert && !a.trace && a.bias_dtype < 0, "gemm variant 13 / 14: dense problems without bias, no trace build");
+        LT_REQUIRE(a.K % 64 == 0 && a.K >= 128, "gemm variant 13 / 14: K=%d must be a multiple of 64, >= 128 (slabs are consumed in pairs)", a.K);
+        LT_REQUIRE(255LL * a.ldc * 2 + (long long)a.N * 2 < 0x7fffffffLL, "gemm variant 13 / 14: C row stride too large for 32-bit tile offsets");
+        if (variant == 14) return epilogue == 1 ? launch_w4p<1, true>(a, stream, ev0, ev1) : launch_w4p<0, true>(a, stream, ev0, ev1);
         return epilogue == 1 ? launch_w4p<1>(a, stream, ev0, ev1) : launch_w4p<0>(a, stream, ev0, ev1);
     }
     if (variant == 12) {  // EXPERIMENTAL: 4 waves, VGPR-staged (see gemm_bf16_w4s); not part of the parity suite yet

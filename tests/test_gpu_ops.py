@@ -149,14 +149,16 @@ def test_gemm_experimental_4wave_vgpr_staged(M, N, K, epi):
                            "not yet run on hardware (scripts/gpu_round2_first.sh runs it)")
 @pytest.mark.parametrize("M,N,K,epi", [(8192, 12288, 2304, 1), (8300, 6912, 2304, 0), (2100, 1280, 128, 1), (512, 512, 128, 0),
                                        (300, 576, 192, 0), (16384, 2304, 6144, 0), (70000, 520, 256, 0), (256, 131072, 128, 1)])
-def test_gemm_experimental_4wave_persistent(M, N, K, epi):
+@pytest.mark.parametrize("variant", [13, 14])
+def test_gemm_experimental_4wave_persistent(M, N, K, epi, variant):
     """gemm_bf16_w4p: one workgroup per CU walks its tiles, slab stream and LDS ring carried across tile boundaries; same MFMA
     order as every other kernel -> bit-identical to variant 1.  Shapes: 6 tiles per CU, ragged M, one tile per workgroup and
-    fewer tiles than CUs, K = 128 (every body is a boundary body), more than two tiles per CU with ragged edges both ways."""
+    fewer tiles than CUs, K = 128 (every body is a boundary body), more than two tiles per CU with ragged edges both ways.
+    Variant 14 stores a tile from inside the next tile's first body (in-place C = 0 MFMAs behind explicit accumulator copy-outs)."""
     g = torch.Generator().manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g))
     W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
-    assert torch.equal(_gemm(A, W, None, epi, variant=13), _gemm(A, W, None, epi, variant=1))
+    assert torch.equal(_gemm(A, W, None, epi, variant=variant), _gemm(A, W, None, epi, variant=1))
 
 
 @pytest.mark.parametrize("variant", [0, 1, 3, 7])
