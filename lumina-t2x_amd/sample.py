@@ -50,10 +50,11 @@ def load_checkpoint(ckpt_dir: str, ema: bool) -> dict:
                             "engine keeps the whole 2B model on one GPU)")
 
 
-def make_text_encoder(path: str, dtype, device) -> Tuple[Callable[[List[str]], Tuple[torch.Tensor, torch.Tensor]], int]:
-    """(encode(captions) -> (feats [n, T, C], mask [n, T]), C) with the reference's tokenizer settings (sample.py:34-51)."""
+def make_text_encoder(path: str, dtype, device, add_eos: bool = True) -> Tuple[Callable[[List[str]], Tuple[torch.Tensor, torch.Tensor]], int]:
+    """(encode(captions) -> (feats [n, T, C], mask [n, T]), C) with the reference's tokenizer settings (sample.py:34-51;
+    ``add_eos=False`` is the ``lumina_next`` CLI's tokenizer, utils/cli.py:121)."""
     from transformers import AutoModel, AutoTokenizer
-    tok = AutoTokenizer.from_pretrained(path, add_eos=True)
+    tok = AutoTokenizer.from_pretrained(path, add_eos=True) if add_eos else AutoTokenizer.from_pretrained(path)
     tok.padding_side = "right"
     enc = AutoModel.from_pretrained(path, torch_dtype=dtype).to(device).eval()
 

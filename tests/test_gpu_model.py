@@ -7,6 +7,7 @@ cond-uncond error ~2.8x) on synthetic weights.  Gates: plain forward <= 2.5e-2, 
 measured floor, and the bf16-emulating oracle (same rounding choreography) must be matched 3x tighter.
 """
 import json
+import math
 import os
 
 import numpy as np
@@ -315,6 +316,67 @@ def test_sample_driver_end_to_end_with_injected_encoder(golden_dir, tmp_path):
     want = fn(z, model.forward_with_cfg, cap_feats=feats, cap_mask=mask, cfg_scale=4.0, proportional_attn=True,
               base_seqlen=256, scale_factor=1.0, scale_watershed=1.0)[-1][:1]
     assert torch.equal(decoded[0], want / 0.13025)
+
+
+@pytest.mark.skipif(os.environ.get("LUMINA_EXPERIMENTAL") != "1",
+                    reason="written after the last GPU minute of round 1 (the CPU half of the CLI is covered by tests/test_host_logic.py); "
+                           "scripts/gpu_round2_first.sh runs it, then the gate goes")
+def test_lumina_next_cli_infer_with_injected_encoder(golden_dir, tmp_path):
+    """lumina_t2x_amd.cli.infer (reference utils/cli.py:161-333 flow): yaml settings -> sampler + model kwargs -> one CFG solve
+    on the engine -> decoded file named after the caption.  The latent handed to the (injected) VAE must equal a direct Sampler
+    call with the same seed; note the CLI's height-first latent and its '(Extrapolation)' time-aware scaling."""
+    import argparse
+
+    from safetensors.torch import save_file
+
+    from lumina_t2x_amd import cli
+
+    g, cfg = _golden(golden_dir, "nextdit_tiny")
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ck / "consolidated.00-of-01.safetensors"))
+    torch.save(argparse.Namespace(model="NextDiT_tiny_cli", qk_norm=cfg.qk_norm, image_size=64, vae="sdxl"), str(ck / "model_args.pth"))
+    models.__dict__["NextDiT_tiny_cli"] = lambda **kw: models.NextDiT(**{**cfg.ctor_kwargs(), **kw})
+    settings = tmp_path / "settings.yaml"
+    settings.write_text(f"""
+- settings:
+  model: {{ckpt: "{ck}", ckpt_lm: "unused", token: ""}}
+  transport: {{path_type: "Linear", prediction: "velocity", loss_weight: "velocity", sample_eps: 0.1, train_eps: 0.2}}
+  ode: {{atol: 1.0e-6, rtol: 1.0e-3, reverse: false, likelihood: false}}
+  infer: {{resolution: "(Extrapolation) 64x128", num_sampling_steps: 3, cfg_scale: 3.0, solver: "euler", t_shift: 4,
+          scaling_method: "Time-aware", scale_watershed: 0.3, proportional_attn: true, seed: 5}}
+""")
+    gen = torch.Generator().manual_seed(4)
+    table = {c: torch.randn(16, cfg.cap_feat_dim, generator=gen) for c in ("a tall tower. at dusk", "")}
+
+    def encode(caps):
+        feats = torch.stack([table[c] for c in caps]).to("cuda", torch.bfloat16)
+        mask = torch.ones(len(caps), 16, dtype=torch.int64, device="cuda")
+        mask[-1, 8:] = 0
+        return feats, mask
+
+    decoded = []
+
+    def decode(lat):
+        decoded.append(lat.clone())
+        return torch.sigmoid(lat[:, :3].float())
+
+    try:
+        out = cli.infer("a tall tower. at dusk", str(tmp_path / "out"), ckpt=None, ckpt_lm=None, ema=False, precision="bf16",
+                        config_path=str(settings), token=None, encode_fn=encode, cap_feat_dim=cfg.cap_feat_dim, decode_fn=decode)
+    finally:
+        del models.__dict__["NextDiT_tiny_cli"]
+    assert os.path.exists(out) and os.path.basename(out).startswith("a_tall_tower_") and out.endswith("_lumina.png")
+    model = _model(cfg, int(g["seed_w"]))
+    torch.random.manual_seed(5)
+    z = torch.randn([1, 4, 128 // 8, 64 // 8], device="cuda").to(torch.bfloat16).repeat(2, 1, 1, 1)
+    feats, mask = encode(["a tall tower. at dusk", ""])
+    fn = Sampler(create_transport("Linear", "velocity", "velocity", 0.2, 0.1)).sample_ode(sampling_method="euler", num_steps=3,
+                                                                                         time_shifting_factor=4)
+    want = fn(z, model.forward_with_cfg, cap_feats=feats, cap_mask=mask, cfg_scale=3.0, proportional_attn=True, base_seqlen=16,
+              scale_factor=math.sqrt(64 * 128 / 64 ** 2), scale_watershed=0.3)[-1][:1]
+    assert len(decoded) == 1 and torch.equal(decoded[0], want / 0.13025)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

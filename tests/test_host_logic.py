@@ -1,6 +1,7 @@
 """CPU: host-side mirror of the reference API (models/, transport/) - construction, state_dict contract,
 sampler factory wiring, and the 'no CPU fallback' rule of the product path."""
 import json
+import math
 import os
 
 import numpy as np
@@ -307,3 +308,99 @@ def test_prompt_cache_needs_the_same_unmodified_tensor_objects():
     assert ref() is not None
     cache.clear()
     assert ref() is None
+
+
+# ---- `lumina_next` command line (reference entry_point.py / utils/cli.py) ---------------------------------------------------
+_SETTINGS_YAML = """
+- settings:
+
+  model:
+    ckpt: "/ckpts/dit"
+    ckpt_lm: "/ckpts/lm"
+    token: ""
+
+  transport:
+    path_type: "Linear"
+    prediction: "velocity"
+    loss_weight: "velocity"
+    sample_eps: 0.1
+    train_eps: 0.2
+
+  ode:
+    atol: 1e-6
+    rtol: 1e-3
+    reverse: false
+    likelihood: false
+
+  infer:
+      resolution: "(Extrapolation) 1024x2048"
+      num_sampling_steps: 60
+      cfg_scale: 4.
+      solver: "euler"
+      t_shift: 4
+      scaling_method: "Time-aware"
+      scale_watershed: 0.3
+      proportional_attn: true
+      seed: 25
+"""
+
+
+def _cli():
+    import importlib
+
+    return importlib.import_module("lumina_t2x_amd.cli")
+
+
+def test_cli_plan_matches_reference_inference_conventions(tmp_path):
+    """utils/cli.py:161-263: latent drawn height first, '(Extrapolation)' + 'Time-aware' -> sqrt(w h / size^2) scale factor,
+    proportional attention -> base_seqlen (size / 16)^2; the shipped yaml's `scale_watershed` key is honoured."""
+    cli = _cli()
+    path = tmp_path / "settings.yaml"
+    path.write_text(_SETTINGS_YAML)
+    cfg = cli.load_settings(str(path))
+    plan = cli.plan_inference(cfg, image_size=1024)
+    assert plan["latent_shape"] == [1, 4, 2048 // 8, 1024 // 8] and (plan["width"], plan["height"]) == (1024, 2048)
+    assert plan["sampler"] == dict(sampling_method="euler", num_steps=60, atol=1e-6, rtol=1e-3, reverse=False, time_shifting_factor=4)
+    assert plan["transport"] == dict(path_type="Linear", prediction="velocity", loss_weight="velocity", train_eps=0.2, sample_eps=0.1)
+    mk = plan["model_kwargs"]
+    assert mk["cfg_scale"] == 4.0 and mk["proportional_attn"] is True and mk["base_seqlen"] == 64 ** 2
+    assert mk["scale_factor"] == pytest.approx(math.sqrt(2.0)) and mk["scale_watershed"] == 0.3 and plan["seed"] == 25
+    # native resolution, no proportional attention
+    cfg["infer"].update(resolution="1024x1024", proportional_attn=False)
+    mk = cli.plan_inference(cfg, 1024)["model_kwargs"]
+    assert (mk["scale_factor"], mk["scale_watershed"], mk["base_seqlen"], mk["proportional_attn"]) == (1.0, 1.0, None, False)
+    cfg["ode"]["likelihood"] = True
+    with pytest.raises(NotImplementedError):
+        cli.plan_inference(cfg, 1024)
+    # paths: cli options win, otherwise the yaml's model section
+    assert cli.resolve_paths(None, None, False, cfg) == ("/ckpts/dit", "/ckpts/lm", "")
+    assert cli.resolve_paths("/a", "/b", False, cfg) == ("/a", "/b", False)
+    cfg["model"]["ckpt"] = None
+    with pytest.raises(ValueError):
+        cli.resolve_paths(None, "/b", False, cfg)
+
+
+def test_cli_convert_round_trip_and_default_command(tmp_path, monkeypatch):
+    cli = _cli()
+    state = {"layers.0.attention.wq.weight": torch.randn(8, 4), "pad_token": torch.arange(4.0), "x_embedder.bias": torch.zeros(3).bfloat16()}
+    src = tmp_path / "consolidated.00-of-01.pth"
+    torch.save(state, str(src))
+    st = cli.main(["convert", str(src), str(tmp_path / "o1")])
+    assert st.endswith("consolidated.00-of-01.safetensors") and os.path.exists(st)
+    back = cli.main(["convert", st, str(tmp_path / "o2")])
+    got = torch.load(back, map_location="cpu", weights_only=True)
+    assert set(got) == set(state) and all(torch.equal(got[k], state[k]) and got[k].dtype == state[k].dtype for k in state)
+    with pytest.raises(ValueError):
+        cli.convert(str(tmp_path / "weights.bin"), str(tmp_path / "o3"))
+    # `infer` is the default command: a leading caption is not a command name
+    seen = {}
+    monkeypatch.setattr(cli, "infer", lambda text, output_path, **kw: seen.update(text=text, out=output_path, **kw) or "ok")
+    assert cli.main(["a cat. on a mat", "outdir", "--ckpt", "/c", "--ckpt_lm", "/l", "--ema", "-c", "s.yaml"]) == "ok"
+    assert seen["text"] == "a cat. on a mat" and seen["out"] == "outdir" and seen["ckpt"] == "/c" and seen["ema"] is True
+    assert seen["config_path"] == "s.yaml" and seen["precision"] == "bf16" and seen["num_gpus"] == 1
+    seen.clear()
+    cli.main(["infer", "x"])
+    assert seen["out"] == "./" and seen["config_path"] == "cofing/infer/settings.yaml" and seen["ema"] is False
+    import time as _t
+
+    assert cli.output_name("a cat. on a mat", _t.struct_time((2024, 5, 6, 7, 8, 9, 0, 127, 0))) == "a_cat_2024-05-06-07-08-09_lumina"
