@@ -404,3 +404,30 @@ def test_cli_convert_round_trip_and_default_command(tmp_path, monkeypatch):
     import time as _t
 
     assert cli.output_name("a cat. on a mat", _t.struct_time((2024, 5, 6, 7, 8, 9, 0, 127, 0))) == "a_cat_2024-05-06-07-08-09_lumina"
+
+
+# ---- class-conditional driver (reference Next-DiT-ImageNet/sample.py) ---------------------------------------------------------
+def test_imagenet_driver_command_line_and_grid():
+    import importlib
+
+    S = importlib.import_module("lumina_t2x_amd.sample_imagenet")
+    mode, a = S.parse(["ODE", "--ckpt", "/c", "--sampling-method", "euler", "--num_sampling_steps", "50", "--class_labels", "1", "2", "3"])
+    assert mode == "ODE" and a.sampling_method == "euler" and a.num_sampling_steps == 50 and a.class_labels == [1, 2, 3]
+    assert a.ema is True and a.precision == "tf32" and a.cfg_scale == 4.0 and a.atol == 1e-6 and a.reverse is False and a.likelihood is False
+    mode, a = S.parse(["SDE", "--ckpt", "/c", "--no_ema", "--last-step", "None"])
+    assert mode == "SDE" and a.sampling_method == "Euler" and a.diffusion_form == "sigma" and a.last_step is None and a.ema is False
+    assert a.class_labels == [207, 360, 387, 974, 88, 979, 417, 279] and a.last_step_size == 0.04
+    mode, a = S.parse(["--ckpt", "/c"])  # anything but ODE / SDE in argv[1]: ODE (reference :218-220)
+    assert mode == "ODE" and a.sampling_method == "dopri5"
+    with pytest.raises(AssertionError):
+        S.parse(["ODE", "--ckpt", "/c", "--num_gpus", "2"])
+    mode, a = S.parse(["ODE", "--ckpt", "/c", "--likelihood"])
+    with pytest.raises(NotImplementedError):
+        S.build_sample_fn(a, mode)
+    # grid: torchvision.utils.save_image(nrow=8) layout - 2-pixel black frame around every tile
+    imgs = torch.stack([torch.full((3, 4, 5), (i + 1) / 16.0) for i in range(11)])
+    grid = S.make_grid(imgs, nrow=8)
+    assert grid.shape == (3, 2 * (4 + 2) + 2, 8 * (5 + 2) + 2)
+    assert torch.all(grid[:, 2:6, 2:7] == 1 / 16.0) and torch.all(grid[:, 8:12, 16:21] == 11 / 16.0) and torch.all(grid[:, :2] == 0)
+    assert torch.all(grid[:, 8:12, 23:] == 0)  # the unused cells of the last row stay black
+    assert S.make_grid(imgs[:3], nrow=8).shape == (3, 4 + 4, 3 * 7 + 2)
