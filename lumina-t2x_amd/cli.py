@@ -12,6 +12,10 @@ tokenizer is built without ``add_eos``.  The shipped yaml spells the watershed k
 reads ``scaling_watershed`` (so the reference's own default config raises a KeyError that its blanket ``except`` swallows);
 both spellings are accepted here.
 
+``--family flag`` is the same command for the Flag-DiT sub-project (``lumina_t2i/entry_point.py``, ``utils/cli.py:124-240``: the
+``lumina`` console script): its yaml has ``ntk_scaling`` instead of the time-aware scaling keys, the proportional-attention base
+length counts the end-of-line tokens, and the caption goes through ``tokenizer.encode`` / ``last_hidden_state`` with a bool mask.
+
 The DiT runs on the HIP engine (``models.NextDiT``); text encoder and VAE stay third-party and load from LOCAL paths
 (``--ckpt_lm``, ``--vae``): there is no network here, so the reference's hub names are not resolved.  Without ``diffusers``
 the final latent is written as ``.pt``.
@@ -64,20 +68,27 @@ def load_settings(config_path: str) -> dict:
         return yaml.safe_load(f)[0]
 
 
-def plan_inference(config: dict, image_size: int) -> dict:
-    """Everything ``utils/cli.py:inference`` derives from the yaml before it touches a model."""
+def plan_inference(config: dict, image_size: int, family: str = "next") -> dict:
+    """Everything ``utils/cli.py:inference`` derives from the yaml before it touches a model (``family``: "next" =
+    lumina_next_t2i, "flag" = lumina_t2i)."""
     tr, ode, inf = config["transport"], config["ode"], config["infer"]
     resolution = str(inf["resolution"])
     extrapolate = "Extrapolation" in resolution
     w, h = (int(v) for v in resolution.split(" ")[-1].split("x"))
-    watershed = inf["scaling_watershed"] if "scaling_watershed" in inf else inf.get("scale_watershed", 1.0)
     prop = bool(inf["proportional_attn"])
-    model_kwargs = dict(cfg_scale=float(inf["cfg_scale"]), proportional_attn=prop,
-                        base_seqlen=(image_size // 16) ** 2 if prop else None)
-    if extrapolate and inf["scaling_method"] == "Time-aware":
-        model_kwargs.update(scale_factor=math.sqrt(w * h / image_size ** 2), scale_watershed=float(watershed))
+    model_kwargs = dict(cfg_scale=float(inf["cfg_scale"]))
+    if family == "flag":  # lumina_t2i/utils/cli.py:204-214: keys are only present when switched on
+        if prop:
+            model_kwargs.update(proportional_attn=True, base_seqlen=(image_size // 16) ** 2 + (image_size // 16) * 2)
+        if inf["ntk_scaling"]:
+            model_kwargs["ntk_factor"] = ((w // 16) * (h // 16)) / ((image_size // 16) ** 2)
     else:
-        model_kwargs.update(scale_factor=1.0, scale_watershed=1.0)
+        watershed = inf["scaling_watershed"] if "scaling_watershed" in inf else inf.get("scale_watershed", 1.0)
+        model_kwargs.update(proportional_attn=prop, base_seqlen=(image_size // 16) ** 2 if prop else None)
+        if extrapolate and inf["scaling_method"] == "Time-aware":
+            model_kwargs.update(scale_factor=math.sqrt(w * h / image_size ** 2), scale_watershed=float(watershed))
+        else:
+            model_kwargs.update(scale_factor=1.0, scale_watershed=1.0)
     if ode.get("likelihood", False):
         raise NotImplementedError("ode.likelihood: sample_ode_likelihood differentiates through the model (transport.py:393-450); "
                                   "the engine is forward-only")
@@ -106,10 +117,33 @@ def output_name(cap: str, now: Optional[time.struct_time] = None) -> str:
     return f"{'_'.join(cap.split(' ')).split('.')[0]}_{stamp}_lumina"
 
 
+def make_llama_encoder(path: str, dtype, device):
+    """Flag-DiT's caption path (lumina_t2i/utils/cli.py:86, :186-202): ``tokenizer.encode`` with BOS + EOS, both prompts padded
+    with zeros to the longer one, ``last_hidden_state`` of the LM, bool mask."""
+    from transformers import AutoModel, AutoTokenizer
+    tok = AutoTokenizer.from_pretrained(path, add_bos_token=True, add_eos_token=True)
+    tok.padding_side = "right"
+    lm = AutoModel.from_pretrained(path, torch_dtype=dtype).to(device).eval()
+
+    @torch.no_grad()
+    def encode(captions):
+        ids = [tok.encode(c, truncation=False) for c in captions]
+        t = torch.zeros([len(ids), max(len(i) for i in ids)], dtype=torch.long, device=device)
+        m = torch.zeros_like(t, dtype=torch.bool)
+        for r, i in enumerate(ids):
+            t[r, : len(i)] = torch.tensor(i)
+            m[r, : len(i)] = True
+        return lm(input_ids=t).last_hidden_state, m
+
+    return encode, lm.config.hidden_size
+
+
 def infer(text: str, output_path: str, *, ckpt, ckpt_lm, ema: bool, precision: str, config_path: str, token=False, num_gpus: int = 1,
-          vae: str = "", encode_fn=None, cap_feat_dim=None, decode_fn=None, model=None) -> str:
+          vae: str = "", family: str = "next", encode_fn=None, cap_feat_dim=None, decode_fn=None, model=None) -> str:
     """One caption -> one image (or latent) file; returns its path.  ``encode_fn`` / ``decode_fn`` / ``model`` can be injected."""
     from . import models
+    if family == "flag":
+        from .models import flag_dit as models  # noqa: F811  (each reference sub-project calls its own package `models`)
     from .sample import VAE_SCALE, load_checkpoint, load_train_args, make_text_encoder, make_vae_decoder, save_png
     from .transport import Sampler, create_transport
 
@@ -124,7 +158,8 @@ def infer(text: str, output_path: str, *, ckpt, ckpt_lm, ema: bool, precision: s
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[precision]
     train_args = load_train_args(ckpt)
     if encode_fn is None:
-        encode_fn, cap_feat_dim = make_text_encoder(ckpt_lm, dtype, device, add_eos=False)
+        encode_fn, cap_feat_dim = (make_llama_encoder(ckpt_lm, dtype, device) if family == "flag"
+                                   else make_text_encoder(ckpt_lm, dtype, device, add_eos=False))
     if model is None:
         print(f"> Creating DiT model: {train_args.model}")
         model = models.__dict__[train_args.model](qk_norm=train_args.qk_norm, cap_feat_dim=cap_feat_dim)
@@ -132,7 +167,7 @@ def infer(text: str, output_path: str, *, ckpt, ckpt_lm, ema: bool, precision: s
         model.load_state_dict(load_checkpoint(ckpt, ema), strict=True)
     if decode_fn is None:
         decode_fn = make_vae_decoder(vae, device)
-    plan = plan_inference(config, train_args.image_size)
+    plan = plan_inference(config, train_args.image_size, family)
     sample_fn = Sampler(create_transport(**plan["transport"])).sample_ode(**plan["sampler"])
     if plan["seed"] != 0:
         torch.random.manual_seed(plan["seed"])
@@ -172,6 +207,8 @@ def build_parser() -> argparse.ArgumentParser:
                     help="setting for inference with different parameter.")
     pi.add_argument("--token", default=False, help="huggingface token (unused: weights load from local paths).")
     pi.add_argument("--vae", type=str, default="", help="local path of the diffusers AutoencoderKL weights; empty: save the latent")
+    pi.add_argument("--family", type=str, choices=["next", "flag"], default="next",
+                    help="next: lumina_next_t2i (`lumina_next`), flag: lumina_t2i / Flag-DiT (`lumina`)")
     pc = sub.add_parser("convert", help="convert torch model weight `.pth` into `.safetensors` (or back)")
     pc.add_argument("weight_path", type=str)
     pc.add_argument("output_dir", type=str)
@@ -187,7 +224,7 @@ def main(argv=None):
         return convert(a.weight_path, a.output_dir)
     if a.command == "infer":
         return infer(a.text, a.output_path, ckpt=a.ckpt, ckpt_lm=a.ckpt_lm, ema=a.ema, precision=a.precision, config_path=a.config,
-                     token=a.token, num_gpus=a.num_gpus, vae=a.vae)
+                     token=a.token, num_gpus=a.num_gpus, vae=a.vae, family=a.family)
     build_parser().print_help()
     return None
 

@@ -372,6 +372,14 @@ def test_cli_plan_matches_reference_inference_conventions(tmp_path):
     cfg["ode"]["likelihood"] = True
     with pytest.raises(NotImplementedError):
         cli.plan_inference(cfg, 1024)
+    # Flag-DiT (lumina_t2i/utils/cli.py:204-214): base length counts the end-of-line tokens, NTK factor = token-count ratio,
+    # and the optional keys are only passed when switched on
+    cfg["ode"]["likelihood"] = False
+    cfg["infer"].update(resolution="(Extrapolation) 1024x2048", proportional_attn=True, ntk_scaling=True)
+    mk = cli.plan_inference(cfg, 1024, family="flag")["model_kwargs"]
+    assert mk == dict(cfg_scale=4.0, proportional_attn=True, base_seqlen=64 ** 2 + 128, ntk_factor=2.0)
+    cfg["infer"].update(proportional_attn=False, ntk_scaling=False)
+    assert cli.plan_inference(cfg, 1024, family="flag")["model_kwargs"] == dict(cfg_scale=4.0)
     # paths: cli options win, otherwise the yaml's model section
     assert cli.resolve_paths(None, None, False, cfg) == ("/ckpts/dit", "/ckpts/lm", "")
     assert cli.resolve_paths("/a", "/b", False, cfg) == ("/a", "/b", False)
