@@ -95,6 +95,9 @@ const char* lt_version(void);
  *   "gemm_pipeline"     0 auto (default) | 1 ping-pong wave groups | 2 classic double buffer (small-M tiles: register
  *                       pipeline) | 3 single-barrier rendezvous
  *   "gemm_pp_tail"      0 (default) | 1: tail MFMAs issued after the ping-pong hand-over barrier
+ *   "gemm_persist"      0 (default) | 1: persistent ping-pong kernel for multi-round SwiGLU GEMMs
+ *   "gemm_stagger"      0 (default) .. 64: 4-wave GEMM kernels (explicit variants 10, 13, 14) spread the start of the workgroups
+ *                       of an XCD over eight phases, n * ~1024 cycles apart (experiment knob)
  *   "qkv_post_fused"    0 three launches (default) | 1 one launch for q / k post-processing + V transpose */
 int lt_set_option(const char* name, int32_t value);
 

@@ -276,6 +276,20 @@ __device__ __forceinline__ void pp_barrier() {
 // AGPR: issue the MFMAs as inline assembly with the accumulators constrained to the AGPR file.  (The builtin lets the compiler
 // use the unified-VGPR form whenever the kernel fits 256 registers, which the 8-wave kernels do; the vendor library's kernels
 // keep their accumulators in AGPRs and run ~25 % faster clocks on the same problem - profiles/r01/vendor_vs_engine_pmc.log.)
+// Experiment knob of the 4-wave kernels (variants 10, 13, 14; lt_set_option("gemm_stagger", n)): workgroup b sleeps
+// ((b >> 3) & 7) * n * ~1024 cycles before its first load, which spreads the CUs of an XCD over eight tile phases.  All tiles of
+// a GEMM take the same time, so without it every CU of the chip is in its prologue / epilogue at the same moment; whether that
+// synchronised idle phase is what keeps the clock low is one of the next round's questions.  A __device__ word
+// instead of a GemmArgs field: the kernels of the product path do not read it and keep their argument layout.
+__device__ int g_dev_gemm_stagger = 0;
+__device__ __forceinline__ void stagger_start() {
+    const int n = g_dev_gemm_stagger;
+    if (n > 0) {
+        const int reps = ((blockIdx.x >> 3) & 7) * n;
+        for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+}
+
 template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0, int MODE = 0, int KS = 2, bool AGPR = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(GemmArgs p) {
     static_assert(MODE == 0 || TAILN == 0, "rendezvous mode has no hand-over barrier");
@@ -363,6 +377,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int ns = p.K / (16 * KS);
+    if constexpr (MODE == 2 && G == 1) stagger_start();  // 4-wave kernel only (variant 10)
     // prologue: slabs 0..2 in flight, slab 0 landed and visible
     stage(0);
     if (ns > 1) stage(1);
@@ -1198,6 +1213,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmArgs p) {
         for (int i = 0; i < IP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(i < 4 ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, voff[i], soff, 0, 0);
     };
+    stagger_start();
     // prologue (once per workgroup): slabs 0..2 in flight, slab 0 read into the first fragment set, slab 1 landed and visible
     stage_from(0, 0, cur);
     stage_from(1, 1, cur);
@@ -1571,6 +1587,10 @@ static int g_gemm_persist = 0;   // 1: SwiGLU GEMMs with >= 2 tile rounds per CU
 void lt_set_gemm_persist(int v) { g_gemm_persist = v; }
 static int g_gemm_pp_tail = 0;   // 8-wave ping-pong kernel: 1 = tail MFMAs issued after the hand-over (TAILN = 3; measured no gain), 0 = plain
 void lt_set_gemm_pp_tail(int v) { g_gemm_pp_tail = v; }
+int lt_set_gemm_stagger(int v) {  // device-side word (see stagger_start)
+    LT_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(lt_gemm::g_dev_gemm_stagger), &v, sizeof(int)));
+    return 0;
+}
 
 // variant: 0 = pick the tile shape that minimises (rounds over the CUs) x (tile width); 1 = 256x256; 2 = 256x288;
 //          3 / 4 = the same two shapes with the ping-pong kernel regardless of the process-wide pipeline option;

@@ -117,6 +117,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream);
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
+int lt_set_gemm_stagger(int v);         // 4-wave kernels (variants 10, 13, 14): start-phase spread per XCD, units of ~1024 cycles (0 = off)
 void lt_set_gemm_pp_tail(int v);        // 8-wave ping-pong kernel: 1 = tail MFMAs issued after the hand-over barrier, 0 = plain (default)
 void lt_set_gemm_persist(int v);         // 1 = persistent ping-pong kernel for multi-round SwiGLU GEMMs
 void lt_set_gemm_pipeline(int v);      // 0 = classic double-buffered loop, 1 = ping-pong wave groups

@@ -321,8 +321,13 @@ if __name__ == "__main__":
     ap.add_argument("--attn-variants", type=str, default="1,2")
     ap.add_argument("--cold", type=int, default=0, help="gemm_small: rotate through this many weight copies (HBM-cold weights)")
     ap.add_argument("--gemm-zeros", action="store_true", help="all-zero operands (power / clock probe)")
+    ap.add_argument("--gemm-stagger", type=int, default=0, help="4-wave GEMM kernels (variants 10, 13, 14): start-phase spread per XCD in "
+                    "units of ~1024 cycles (lt_set_option gemm_stagger)")
     a = ap.parse_args()
     print("device:", torch.cuda.get_device_name(0), flush=True)
+    if a.gemm_stagger:
+        set_option("gemm_stagger", a.gemm_stagger)
+        print("gemm_stagger =", a.gemm_stagger, flush=True)
     if "gemm" in a.what:
         bench_gemm(a.rounds, [v if ("t" in v or "p" in v) else int(v) for v in a.gemm_variants.split(",")], zeros=a.gemm_zeros)
         set_option("gemm_pp_tail", 0)
