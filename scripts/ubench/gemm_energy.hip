@@ -21,7 +21,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 //          about that share of their fetches to the fabric); F_TILES: a tile boundary every 144 k-steps (72 slabs): the 256
 //          accumulator registers go out as bf16 (128 KiB per workgroup, to the big region), then the loop drains every
 //          outstanding load and meets at a barrier - the epilogue + cold prologue of a real tile.
-enum { F_READS = 1, F_DMA = 2, F_STAGED = 4, F_BARRIER = 8, F_SHARE_A = 16, F_HBM16 = 32, F_TILES = 64 };
+// F_STAGGER: the workgroups of an XCD start in eight phases, an eighth of a tile (~10 k cycles) apart, so that the chip is never
+//          in its tile boundary all at once.
+enum { F_READS = 1, F_DMA = 2, F_STAGED = 4, F_BARRIER = 8, F_SHARE_A = 16, F_HBM16 = 32, F_TILES = 64, F_STAGGER = 128 };
 // idle gap per k-step (SLEEP > 0), by kind: 0 s_sleep SLEEP (wave descheduled), 1 s_nop spin of the same length (wave issuing),
 // 2 s_waitcnt vmcnt(0) on a fresh load from the big region (wave parked on a counter), 3 waves 1-3 parked at s_barrier while
 // wave 0 sleeps
@@ -147,6 +149,10 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void probe(const unsigned sho
     };
     constexpr bool TILES = (FLAGS & F_TILES) != 0;
     const int ntile = TILES ? iters / 144 : 1, per = TILES ? 144 : iters;
+    if constexpr ((FLAGS & F_STAGGER) != 0) {
+        const int reps = ((blockIdx.x >> 3) & 7) * 10;
+        for (int q = 0; q < reps; ++q) __builtin_amdgcn_s_sleep(16);
+    }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     int it = 0;
     for (int t = 0; t < ntile; ++t) {
@@ -233,6 +239,7 @@ int main(int argc, char** argv) {
         CASE("full loop + HBM + tile boundaries", 4, 1, F_READS | F_DMA | F_BARRIER | F_HBM16 | F_TILES, 0),
         CASE("full loop + HBM + tile boundaries", 2, 2, F_READS | F_DMA | F_BARRIER | F_HBM16 | F_TILES, 0),
         CASE("full loop + HBM + tiles, s_sleep 2", 4, 1, F_READS | F_DMA | F_BARRIER | F_HBM16 | F_TILES, 2),
+        CASE("full loop + HBM + tiles, staggered", 4, 1, F_READS | F_DMA | F_BARRIER | F_HBM16 | F_TILES | F_STAGGER, 0),
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
