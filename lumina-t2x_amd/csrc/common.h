@@ -20,6 +20,14 @@ __device__ __forceinline__ float bfr(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
+// The same value from ONE v_cvt_pk_bf16_f32 (the scalar form above compiles to two single-operand converts, a shift and an SDWA
+// or: four instructions per pair).  Used by the GEMM epilogues, where the main loops were checked to stay opcode-identical; the
+// attention kernels keep pack2bf until the change can be measured (it re-schedules three of attn v3's seven MFMA blocks).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ unsigned pack2bf_pk(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
@@ -69,8 +77,6 @@ __device__ __forceinline__ bf8_t pack8(const float* f) {
 
 // ---- pairwise (packed) helpers: the row kernels are VALU-heavy (a bf16 rounding after every reference op), so they
 // work on two elements per instruction: v_pk_mul/add/fma_f32 and one v_cvt_pk_bf16_f32 per rounded pair ------------------
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ unsigned pk_bf(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
 __device__ __forceinline__ f32x2 unpk_bf(unsigned u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
 __device__ __forceinline__ f32x2 bfr2(f32x2 v) { return unpk_bf(pk_bf(v)); }  // round both to bf16, keep as fp32

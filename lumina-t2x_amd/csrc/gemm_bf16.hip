@@ -80,8 +80,8 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[MT][NT], const GemmArgs
                             v[j] += load_bias(p.bias, p.bias_dtype, n);
                         }
                     }
-                    unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
-                    unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
+                    unsigned ax = pack2bf_pk(v[0], v[1]), ay = pack2bf_pk(v[2], v[3]);
+                    unsigned bx = pack2bf_pk(v[4], v[5]), by = pack2bf_pk(v[6], v[7]);
                     auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                     auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
                     const int col = nbase + 16 * qp + 8 * hi;
@@ -105,8 +105,8 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[MT][NT], const GemmArgs
                         const float b = bfr(acc[mt][2 * np + 1][8 * qp + j]);
                         v[j] = bfr(silu_f(a)) * b;
                     }
-                    unsigned ax = pack2bf(v[0], v[1]), ay = pack2bf(v[2], v[3]);
-                    unsigned bx = pack2bf(v[4], v[5]), by = pack2bf(v[6], v[7]);
+                    unsigned ax = pack2bf_pk(v[0], v[1]), ay = pack2bf_pk(v[2], v[3]);
+                    unsigned bx = pack2bf_pk(v[4], v[5]), by = pack2bf_pk(v[6], v[7]);
                     auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                     auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
                     const int col = obase + 16 * qp + 8 * hi;
@@ -1307,8 +1307,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmArgs p) {
                     vv[j] = bfr(silu_f(a)) * b;
                 }
             }
-            unsigned ax = pack2bf(vv[0], vv[1]), ay = pack2bf(vv[2], vv[3]);
-            unsigned bx = pack2bf(vv[4], vv[5]), by = pack2bf(vv[6], vv[7]);
+            unsigned ax = pack2bf_pk(vv[0], vv[1]), ay = pack2bf_pk(vv[2], vv[3]);
+            unsigned bx = pack2bf_pk(vv[4], vv[5]), by = pack2bf_pk(vv[6], vv[7]);
             auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
             auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
             const int col = cbase + 16 * qp + 8 * hi;
