@@ -98,7 +98,9 @@ const char* lt_version(void);
  *   "gemm_persist"      0 (default) | 1: persistent ping-pong kernel for multi-round SwiGLU GEMMs
  *   "gemm_stagger"      0 (default) .. 64: 4-wave GEMM kernels (explicit variants 10, 13, 14) spread the start of the workgroups
  *                       of an XCD over eight phases, n * ~1024 cycles apart (experiment knob)
- *   "qkv_post_fused"    0 three launches (default) | 1 one launch for q / k post-processing + V transpose */
+ *   "qkv_post_fused"    0 three launches (default) | 1 one launch for q / k post-processing + V transpose
+ *   "norm_specialize"   0 (default) | 1: gated_residual_norm runs instantiations with its three mode switches fixed at compile
+ *                       time (the engine's combinations at d = 1536 / 2304 / 3072; bit-identical by construction, unmeasured) */
 int lt_set_option(const char* name, int32_t value);
 
 /* ---- engine lifetime ------------------------------------------------------------------------- */

@@ -1058,6 +1058,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     if (strcmp(name, "qkv_post_fused") == 0) { g_qkv_post_fused = value != 0; return 0; }
     if (strcmp(name, "gemm_persist") == 0) { lt_set_gemm_persist(value != 0); return 0; }
     if (strcmp(name, "gemm_pp_tail") == 0) { lt_set_gemm_pp_tail(value != 0); return 0; }
+    if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_stagger") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_stagger must be 0..64"); return lt_set_gemm_stagger(value); }
     if (strcmp(name, "gemm_pipeline") == 0) { LT_REQUIRE(value >= 0 && value <= 3, "gemm_pipeline must be 0..3"); lt_set_gemm_pipeline(value); return 0; }
     if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }

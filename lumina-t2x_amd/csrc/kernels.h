@@ -51,6 +51,7 @@ struct GatedResArgs {
     int scale_pre = 0;  // 1: next_scale already holds bf16(1 + scale)
 };
 int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream);
+void lt_set_norm_specialize(int v);  // 1: mode-specialised gated_residual_norm instantiations (experiment, default 0)
 
 // ---- q/k/v post-processing (qkv_post.hip) ------------------------------------------------------
 struct QkPostArgs {

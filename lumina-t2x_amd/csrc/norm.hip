@@ -88,8 +88,12 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(NormModArgs p) {
                         p.shift ? p.shift + (size_t)b * p.ld_mod : nullptr, p.scale_pre, p.out + (size_t)row * p.d, nch, lane);
 }
 
-template <int MAXCH>
+// PM / GM / NM >= 0: post_mode / gate_mode / next_mode fixed at compile time (the engine's combinations; selected by
+// lt_set_option("norm_specialize", 1), OFF by default until measured) - same statements in the same order, the mode tests inside
+// the per-chunk loops fold away.  -1: the mode is read from the arguments (the kernel as it has always been).
+template <int MAXCH, int PM = -1, int GM = -1, int NM = -1>
 __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p) {
+    const int post_mode = PM >= 0 ? PM : p.post_mode, gate_mode = GM >= 0 ? GM : p.gate_mode, next_mode = NM >= 0 ? NM : p.next_mode;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
     load_row(p.y + (size_t)row * p.d, nch, lane, r);
     load_row(xrow, nch, lane, xr);  // issued with y: one memory round trip for both streams
     float rinv = 1.f;
-    if (p.post_mode == 1) rinv = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
+    if (post_mode == 1) rinv = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
     const u16* gate = p.gate ? p.gate + (size_t)b * p.ld_mod : nullptr;
     const f32x2 rv = {rinv, rinv};
     // x' = bfr(x + bfr(g * yn));  r <- x'
@@ -109,16 +113,16 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
         const int ch = lane + 64 * i;
         if (ch < nch) {
             bf8_t wv, gv;
-            if (p.post_mode == 1) wv = *(const bf8_t*)(p.post_w + ch * 8);
-            if (p.gate_mode != 2) gv = *(const bf8_t*)(gate + ch * 8);
+            if (post_mode == 1) wv = *(const bf8_t*)(p.post_w + ch * 8);
+            if (gate_mode != 2) gv = *(const bf8_t*)(gate + ch * 8);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 f32x2 yn = unpk_bf(r.c[i].w[k]);
-                if (p.post_mode == 1) yn = bfr2(bfr2(yn * rv) * unpk_bf(wv.w[k]));
-                if (p.gate_mode == 1) {
+                if (post_mode == 1) yn = bfr2(bfr2(yn * rv) * unpk_bf(wv.w[k]));
+                if (gate_mode == 1) {
                     const f32x2 g = unpk_bf(gv.w[k]);
                     yn = bfr2(bfr2(f32x2{tanhf(g[0]), tanhf(g[1])}) * yn);
-                } else if (p.gate_mode == 0) {
+                } else if (gate_mode == 0) {
                     yn = bfr2(unpk_bf(gv.w[k]) * yn);
                 }
                 r.c[i].w[k] = pk_bf(unpk_bf(xr.c[i].w[k]) + yn);
@@ -126,11 +130,11 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
             *(bf8_t*)(xrow + ch * 8) = r.c[i];
         }
     }
-    if (p.next_mode == 0) return;
+    if (next_mode == 0) return;
     const u16* nscale = p.next_scale ? p.next_scale + (size_t)b * p.ld_mod : nullptr;
     const u16* nshift = p.next_shift ? p.next_shift + (size_t)b * p.ld_mod : nullptr;
     u16* hrow = p.h + (size_t)row * p.d;
-    if (p.next_mode == 1) {
+    if (next_mode == 1) {
         const float r2 = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
         apply_rms_mod_store(r, r2, p.next_w, nscale, nshift, p.scale_pre, hrow, nch, lane);
     } else {
@@ -191,6 +195,8 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
         default: hipLaunchKernelGGL(kernel<8>, grid, dim3(256), 0, stream, args); break;                  \
     }
 
+static int g_norm_specialize = 0;  // 1: gated_residual_norm runs its mode-specialised instantiations (see the kernel)
+
 int launch_rmsnorm_mod(const NormModArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH_LIMIT, "rmsnorm_mod: d=%d must be a multiple of 8 and <= 4096", a.d);
     LT_REQUIRE(a.rows_per_batch > 0 && a.rows > 0, "rmsnorm_mod: empty input");
@@ -205,7 +211,27 @@ int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.gate_mode == 2 || a.gate != nullptr, "gated_residual_norm: gate pointer missing");
     LT_REQUIRE(a.post_mode == 0 || a.post_w != nullptr, "gated_residual_norm: post-norm weight missing");
     LT_REQUIRE(a.next_mode == 0 || a.h != nullptr, "gated_residual_norm: h output missing");
-    LT_DISPATCH_CHUNKS(gated_residual_norm_kernel, dim3((a.rows + 3) / 4), a);
+    const dim3 grid((a.rows + 3) / 4);
+    if (g_norm_specialize && a.gate_mode == 0 && (a.post_mode == 0 || a.post_mode == 1) && (a.next_mode == 1 || a.next_mode == 2)) {
+        const int nch64 = ((a.d >> 3) + 63) / 64;
+#define LT_GRN_SPEC(MC, PMV, NMV) \
+    hipLaunchKernelGGL((gated_residual_norm_kernel<MC, PMV, 0, NMV>), grid, dim3(256), 0, stream, a)
+#define LT_GRN_MODES(MC)                                                                      \
+    do {                                                                                      \
+        if (a.post_mode == 1 && a.next_mode == 1) LT_GRN_SPEC(MC, 1, 1);                      \
+        else if (a.post_mode == 1) LT_GRN_SPEC(MC, 1, 2);                                     \
+        else if (a.next_mode == 1) LT_GRN_SPEC(MC, 0, 1);                                     \
+        else LT_GRN_SPEC(MC, 0, 2);                                                           \
+    } while (0)
+        if (nch64 == 3) { LT_GRN_MODES(3); LT_CHECK_HIP(hipGetLastError()); return 0; }  // d = 1536 (cfg 1, 5)
+        if (nch64 == 5) { LT_GRN_MODES(5); LT_CHECK_HIP(hipGetLastError()); return 0; }  // d = 2304 (cfg 2, 4)
+        if (nch64 == 6) { LT_GRN_MODES(6); LT_CHECK_HIP(hipGetLastError()); return 0; }  // d = 3072 (cfg 3)
+#undef LT_GRN_MODES
+#undef LT_GRN_SPEC
+    }
+    LT_DISPATCH_CHUNKS(gated_residual_norm_kernel, grid, a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+void lt_set_norm_specialize(int v) { g_norm_specialize = v; }

@@ -259,6 +259,37 @@ def test_gated_residual_norm(next_mode):
         assert rel_l2(h, ref) < 3e-3, rel_l2(h, ref)
 
 
+@pytest.mark.skipif(os.environ.get("LUMINA_EXPERIMENTAL") != "1",
+                    reason="mode-specialised gated_residual_norm (lt_set_option norm_specialize, default off): written after the last "
+                           "GPU minute of round 1, same statements as the generic kernel; scripts/gpu_round2_first.sh runs it")
+@pytest.mark.parametrize("d", [1536, 2304, 3072, 576])
+@pytest.mark.parametrize("post_mode,next_mode", [(1, 1), (1, 2), (0, 1), (0, 2)])
+def test_gated_residual_norm_specialised_is_bit_identical(d, post_mode, next_mode):
+    """the engine's mode combinations on the compile-time-specialised instantiations (d = 576 has none: falls through to the
+    generic kernel) against the generic kernel on the same inputs"""
+    B, N = 2, 70
+    g = torch.Generator().manual_seed(d + 10 * post_mode + next_mode)
+    x = bf(torch.randn(B * N, d, generator=g))
+    y = bf(torch.randn(B * N, d, generator=g) * 2)
+    pw, nw = bf(1 + 0.1 * torch.randn(d, generator=g)), bf(1 + 0.1 * torch.randn(d, generator=g))
+    ld = 4 * d
+    mod = bf(torch.randn(B, ld, generator=g) * 0.3)
+    outs = []
+    for spec in (0, 1):
+        xs, hs = x.clone(), torch.full_like(x, float("nan"))
+        set_option("norm_specialize", spec)
+        try:
+            ok(lib().lt_op_gated_residual_norm(P(xs), P(y), P(pw) if post_mode else None, P(mod[:, d:]), post_mode, 0,
+                                               P(nw) if next_mode == 1 else None, P(mod[:, 2 * d:]), P(mod[:, 3 * d:]), next_mode, ld, P(hs),
+                                               B, N, d, 1e-5, 1e-6, 1, stream()))
+        finally:
+            set_option("norm_specialize", 0)
+        torch.cuda.synchronize()
+        outs.append((xs, hs))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[1][1].float()).all()
+
+
 @pytest.mark.parametrize("heads,hd,qk_norm", [(8, 72, True), (2, 72, True), (32, 72, False), (32, 48, True)])
 def test_qk_norm_rope(heads, hd, qk_norm):
     from oracle import nextdit_oracle as O
