@@ -2,47 +2,81 @@
 """Headline benchmark: denoising-step throughput of Next-DiT 2B (Lumina-Next, BASELINE.json configs[1]) at
 1024x1024 with classifier-free guidance, flow-matching Euler ODE, bf16, synthetic data / random-init weights.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 the script launches its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W               (the driver's form; RANK / WORLD_SIZE come from the launcher)
 
 A "step" is one denoising step = one ``forward_with_cfg`` (NFE) on a cond+uncond pair plus the Euler update,
 driven exactly as a user would: ``Sampler(transport).sample_ode(...)(z, model.forward_with_cfg, **kwargs)``.
 Each rank denoises ONE image (weak scaling: images shard over GPUs, no data-path collective; the text
 features are broadcast once from rank 0 over RCCL before the timed region).  Inputs are resident in HBM when
 the timed region starts.  Rank 0 prints one JSON line; ``value`` is whole-job latent-tokens/s
-(images x 4096 latent tokens x NFE / wall), ``denoising_steps_per_s`` the same in NFE/s.
+(images x latent tokens x NFE / wall), ``denoising_steps_per_s`` the same in NFE/s.
 
-``roofline`` is measured live with HIP events around every launch of the dominant kernel (the bf16 MFMA GEMM,
-76 % of the algorithmic FLOPs) on the launch stream; ``cpu_baseline`` times the CPU oracle (fp32, all host
-cores) on a bounded sample: a full-width forward_with_cfg with 2 of the 24 layers, scaled to 24.
+``--workload cfg4`` runs BASELINE configs[3] instead (Lumina-Next-SFT 2B GQA at 2048x2048 = 16384 latent tokens per image,
+time-aware RoPE scaling, one image per GPU: its BASELINE form "batch = 8 sharded over 8 GPUs" is ``--gpus 8``).
+
+``roofline`` is measured live with HIP events around every launch of the dominant kernel class (the bf16 MFMA GEMMs,
+76 % of the algorithmic FLOPs) on the launch stream; ``cpu_baseline`` times the CPU oracle (fp32, host
+cores) on a bounded sample: a full-width forward_with_cfg with 2 of the 24 layers, scaled to 24; the one TRUE reference
+timing (unmodified reference module, authoring container) is quoted beside it from profiles/.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import lumina_t2x_amd  # noqa: E402,F401
-from lumina_t2x_amd import models, parallel  # noqa: E402
-from lumina_t2x_amd.transport import Sampler, create_transport  # noqa: E402
-
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
-RES = 1024
-LATENT = RES // 8            # 128
-N_TOKENS = (LATENT // 2) ** 2  # 4096
 TEXT_LEN = 128
+
+WORKLOADS = {
+    # name: (constructor, gqa, resolution, extra model kwargs, description)
+    "cfg2": dict(ctor="NextDiT_2B_patch2", gqa=False, res=1024, scale_factor=1.0, scale_watershed=1.0,
+                 desc="BASELINE configs[1]: Lumina-Next-T2I 2B (NextDiT_2B_patch2, d2304 L24 H32 hd72 F6144), 1024x1024 (4096 latent tokens)"),
+    "cfg2-gqa": dict(ctor="NextDiT_2B_GQA_patch2", gqa=True, res=1024, scale_factor=1.0, scale_watershed=1.0,
+                     desc="Lumina-Next 2B GQA (NextDiT_2B_GQA_patch2, 32 / 8 heads) at the configs[1] workload, 1024x1024 (4096 latent tokens)"),
+    "cfg4": dict(ctor="NextDiT_2B_GQA_patch2", gqa=True, res=2048, scale_factor=2.0, scale_watershed=0.3,
+                 desc="BASELINE configs[3]: Lumina-Next-SFT 2B (NextDiT_2B_GQA_patch2), 2048x2048 any-resolution (16384 latent tokens, "
+                      "NTK-aware / time-aware RoPE scale_factor 2, watershed 0.3)"),
+}
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(argv, n_gpus, port=None):
+    """the torch.distributed.run command line `python bench.py --gpus N ...` re-executes itself under (one rank per GPU)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(args, argv) -> None:
+    """`python bench.py --gpus N` (N > 1) without a launcher environment: start N ranks and relay rank 0's JSON line."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    rc = subprocess.run(launcher_command(argv, args.gpus), env=env).returncode
+    sys.exit(rc)
 
 
 def random_init_(model, seed):
     """Random-init weights of the named architecture directly on the GPU.  The reference zero-inits the adaLN /
     final / cap-embedder / gate paths (model.py:567,643,652,709,201), which would turn every block into an
     identity; give them the SURVEY.md 8d synthetic statistics instead so the timed work is representative."""
+    import torch
     g = torch.Generator(device="cuda").manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -68,8 +102,19 @@ def pmc_traffic():
     return float(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], REPO)
 
 
-def cpu_baseline(n_sample_layers=2):
-    """Oracle (CPU restatement of the reference forward, fp32, all host cores) on a bounded sample."""
+def reference_cpu_timing():
+    """the one TRUE reference number: 1 NFE of the unmodified NextDiT_2B_patch2 (fp32, CPU) in the authoring container, recorded
+    by oracle/make_fulldepth_golden.py (the GPU box has no /root/reference)"""
+    path = os.path.join(REPO, "profiles", "r02", "reference_cpu_timing.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def cpu_baseline(latent, n_tokens, n_sample_layers=2):
+    """Oracle (CPU restatement of the reference forward, fp32, host cores) on a bounded sample."""
+    import torch
     from oracle import nextdit_oracle as O
     from oracle import synth
 
@@ -91,8 +136,8 @@ def cpu_baseline(n_sample_layers=2):
     torch.set_num_threads(cores)
     cfg = synth.NextDiTConfig(n_layers=n_sample_layers)
     sd = synth.synth_state_dict(cfg, seed=0)
-    z, t, cap, mask = synth.synth_inputs(cfg, latent_hw=(LATENT, LATENT), text_len=TEXT_LEN, uncond_len=8, seed=1)
-    kw = dict(cfg_scale=4.0, proportional_attn=True, base_seqlen=N_TOKENS)
+    z, t, cap, mask = synth.synth_inputs(cfg, latent_hw=(latent, latent), text_len=TEXT_LEN, uncond_len=8, seed=1)
+    kw = dict(cfg_scale=4.0, proportional_attn=True, base_seqlen=n_tokens)
     t0 = time.time()
     O.forward_with_cfg(sd, cfg, z, t, cap, mask, n_layers=0, **kw)
     t_fixed = time.time() - t0
@@ -101,12 +146,28 @@ def cpu_baseline(n_sample_layers=2):
     t_sample = time.time() - t0
     per_layer = max(t_sample - t_fixed, 1e-9) / n_sample_layers
     t_nfe = t_fixed + 24 * per_layer
-    return {
-        "value": N_TOKENS / t_nfe, "unit": "latent-tokens/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle fp32 forward_with_cfg at full width (d=2304, N=4096, T=128, B=2) with {n_sample_layers} of 24 "
+    out = {
+        "value": n_tokens / t_nfe, "unit": "latent-tokens/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle fp32 forward_with_cfg at full width (d=2304, N={n_tokens}, T=128, B=2) with {n_sample_layers} of 24 "
                    f"layers: {t_sample:.1f} s; embed/final part {t_fixed:.2f} s; extrapolated to 24 layers = {t_nfe:.1f} s per NFE"),
         "denoising_steps_per_s": 1.0 / t_nfe,
     }
+    ref = reference_cpu_timing()
+    if ref:
+        out["reference_module_authoring_container"] = ref
+    return out
+
+
+def gemm_kernel_label(lib, M, d, F, dkv):
+    """names of the kernels the engine's dispatcher runs for this workload's GEMM shapes (lt_op_gemm_describe)"""
+    import ctypes as C
+    shapes = [("QK", M, d + dkv, d, 0), ("V", M, dkv, d, 2), ("O", M, d, d, 0), ("W1|W3+SwiGLU", M, 2 * F, d, 1), ("W2", M, d, F, 0)]
+    parts = []
+    for nm, m, n, k, epi in shapes:
+        buf = C.create_string_buffer(160)
+        lib.lt_op_gemm_describe(m, n, k, epi, 0, buf, 160)
+        parts.append(f"{nm}: {buf.value.decode()}")
+    return "; ".join(parts)
 
 
 def main():
@@ -114,22 +175,37 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=29, help="timed denoising steps (NFE); 29 = one 30-point Euler grid")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine A/B knob name=value (lt_set_option), repeatable")
     ap.add_argument("--event-steps", type=float, default=0.5,
                     help="NFEs of the timed region whose GEMM launches carry HIP start/stop events (0 = all).  A timed launch "
                          "costs ~0.1 ms of queue idle time on this stack (the host waits on the dispatch signal), so the default "
-                         "samples the first half NFE = 49 launches = embedder + every GEMM shape x 12 layers (every layer and "
-                         "every NFE has the same four shapes): 5 ms in the timed region instead of 10")
+                         "samples the first half NFE = embedder + every GEMM shape x 12 layers (every layer and every NFE has the "
+                         "same shapes)")
     ap.add_argument("--profile-classes", type=int, default=1,
                     help="bit mask of kernel classes bracketed by HIP events IN THE TIMED REGION: 1 GEMM (the roofline kernel, "
                          "default), 2 attention, 4 other.  Every bracketed launch costs two event packets (all classes: +4 %% "
                          "wall), so the attention / other breakdown is taken in a short untimed pass after the timed region")
-    ap.add_argument("--gqa", action="store_true", help="NextDiT_2B_GQA_patch2 instead of the MHA model")
+    ap.add_argument("--gqa", action="store_true", help="shorthand for --workload cfg2-gqa")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B knob: 1 baseline, 2 VALU-diet, 3 ping-pong (default)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B knob: 0 auto (default), 1 256x256, 2 256x288")
     args = ap.parse_args()
-    from lumina_t2x_amd import _lib
+    maybe_self_launch(args, sys.argv[1:])
+
+    import torch
+
+    import lumina_t2x_amd  # noqa: F401
+    from lumina_t2x_amd import _lib, models, parallel
+    from lumina_t2x_amd.flops import flops_per_nfe
+    from lumina_t2x_amd.transport import Sampler, create_transport
+
+    if args.gqa and args.workload == "cfg2":
+        args.workload = "cfg2-gqa"
+    wl = WORKLOADS[args.workload]
+    res = wl["res"]
+    latent = res // 8
+    n_tokens = (latent // 2) ** 2
     if args.attn_variant is not None:
         _lib.check(_lib.load().lt_set_option(b"attention_variant", args.attn_variant))
     for opt in args.opt:
@@ -144,8 +220,7 @@ def main():
     torch.manual_seed(0)
 
     with torch.device(dev):
-        ctor = models.NextDiT_2B_GQA_patch2 if args.gqa else models.NextDiT_2B_patch2
-        model = ctor(qk_norm=True, cap_feat_dim=2048).to(torch.bfloat16)
+        model = getattr(models, wl["ctor"])(qk_norm=True, cap_feat_dim=2048).to(torch.bfloat16)
     random_init_(model, seed=0)
     model.eval()
 
@@ -162,9 +237,10 @@ def main():
     cap_feats, cap_mask = feats[mine].contiguous(), mask[mine].contiguous()
 
     g = torch.Generator(device="cuda").manual_seed(100 + mine)
-    z = torch.randn(1, 4, LATENT, LATENT, device=dev, generator=g).to(torch.bfloat16).repeat(2, 1, 1, 1)
-    kw = dict(cap_feats=cap_feats, cap_mask=cap_mask, cfg_scale=4.0, proportional_attn=True, base_seqlen=(RES // 16) ** 2,
-              scale_factor=1.0, scale_watershed=1.0)
+    z = torch.randn(1, 4, latent, latent, device=dev, generator=g).to(torch.bfloat16).repeat(2, 1, 1, 1)
+    # sample.py:214-232: base_seqlen = (image_size // 16) ** 2 with the model's training image_size 1024
+    kw = dict(cap_feats=cap_feats, cap_mask=cap_mask, cfg_scale=4.0, proportional_attn=True, base_seqlen=(1024 // 16) ** 2,
+              scale_factor=wl["scale_factor"], scale_watershed=wl["scale_watershed"])
     transport = create_transport("Linear", "velocity", None, None, None)
 
     def run(nfe):
@@ -178,7 +254,7 @@ def main():
     eng.profile_enable(args.profile_classes)
     # HIP start/stop events on the GEMM dispatches of the first --event-steps NFE of the timed region (every NFE has the
     # same launch mix; timing all of them costs ~2.5 ms per NFE of queue idle time, which would be charged to `value`)
-    gemm_launches_per_nfe = 4 * model.n_layers + 2
+    gemm_launches_per_nfe = 5 * model.n_layers + 2
     event_launches = -1 if args.event_steps <= 0 else max(1, int(round(args.event_steps * gemm_launches_per_nfe)))
     eng.profile_set_budget(0, event_launches)
     eng.profile_reset()
@@ -206,31 +282,30 @@ def main():
     assert torch.isfinite(traj[-1].float()).all(), "non-finite latent"
 
     if rank == 0:
-        from oracle.nextdit_oracle import flops_per_nfe
-        from oracle.synth import NEXT_2B, NextDiTConfig
-
-        cfgm = NextDiTConfig(n_kv_heads=8) if args.gqa else NEXT_2B
-        nfe_flops = flops_per_nfe(cfgm, N_TOKENS, TEXT_LEN, 2)
+        hd = model.dim // model.n_heads
+        nfe_flops = flops_per_nfe(dim=model.dim, n_layers=model.n_layers, n_heads=model.n_heads, n_kv_heads=model.n_kv_heads,
+                                  ffn=model.ffn_hidden, cap_feat_dim=model.cap_feat_dim, n_tokens=n_tokens, text_len=TEXT_LEN, batch=2)
         gemm_ms, gemm_n, gemm_fl = gemm_prof
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic()
         out = {
-            "metric": "denoising-steps/s & latent-tokens/s, Next-DiT 2B 1024^2 CFG",
-            "value": world * N_TOKENS * args.steps / dt,
+            "metric": "denoising-steps/s & latent-tokens/s, Next-DiT 2B %d^2 CFG" % res,
+            "value": world * n_tokens * args.steps / dt,
             "unit": "latent-tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: Lumina-Next-T2I 2B (NextDiT_2B_%spatch2, d2304 L24 H32 hd72 F6144), "
-                                    "1024x1024 (4096 latent tokens), text T=128, CFG=4 (cond+uncond B=2), proportional attention, "
-                                    "flow-matching Euler ODE t_shift 4, 1 image per GPU" % ("GQA_" if args.gqa else "")),
+            "config": {"workload": (wl["desc"] + ", text T=128, CFG=4 (cond+uncond B=2), proportional attention, "
+                                    "flow-matching Euler ODE t_shift 4, 1 image per GPU"),
                        "images_per_gpu": 1, "nfe_timed": args.steps, "parallelism": f"images sharded x{world}, weights replicated"},
             "denoising_steps_per_s": world * args.steps / dt,
             "model_tflops_per_s_per_gpu": nfe_flops * args.steps / dt / 1e12,
             "mfma_roofline_frac_whole_step": nfe_flops * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "roofline": {
-                "bound": "mfma", "kernel": "gemm_bf16_tn_256 (all GEMM launches of the timed region)",
+                "bound": "mfma",
+                "kernel": "all bf16 GEMM launches of the timed region - " + gemm_kernel_label(
+                    _lib.load(), 2 * n_tokens, model.dim, model.ffn_hidden, model.n_kv_heads * hd),
                 "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
                 "traffic_source": traffic_src,
@@ -241,9 +316,11 @@ def main():
             "kernel_time_ms_per_step": dict(breakdown, note=f"untimed pass of {nb} NFE with events around every launch"),
             "attention_tflops_per_s": attn_fl_b / (attn_ms_b * 1e-3) / 1e12 if attn_ms_b > 0 else 0.0,
             "kernel_variants": {"attention": args.attn_variant or 3, "gemm": args.gemm_variant or 0},
+            "ode_stepping_parity": "unpinned (torchdiffeq is neither vendored, pinned nor installed; fixed-grid solvers restated "
+                                   "from its published algorithm, DESIGN.md 6)",
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
+            out["cpu_baseline"] = cpu_baseline(latent, n_tokens)
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

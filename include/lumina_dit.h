@@ -38,6 +38,9 @@ extern "C" {
 #define LT_VARIANT_NEXT_IMAGENET 1 /* Next-DiT-ImageNet/models/models.py:836 DiT_Llama         */
 #define LT_VARIANT_FLAG_T2I 2      /* lumina_t2i/models/model.py:661 DiT_Llama (Flag-DiT)      */
 #define LT_VARIANT_NEXT_MOE 3      /* Next-DiT-MoE/models/models2.py:850 DiT_Llama (time+space MoE) */
+#define LT_VARIANT_NEXT_MOE_TIME 4  /* Next-DiT-MoE/models/models.py:802 DiT_Llama: ONE MoE FFN per block, routed by the timestep
+                                       embedding (every token of a sample visits the same two experts; models.py:459-477)  */
+#define LT_VARIANT_NEXT_MOE_SPACE 5 /* Next-DiT-MoE/models/models1.py:802 DiT_Llama: ONE MoE FFN per block, routed per token   */
 
 /* fixed-grid ODE methods, torchdiffeq names (lumina_next_t2i/transport/integrators.py:115) */
 #define LT_ODE_EULER 0
@@ -65,7 +68,7 @@ typedef struct lt_config {
     int32_t max_tokens;    /* max latent tokens per sample (N)                                    */
     int32_t max_text;      /* max text tokens per sample (T)                                      */
     int32_t rope_table_len;/* 384 (model.py:734); positions per axis in the 2-D RoPE table        */
-    int32_t num_experts;   /* LT_VARIANT_NEXT_MOE: experts per MoE layer (4, models2.py:696); top-2 routing */
+    int32_t num_experts;   /* LT_VARIANT_NEXT_MOE*: experts per MoE layer (4 models2.py:696, 8 models.py / models1.py:666); top-2 */
 } lt_config;
 
 /* kwargs of NextDiT.forward_with_cfg (model.py:866-877) that are not tensors */
@@ -86,21 +89,23 @@ typedef struct lt_step_args {
 } lt_step_args;
 
 const char* lt_last_error(void);
-/* library / build identification: returns e.g. "lumina_dit gfx950 r1" */
+/* library / build identification: "lumina_dit gfx950 r2", with "+experimental" appended by EXPERIMENTAL=1 builds */
 const char* lt_version(void);
 
 /* process-wide kernel selection knobs (A/B measurements, tests; defaults are the measured-best settings):
  *   "attention_variant" 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (default; hd 72)
  *   "gemm_variant"      0 auto tile shape (default) | 1 256x256 | 2 256x288
- *   "gemm_pipeline"     0 auto (default) | 1 ping-pong wave groups | 2 classic double buffer (small-M tiles: register
- *                       pipeline) | 3 single-barrier rendezvous
- *   "gemm_pp_tail"      0 (default) | 1: tail MFMAs issued after the ping-pong hand-over barrier
- *   "gemm_persist"      0 (default) | 1: persistent ping-pong kernel for multi-round SwiGLU GEMMs
+ *   "gemm_swiglu_w4p"   1 (default): dense multi-round SwiGLU GEMMs run on the persistent 4-wave kernel | 0: 8-wave ping-pong
  *   "gemm_stagger"      0 (default) .. 64: 4-wave GEMM kernels (explicit variants 10, 13, 14) spread the start of the workgroups
  *                       of an XCD over eight phases, n * ~1024 cycles apart (experiment knob)
- *   "qkv_post_fused"    0 three launches (default) | 1 one launch for q / k post-processing + V transpose
- *   "norm_specialize"   0 (default) | 1: gated_residual_norm runs instantiations with its three mode switches fixed at compile
- *                       time (the engine's combinations at d = 1536 / 2304 / 3072; bit-identical by construction, unmeasured) */
+ *   "qkv_post_fused"    0 separate launches (default) | 1 one launch for q / k post-processing + V transpose
+ *   "qkv_vt_epilogue"   1 (default): the V projection is its own GEMM whose epilogue writes the attention kernels' transposed,
+ *                       key-permuted V image directly (no V transpose pass; needs tokens per sample % 64 == 0, large M) | 0: off
+ *   "norm_specialize"   1 (default): gated_residual_norm runs instantiations with its three mode switches fixed at compile
+ *                       time (the engine's combinations at d = 1536 / 2304 / 3072; bit-identical, 34.4 -> 31.6 us) | 0: generic
+ *   "graph"             1 (default): one model evaluation is captured into a HIP graph per (shape, arguments) and replayed | 0: eager
+ * (the round-1 knobs gemm_pipeline / gemm_pp_tail / gemm_persist selected study kernels that now live in
+ *  csrc/experimental/ - build with `make EXPERIMENTAL=1` and use the explicit lt_op_gemm_bf16 variants) */
 int lt_set_option(const char* name, int32_t value);
 
 /* ---- engine lifetime ------------------------------------------------------------------------- */
@@ -171,23 +176,29 @@ int lt_profile_set_budget(lt_engine* e, int32_t klass, int64_t max_event_launche
 /* ---- operator-level entry points (parity tests call each kernel through these) ---------------- */
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in/out, fp32 accumulate.  K % 64 == 0.
  * epilogue 0: plain, 1: SwiGLU on 32-row interleaved W (out has N/2 columns: silu(w1 x) * (w3 x)).
- * variant 0: what the engine uses (tile shape / pipeline picked from the problem size); 1 / 2: 256x256 / 256x288 tiles;
- * 3 / 4: the same with the ping-pong kernel; 5 / 6: single-barrier rendezvous kernel; 7 / 8: 128x128 / 64x128 small-M tiles;
- * 9: persistent ping-pong; 10: 4 waves x 128x128 (LDS-DMA); 11: ping-pong with AGPR accumulators (A/B variants, parity-tested);
- * 12: experimental 4-wave VGPR-staged kernel (bit-identical in its first hardware run; tests gated by LUMINA_EXPERIMENTAL=1);
- * 13: experimental persistent 4-wave kernel (variant 10's loop carried across tile boundaries; K % 64 == 0, K >= 128, no bias;
- *     compiled and ISA-checked, not yet run on hardware; tests gated by LUMINA_EXPERIMENTAL=1); 14: the same with a tile's
- *     epilogue issued from inside the next tile's first slab. */
+ * variant 0: what the engine uses (kernel picked from the problem size); 1 / 2: 256x256 / 256x288 tiles, classic double-buffered
+ * loop; 3: 256x256 8-wave ping-pong; 7 / 8: 128x128 / 64x128 small-M tiles; 13 / 14: persistent 4 waves x (128 x 128), LDS ring
+ * and DMA prefetch carried across tile boundaries (K % 64 == 0, K >= 128, no bias; 14 issues a tile's epilogue from inside the
+ * next tile's first slab - the engine's SwiGLU kernel).  4 (256x288 ping-pong), 5 / 6 (single-barrier rendezvous), 9 (persistent
+ * 8-wave ping-pong), 10 (4 x (128 x 128), one tile per workgroup), 11 (AGPR accumulators), 12 (VGPR-staged): round-1 study
+ * kernels, only in EXPERIMENTAL=1 builds (csrc/experimental/). */
 int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, int32_t bias_dtype,
                     void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
                     void* stream);
+/* V projection with the V^T epilogue: vt[b][h][d][perm(tok)] = sum_k A[b * tokens + tok][k] * W[h * hd + d][k] - the attention
+ * kernels' transposed, key-permuted V image (lt_op_v_transpose layout with Npad = tokens) written straight from the GEMM.
+ * M = B * tokens, tokens % 64 == 0, N = kv_heads * hd; variant 0 auto | 1 256x256 | 2 256x288. */
+int lt_op_gemm_vt(const void* A_dev, const void* W_dev, void* vt_dev, int32_t M, int32_t N, int32_t K, int32_t tokens,
+                  int32_t hd, int32_t variant, void* stream);
+/* name of the kernel lt_op_gemm_bf16(..., variant) would launch for a dense problem (bench.py labels its roofline line with it) */
+int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap);
 /* grouped (mixture-of-experts) form of lt_op_gemm_bf16 - replaces the per-expert Python loop `for i, expert in
  * enumerate(self.experts): ... expert(x[batch_idx])` of Next-DiT-MoE/models/models2.py:470-476, :499-505 on expert-sorted
  * rows: rows [256 t, 256 t + 256) of A multiply with W_dev + tile_expert[t] * w_expert_stride (elements); tile_expert[t] < 0
  * marks a padding segment whose output rows are left untouched.  M % 256 == 0; tile_expert_dev: int32 [M / 256]. */
 int lt_op_gemm_grouped(const void* A_dev, const void* W_dev, const void* tile_expert_dev, int64_t w_expert_stride,
                        void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* stream);
-/* diagnostics: a GEMM built with s_memtime stamps (variant 3 | 4 ping-pong, 5 rendezvous, 10 four-wave LDS-DMA, 12 four-wave
+/* diagnostics (EXPERIMENTAL=1 builds only): a GEMM built with s_memtime stamps (variant 3 | 4 ping-pong, 5 rendezvous, 10 four-wave LDS-DMA, 12 four-wave
  * VGPR-staged; plain epilogue); trace_dev (>= 64 * waves * 8 uint64, zeroed by the caller) receives, for every 64th workgroup
  * and each of its waves, 8 x uint64: six per-wave tick totals - variant 3 / 4 / 5: {fragment-read issue, vmcnt wait, lgkmcnt
  * wait, pre-MFMA barrier, MFMA segment, post-MFMA barrier}; 10: {MFMA / read / DMA stream, vmcnt wait, lgkmcnt wait, barrier,

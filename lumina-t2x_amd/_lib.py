@@ -17,6 +17,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lumina_dit.h")
 
 LT_F32, LT_BF16, LT_F16 = 0, 1, 2
 LT_VARIANT_NEXT_T2I, LT_VARIANT_NEXT_IMAGENET, LT_VARIANT_FLAG_T2I, LT_VARIANT_NEXT_MOE = 0, 1, 2, 3
+LT_VARIANT_NEXT_MOE_TIME, LT_VARIANT_NEXT_MOE_SPACE = 4, 5
 LT_ODE_EULER, LT_ODE_MIDPOINT, LT_ODE_RK4 = 0, 1, 2
 ODE_METHODS = {"euler": LT_ODE_EULER, "midpoint": LT_ODE_MIDPOINT, "rk4": LT_ODE_RK4}
 
@@ -77,6 +78,8 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_profile_reset": (_i32, [_vp]),
     "lt_profile_set_budget": (_i32, [_vp, _i32, _i64]),
     "lt_op_gemm_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "lt_op_gemm_vt": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "lt_op_gemm_describe": (_i32, [_i32, _i32, _i32, _i32, _i32, C.c_char_p, _i32]),
     "lt_op_gemm_grouped": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_trace": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "lt_op_pack_w13": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),

@@ -29,7 +29,7 @@ void lt_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lt_last_error(void) { return g_err; }
-extern "C" const char* lt_version(void) { return "lumina_dit gfx950 r1"; }
+extern "C" const char* lt_version(void) { return lt_gemm_has_experimental() ? "lumina_dit gfx950 r2+experimental" : "lumina_dit gfx950 r2"; }
 
 namespace {
 
@@ -37,6 +37,9 @@ constexpr float LOG2E = 1.44269504088896340736f;
 // lt_set_option("qkv_post_fused"): 1 = one launch for q / k post-processing + V transpose, 0 = three launches.  In-situ A/B
 // with the LDS-staged row kernels (profiles/r01/bench_ab_qkv_post_fused.log): three launches 0.1-0.2 ms / NFE faster.
 int g_qkv_post_fused = 0;
+// lt_set_option("qkv_vt_epilogue"): 1 = the V projection is its own GEMM launch whose epilogue writes the attention kernels' V^T
+// image (no v_transpose pass: 15.6 us per layer at cfg 2, and the 37.7 MB V slice is never written row-major / re-read)
+int g_qkv_vt_epilogue = 1;
 
 struct DevBuf {
     void* p = nullptr;
@@ -84,7 +87,9 @@ static VariantDesc variant_desc(int variant) {
     VariantDesc v{};
     if (variant == LT_VARIANT_NEXT_T2I) {
         v = {4, {-1, -1}, {0, 2}, {1, 3}, true, true, true, true, false, false, false, 1};
-    } else if (variant == LT_VARIANT_NEXT_IMAGENET) {
+    } else if (variant == LT_VARIANT_NEXT_IMAGENET || variant == LT_VARIANT_NEXT_MOE_TIME || variant == LT_VARIANT_NEXT_MOE_SPACE) {
+        // (the single-MoE models of Next-DiT-MoE/models/models.py / models1.py are the ImageNet block with its FFN replaced
+        //  by one MoeLayer: four adaLN chunks, same norms - models.py:749-758)
         v = {4, {-1, -1}, {0, 2}, {1, 3}, false, true, true, false, true, false, false, 2};
     } else if (variant == LT_VARIANT_NEXT_MOE) {
         // models2.py:783-784: scale_msa, gate_msa, scale_mlp_time, gate_mlp_time, scale_mlp_space, gate_mlp_space;
@@ -117,6 +122,7 @@ struct lt_engine {
     u16 *tfeat = nullptr, *t1 = nullptr, *temb = nullptr, *cap_ln = nullptr, *cap_emb = nullptr, *adaln_in = nullptr;
     // MoE workspace: expert-sorted rows (moe.hip)
     int E = 0, moe_tiles = 0;
+    int moe_mode = 0;  // 0: time + space MoE per block (models2.py), 1: time-routed MoE only (models.py), 2: token-routed only (models1.py)
     u16 *moe_xs = nullptr, *moe_us = nullptr, *moe_ys = nullptr, *moe_logits = nullptr, *moe_wts = nullptr;
     int *moe_sel = nullptr, *moe_pos = nullptr, *moe_tile_expert = nullptr;
     u16 *capb = nullptr, *capn = nullptr, *kvy = nullptr;
@@ -242,7 +248,25 @@ int find_slot(lt_engine* e, const std::string& key, Slot* s) {
             if (r == "feed_forward.w3.weight") return set(w.w13, F, d, d, 0, 2);
             if (r == "feed_forward.w2.weight") return set(w.w2, d, F, F);
         }
-        if (e->cfg.variant == LT_VARIANT_NEXT_MOE) {
+        if (e->E > 0 && e->moe_mode != 0) {  // one MoeLayer as `feed_forward` (models.py:700-707 / models1.py:700-707)
+            const bool time = e->moe_mode == 1;
+            if (r == "attention_norm.weight") return set(w.attn_norm2, 1, d, d);
+            if (r == "ffn_norm.weight") return set(w.ffn_norm2, 1, d, d);
+            if (r == "feed_forward.gate.weight") return time ? set(w.gate_t, e->E, A, A) : set(w.gate_s, e->E, d, d);
+            const char* pre = "feed_forward.experts.";
+            const size_t pl = strlen(pre);
+            if (r.compare(0, pl, pre) == 0) {
+                char* end = nullptr;
+                const long ex = strtol(r.c_str() + pl, &end, 10);
+                LT_REQUIRE(end != r.c_str() + pl && ex >= 0 && ex < e->E, "weight key %s: expert out of range", key.c_str());
+                const std::string tail(end);
+                u16* w13 = (time ? w.w13_t : w.w13_s) + (size_t)ex * 2 * F * d;
+                u16* w2 = (time ? w.w2_t : w.w2_s) + (size_t)ex * d * F;
+                if (tail == ".w1.weight") return set(w13, F, d, d, 0, 1);
+                if (tail == ".w3.weight") return set(w13, F, d, d, 0, 2);
+                if (tail == ".w2.weight") return set(w2, d, F, F);
+            }
+        } else if (e->cfg.variant == LT_VARIANT_NEXT_MOE) {
             if (r == "attention_norm.weight") return set(w.attn_norm2, 1, d, d);
             if (r == "ffn_norm_time.weight") return set(w.norm_time, 1, d, d);
             if (r == "ffn_norm_space.weight") return set(w.norm_space, 1, d, d);
@@ -471,7 +495,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             if (v.gate_tanh && v.i_gate[i] >= 0) tanh_mask |= 1u << v.i_gate[i];
             if (v.i_scale[i] >= 0) scale_mask |= 1u << v.i_scale[i];
         }
-        if (c.variant == LT_VARIANT_NEXT_MOE) { tanh_mask |= 1u << 5; scale_mask |= 1u << 4; }
+        if (c.variant == LT_VARIANT_NEXT_MOE) { tanh_mask |= 1u << 5; scale_mask |= 1u << 4; }  // the space branch's chunks
         if (launch_prep_mod(e->mod, B, e->ld_mod, L, e->chunks, e->d, tanh_mask, scale_mask, v.final_chunks == 2 ? 1 : 0, s)) return 1;
     }
     auto chunk = [&](int layer, int idx) -> const u16* { return idx < 0 ? nullptr : e->mod + (size_t)layer * cd + (size_t)idx * d; };
@@ -486,7 +510,18 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
     const int post_mode = v.post ? 1 : 0, gate_mode = 0;  // gates arrive ready (tanh applied above where the family has it)
     for (int l = 0; l < L; ++l) {
         LayerW& w = e->lw[l];
-        if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, nullptr, 0, s)) return 1;
+        // V^T epilogue path: q | k columns in one GEMM, the V columns in a second one that writes e->vt directly.  Large problems
+        // only (a second launch of a latency-bound 512-row GEMM costs more than the transpose), whole 64-key tiles per sample
+        // (no key padding to zero), and not for packed batches (their padded rows must read as zero keys)
+        const bool vt_epi = g_qkv_vt_epilogue && !pk && N % 64 == 0 && (long long)((M + 255) / 256) * ((dkv + 255) / 256) >= 128;
+        if (vt_epi) {
+            if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, d + dkv, d, nullptr, 0, s)) return 1;
+            GemmArgs g;
+            g.A = e->h; g.W = w.wqkv + (size_t)(d + dkv) * d; g.C = e->vt; g.bias = nullptr; g.bias_dtype = -1;
+            g.M = M; g.N = dkv; g.K = d; g.lda = d; g.ldw = d; g.ldc = 0; g.vt_tokens = N; g.vt_hd = hd; g.vt_npad = Npad;
+            ProfScope ps(e, 0, 2.0 * M * (double)dkv * d, s, true);
+            if (launch_gemm_bf16(g, 2, 0, s, ps.ev0(), ps.ev1())) return 1;
+        } else if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, nullptr, 0, s)) return 1;
         {
             ProfScope ps(e, 2, 0, s);
             QkPostArgs qa;
@@ -504,12 +539,12 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             pa.k = qa;
             pa.v_src = e->qkv; pa.v_dst = e->vt; pa.v_ld_src = e->qkvn; pa.v_col0 = d + dkv; pa.v_B = B; pa.v_N = N;
             pa.v_Npad = Npad; pa.v_kv_heads = Hkv; pa.v_hd = hd;
-            if (g_qkv_post_fused) {
+            if (g_qkv_post_fused && !vt_epi) {
                 if (launch_qkv_post(pa, s)) return 1;  // q, k post-processing and the V transpose in one launch
             } else {
                 if (launch_qk_norm_rope(pa.q, s)) return 1;
                 if (launch_qk_norm_rope(pa.k, s)) return 1;
-                if (launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
+                if (!vt_epi && launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
             }
         }
         AttnArgs at;
@@ -555,6 +590,10 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s)) return 1;
             if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s)) return 1;
             last_post_w = v.post ? w.ffn_norm2 : nullptr;
+            last_gate = chunk(l, v.i_gate[1]);
+        } else if (e->moe_mode != 0) {  // one MoE FFN in the ImageNet block (models.py:755-758: time-routed; models1.py: per token)
+            if (moe_ffn(e, w, e->moe_mode == 1 ? 0 : 1, M, N, B, s)) return 1;
+            last_post_w = w.ffn_norm2;
             last_gate = chunk(l, v.i_gate[1]);
         } else {  // time MoE -> residual -> space MoE (models2.py:793-800)
             if (moe_ffn(e, w, 0, M, N, B, s)) return 1;
@@ -618,8 +657,9 @@ float bf16_round_host(float f) {
 // =====================================================================================================
 extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     LT_REQUIRE(cfg && out, "lt_create: null argument");
-    LT_REQUIRE(cfg->variant >= LT_VARIANT_NEXT_T2I && cfg->variant <= LT_VARIANT_NEXT_MOE, "lt_create: unknown variant %d", cfg->variant);
-    LT_REQUIRE(cfg->variant != LT_VARIANT_NEXT_MOE || (cfg->num_experts >= 2 && cfg->num_experts <= 8),
+    LT_REQUIRE(cfg->variant >= LT_VARIANT_NEXT_T2I && cfg->variant <= LT_VARIANT_NEXT_MOE_SPACE, "lt_create: unknown variant %d", cfg->variant);
+    const bool is_moe = cfg->variant == LT_VARIANT_NEXT_MOE || cfg->variant == LT_VARIANT_NEXT_MOE_TIME || cfg->variant == LT_VARIANT_NEXT_MOE_SPACE;
+    LT_REQUIRE(!is_moe || (cfg->num_experts >= 2 && cfg->num_experts <= 8),
                "lt_create: the MoE variant needs 2..8 experts (top-2 routing), got %d", cfg->num_experts);
     const VariantDesc vd = variant_desc(cfg->variant);
     LT_REQUIRE(cfg->dim > 0 && cfg->n_layers >= 1 && cfg->n_heads >= 1 && cfg->n_kv_heads >= 1 && cfg->ffn_hidden > 0 && cfg->adaln_dim > 0,
@@ -644,7 +684,8 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     e->cap = vd.text ? cfg->cap_feat_dim : 0; e->nfinal = cfg->patch_size * cfg->patch_size * cfg->out_channels;
     e->kpad = 64; e->chunks = vd.chunks; e->ld_mod = e->L * e->chunks * e->d + vd.final_chunks * e->d;
     e->label_rows = vd.labels ? cfg->num_classes + 1 : 0;
-    e->E = cfg->variant == LT_VARIANT_NEXT_MOE ? cfg->num_experts : 0;
+    e->E = is_moe ? cfg->num_experts : 0;
+    e->moe_mode = cfg->variant == LT_VARIANT_NEXT_MOE_TIME ? 1 : (cfg->variant == LT_VARIANT_NEXT_MOE_SPACE ? 2 : 0);
     // 2-D RoPE: positions per axis (384, model.py:734); 1-D: one position per token of the longest sequence
     e->rope_len = vd.rope_1d ? round_up(cfg->max_tokens, 64) : (cfg->rope_table_len > 0 ? cfg->rope_table_len : 384);
     const int d = e->d, L = e->L, F = e->F, dkv = e->dkv, A = e->A, cap = e->cap, H = e->H, Hkv = e->Hkv;
@@ -658,8 +699,9 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         if (e->E == 0) { A16(w.w13, (size_t)2 * F * d); A16(w.w2, (size_t)d * F); }
         else {
             const size_t E_ = e->E;
-            A16(w.w13_t, E_ * 2 * F * d); A16(w.w2_t, E_ * d * F); A16(w.w13_s, E_ * 2 * F * d); A16(w.w2_s, E_ * d * F);
-            A16(w.gate_t, E_ * A); A16(w.gate_s, E_ * d); A16(w.norm_time, d); A16(w.norm_space, d);
+            if (e->moe_mode != 2) { A16(w.w13_t, E_ * 2 * F * d); A16(w.w2_t, E_ * d * F); A16(w.gate_t, E_ * A); }
+            if (e->moe_mode != 1) { A16(w.w13_s, E_ * 2 * F * d); A16(w.w2_s, E_ * d * F); A16(w.gate_s, E_ * d); }
+            A16(w.norm_time, d); A16(w.norm_space, d);
         }
         A16(w.q_norm_w, d); A16(w.q_norm_b, d); A16(w.k_norm_w, dkv); A16(w.k_norm_b, dkv);
         A16(w.attn_norm1, d); A16(w.attn_norm2, d); A16(w.ffn_norm1, d); A16(w.ffn_norm2, d);
@@ -677,6 +719,8 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         else if (cfg->variant == LT_VARIANT_NEXT_MOE)
             for (const char* nm : {"attention_norm.weight", "ffn_norm_time.weight", "ffn_norm_space.weight",
                                    "feed_forward_time.gate.weight", "feed_forward_space.gate.weight"}) names.push_back(nm);
+        else if (e->moe_mode != 0)
+            for (const char* nm : {"attention_norm.weight", "ffn_norm.weight", "feed_forward.gate.weight"}) names.push_back(nm);
         else
             for (const char* nm : {"attention_norm.weight", "ffn_norm.weight"}) names.push_back(nm);
         if (cfg->qk_norm) {
@@ -687,7 +731,8 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         for (int ex = 0; ex < e->E; ++ex)
             for (const char* br : {"feed_forward_time", "feed_forward_space"})
                 for (const char* wn : {"w1", "w2", "w3"}) {
-                    snprintf(key, sizeof(key), "layers.%d.%s.experts.%d.%s.weight", l, br, ex, wn);
+                    if (e->moe_mode != 0 && br[13] == 's') continue;  // one MoeLayer: keys "feed_forward.experts..."
+                    snprintf(key, sizeof(key), "layers.%d.%s.experts.%d.%s.weight", l, e->moe_mode != 0 ? "feed_forward" : br, ex, wn);
                     e->need[key] = false;
                 }
     }
@@ -770,6 +815,9 @@ extern "C" int lt_set_weight(lt_engine* e, const char* key, const void* src_dev,
     auto it = e->need.find(key);
     if (it != e->need.end()) it->second = true;
     e->weights_ok = false;
+    // the hoisted conditioning (text K / V of every layer, caption / label embedding) was computed from the previous weights:
+    // the next step must be preceded by a new lt_prepare_prompt / lt_prepare_labels (run_forward refuses otherwise)
+    e->prompt_B = 0;
     return 0;
 }
 
@@ -1056,12 +1104,16 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     LT_REQUIRE(name, "lt_set_option: null name");
     if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 3, "attention_variant must be 1, 2 or 3"); lt_set_attention_variant(value); return 0; }
     if (strcmp(name, "qkv_post_fused") == 0) { g_qkv_post_fused = value != 0; return 0; }
-    if (strcmp(name, "gemm_persist") == 0) { lt_set_gemm_persist(value != 0); return 0; }
-    if (strcmp(name, "gemm_pp_tail") == 0) { lt_set_gemm_pp_tail(value != 0); return 0; }
+    if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
+    if (strcmp(name, "gemm_swiglu_w4p") == 0) { lt_set_gemm_swiglu_w4p(value != 0); return 0; }
     if (strcmp(name, "gemm_stagger") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_stagger must be 0..64"); return lt_set_gemm_stagger(value); }
-    if (strcmp(name, "gemm_pipeline") == 0) { LT_REQUIRE(value >= 0 && value <= 3, "gemm_pipeline must be 0..3"); lt_set_gemm_pipeline(value); return 0; }
     if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }
+    if (strcmp(name, "gemm_pipeline") == 0 || strcmp(name, "gemm_pp_tail") == 0 || strcmp(name, "gemm_persist") == 0) {
+        // round-1 study knobs: the kernels they selected moved to csrc/experimental/ (explicit lt_op_gemm_bf16 variants there)
+        LT_REQUIRE(value == 0, "lt_set_option(%s): removed - the round-1 study kernels are explicit variants of EXPERIMENTAL=1 builds", name);
+        return 0;
+    }
     lt_set_error("lt_set_option: unknown option '%s'", name);
     return 2;
 }
@@ -1074,6 +1126,24 @@ extern "C" int lt_op_gemm_bf16(const void* A, const void* W, const void* bias, i
     g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = bias ? bias_dtype : -1;
     return launch_gemm_bf16(g, epilogue, variant, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_gemm_vt(const void* A, const void* W, void* vt, int32_t M, int32_t N, int32_t K, int32_t tokens, int32_t hd,
+                             int32_t variant, void* stream) {
+    LT_REQUIRE(A && W && vt, "lt_op_gemm_vt: null pointer");
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)vt; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = 0; g.bias_dtype = -1; g.vt_tokens = tokens; g.vt_hd = hd; g.vt_npad = tokens;
+    return launch_gemm_bf16(g, 2, variant, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap) {
+    LT_REQUIRE(out && cap > 0, "lt_op_gemm_describe: null buffer");
+    GemmArgs g;
+    g.A = nullptr; g.W = nullptr; g.C = nullptr; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = -1;
+    snprintf(out, (size_t)cap, "%s", lt_gemm_describe(g, epilogue, variant));
+    return 0;
 }
 
 extern "C" int lt_op_gemm_grouped(const void* A, const void* W, const void* tile_expert, int64_t w_expert_stride, void* C,

@@ -1,0 +1,1042 @@
+// Device code of the bf16 MFMA GEMM family (kernel templates + shared epilogue); instantiated by gemm_bf16.hip (product
+// kernels) and experimental/gemm_experimental.hip (A/B variants that lost or were never adopted, built with EXPERIMENTAL=1).
+#pragma once
+#include "common.h"
+#include "kernels.h"
+#include <hip/hip_ext.h>
+#include <algorithm>
+#include <type_traits>
+
+namespace {
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ void tile_coords(int bid, int nwg, int TM, int TN, int& tm, int& tn) {
+    const int NX = 8;
+    const int xcd = bid % NX, idx = bid / NX;
+    const int q = nwg / NX, r = nwg % NX;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int G = 4;
+    const int per_group = G * TN;
+    const int g = L / per_group;
+    const int first_m = g * G;
+    const int gsz = min(G, TM - first_m);
+    const int in = L - g * per_group;
+    tm = first_m + in % gsz;
+    tn = in / gsz;
+}
+
+__device__ __forceinline__ float load_bias(const void* bias, int dt, int n) {
+    return dt == 0 ? ((const float*)bias)[n] : bf2f(((const u16*)bias)[n]);
+}
+
+}  // namespace
+
+// (named namespace: a __global__ template with internal linkage that is only instantiated from another
+//  template loses its host stub with hipcc 7.2)
+namespace lt_gemm {
+
+// ---- epilogue shared by both GEMM kernels: lane holds, per 32x32 tile, row m = l31 and columns 8q + 4hi + j (reg 4q+j) ----
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[MT][NT], const GemmArgs& p, int m0, int n0, int wm, int wn,
+                                           int hi, int l31) {
+    if constexpr (EPI == 2) {
+        // V^T epilogue.  The MFMAs ran with swapped operands (D = A_frag x W_frag), so here a lane holds, per 32x32 tile, COLUMN
+        // n = l31 and rows m = 8 q + 4 hi + j (reg 4 q + j).  Destination: vt[b][kv head][d][token'] (AttnArgs::vt) with the
+        // keys of every group of 16 permuted (bits 2 and 3 of the position swapped - the order in which a lane of the swapped
+        // QK^T MFMA holds its P values, see v_transpose in qkv_post.hip).  Rows 8 q + 4 hi + j of one 16-group (q = 2 g, 2 g + 1)
+        // land on positions 8 hi + 4 (q & 1) + j: the lane's two register quads are 8 CONSECUTIVE permuted keys = one 16-byte
+        // store, no cross-lane exchange.  Tokens per sample are a multiple of 64 (launcher), so a 32-row tile lies in one sample.
+        const int ntok = p.vt_tokens, hd = p.vt_hd, kvh = p.N / hd;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + wn * NT * 32 + nt * 32 + l31;
+            const int head = n / hd, d = n - head * hd;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int mtile = m0 + wm * MT * 32 + mt * 32;  // first row of the 32-row tile (wave-uniform)
+                const int b = mtile / ntok, tok0 = mtile - b * ntok;
+                u16* drow = p.C + (((size_t)b * kvh + head) * hd + d) * (size_t)p.vt_npad + tok0 + 8 * hi;
+                if (mtile < p.M && n < p.N) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const u32x4 o = {pack2bf_pk(acc[mt][nt][8 * g + 0], acc[mt][nt][8 * g + 1]),
+                                         pack2bf_pk(acc[mt][nt][8 * g + 2], acc[mt][nt][8 * g + 3]),
+                                         pack2bf_pk(acc[mt][nt][8 * g + 4], acc[mt][nt][8 * g + 5]),
+                                         pack2bf_pk(acc[mt][nt][8 * g + 6], acc[mt][nt][8 * g + 7])};
+                        *(u32x4*)(drow + 16 * g) = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const size_t ldc = p.ldc;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * MT * 32 + mt * 32 + l31;
+        u16* crow = p.C + (size_t)m * ldc;
+        if (EPI == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nbase = n0 + wn * NT * 32 + nt * 32;
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = acc[mt][nt][8 * qp + j];
+                    if (p.bias_dtype >= 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            int n = nbase + 16 * qp + 8 * (j >> 2) + 4 * hi + (j & 3);
+                            n = n < p.N ? n : p.N - 1;  // clamped (branch-free); out-of-range columns are not stored
+                            v[j] += load_bias(p.bias, p.bias_dtype, n);
+                        }
+                    }
+                    unsigned ax = pack2bf_pk(v[0], v[1]), ay = pack2bf_pk(v[2], v[3]);
+                    unsigned bx = pack2bf_pk(v[4], v[5]), by = pack2bf_pk(v[6], v[7]);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    const int col = nbase + 16 * qp + 8 * hi;
+                    if (m < p.M && col < p.N) {
+                        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        *(u32x4*)(crow + col) = o;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int np = 0; np < NT / 2; ++np) {
+                const int obase = (n0 + wn * NT * 32 + np * 64) / 2;
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
+                        const float a = bfr(acc[mt][2 * np][8 * qp + j]);
+                        const float b = bfr(acc[mt][2 * np + 1][8 * qp + j]);
+                        v[j] = bfr(silu_f(a)) * b;
+                    }
+                    unsigned ax = pack2bf_pk(v[0], v[1]), ay = pack2bf_pk(v[2], v[3]);
+                    unsigned bx = pack2bf_pk(v[4], v[5]), by = pack2bf_pk(v[6], v[7]);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    const int col = obase + 16 * qp + 8 * hi;
+                    if (m < p.M && col < p.N / 2) {
+                        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        *(u32x4*)(crow + col) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// WM x WN waves, each owning an (MT*32) x (NT*32) block of C.  Tile = (WM*MT*32) x (WN*NT*32) x 64.
+//   <2,4,4,2>: 256 x 256, 8 waves  (128 accumulators / lane)  - default and the SwiGLU epilogue
+//   <4,3,2,3>: 256 x 288, 12 waves ( 96 accumulators / lane)  - N = 2304 / 6912: 8192 x 2304 is exactly
+//              256 tiles = one round of the 256 CUs (256-wide tiles need 288 = 1.125 rounds -> 2 rounds)
+template <int WM, int WN, int MT, int NT, int EPI>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_tn(GemmArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int PA = BM / 8, PW = BN / 8;           // 1-KiB staging pieces (8 rows x 128 B)
+    constexpr int IA = (PA + NW - 1) / NW, IW = (PW + NW - 1) / NW;
+    constexpr int W_OFF = BM * 128;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(EPI != 1 || NT % 2 == 0, "SwiGLU epilogue pairs accumulator tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, TM, TN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const u16* Wg = p.W;
+    if (p.tile_expert) {  // grouped mode: the 256-row segment this tile lies in belongs to one expert (or is padding)
+        const int ex = p.tile_expert[(tm * BM) >> 8];
+        if (ex < 0) return;
+        Wg += (size_t)ex * p.w_expert_stride;
+    }
+
+    // descriptors based at the tile's first row; num_records = bytes left => rows past the end read 0
+    const long long a_left = (long long)(p.M - m0) * p.lda * 2;
+    const long long w_left = (long long)(p.N - n0) * p.ldw * 2;
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.A + (size_t)m0 * p.lda), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
+    __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(Wg + (size_t)n0 * p.ldw), 0, (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left), 0x00020000);
+
+    // staging: wave w copies pieces w, w + NW, ... of the A tile and of the W tile.  Piece j holds rows
+    // 8j..8j+7; the lane's 16-byte chunk c of row r is fetched from source chunk c ^ ((r >> 1) & 7).
+    const int srow = wave * 8 + (lane >> 3);
+    const int sswz = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16;  // NW is even: parity of j = parity of w
+    static_assert(IA <= 4 && IW <= 4, "staging pieces per wave");
+    int a_voff[4], w_voff[4];  // fixed size: a dependent bound here breaks host-side substitution (hipcc 7.2)
+#pragma unroll
+    for (int i = 0; i < IA; ++i) a_voff[i] = (srow + 8 * NW * i) * p.lda * 2 + sswz;
+#pragma unroll
+    for (int i = 0; i < IW; ++i) w_voff[i] = (srow + 8 * NW * i) * p.ldw * 2 + sswz;
+    auto stage = [&](int buf, int kt) {
+        const int soff = kt * BK * 2;
+        char* base = smem + buf * STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+            if (wave + NW * i < PA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(base + i * NW * 1024), 16, a_voff[i], soff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < IW; ++i)
+            if (wave + NW * i < PW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(base + W_OFF + i * NW * 1024), 16, w_voff[i], soff, 0, 0);
+    };
+
+    // fragment read offsets (row ≡ l31 mod 32 in every sub-tile, so the swizzle key is per lane)
+    const int fswz = (l31 >> 1) & 7;
+    const int a_row_off = (wm * MT * 32 + l31) * 128;
+    const int w_row_off = W_OFF + (wn * NT * 32 + l31) * 128;
+    int coff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) coff[s] = ((2 * s + hi) ^ fswz) << 4;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 wf[NT], af[MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(sb + w_row_off + nt * 4096 + coff[s]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf16x8*)(sb + a_row_off + mt * 4096 + coff[s]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = EPI == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0)   // rows = m
+                                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);  // rows = n
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
+}
+
+
+// ---- ping-pong kernel ---------------------------------------------------------------------------------
+// Same tile shapes and fragment/epilogue layout as gemm_bf16_tn, different time structure.  The workgroup's
+// waves form G = NW/4 groups (group = wave / 4, i.e. the G waves that share one SIMD belong to G different
+// groups).  K is consumed in 32-deep slabs held in a 4-slot LDS ring (64-byte rows, XOR swizzle on the two
+// chunk-index bits).  Per slab every wave runs
+//        READ  (fragment ds_reads of slab s, counted vmcnt for slab s+1, lgkmcnt(0))   | s_barrier
+//        MFMA  (all MFMAs of slab s, with the LDS-DMA of slab s+3 issued between them)   | s_barrier  [+ G-2 idle]
+// and group g starts g barrier intervals late, so on every SIMD exactly one wave is in its MFMA segment while
+// the others read / wait: the matrix pipe sees back-to-back MFMA segments and no wave ever drains vmcnt to 0
+// in the main loop (LDS-DMA stays in flight across barriers; guide T3/T4, "Pipelining across barriers").
+//
+// Hazards, in barrier-interval units (READ(s) of group g runs in interval G*s + g, MFMA(s) one later):
+//   RAW  slab s+1 is waited for (each wave: its own pieces) in READ(s), interval G*s+g, and first read in
+//        READ(s+1), interval G*s+G+g' > G*s+g for all g, g'  -> a barrier every wave has passed lies between.
+//   WAR  slab s+4 reuses the slot of slab s; it is issued in MFMA(s+1), interval G*s+G+g+1, while the last
+//        read of slab s completed (lgkmcnt(0) before the barrier) in interval G*s+g' <= G*s+G-1.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// TAILN: the barrier that hands the matrix pipe to the other group sits TAILN MFMAs before the end of the MFMA segment; those
+// last MFMAs (k-step 1 fragments, registers only) are issued after the barrier INSIDE the group's next READ segment, between
+// its k-step 0 fragment reads, so the barrier's release latency (~95 cycles) is covered by this group's MFMA work while the
+// other group starts.  (First attempt, tail issued BEFORE the next READ: 5-8 % slower, profiles/r01/opbench_pp_tail_ab.log -
+// READ then started TAILN MFMAs late and READ + tail, not the MFMA segment, set the barrier interval.)
+// Measured (profiles/r01/opbench_gemm_pipelines.log): no gain either - a wave parked in s_barrier cannot issue, so the pipe
+// still idles for the release latency, and the tail MFMAs simply come out of the other group's segment (505 instead of 416
+// cycles for its 13 MFMAs).  Default stays TAILN = 0; option "gemm_pp_tail" keeps the A/B.
+//
+// MODE 1 ("rendezvous"): ONE barrier per slab.  Between two barriers group 0 runs MFMA(k) then READ(k+1), the other groups run
+// READ(k) then MFMA(k): matrix work sits beside memory work in both halves of the interval without a hand-over barrier in the
+// middle (an in-order wave whose MFMA finds the pipe busy simply waits for it), so the pipe idles for one barrier release per
+// slab instead of one per segment.  Hazards (interval k = after barrier k): slab k+1 is read in interval k (group 0) or k+1
+// (others) and every wave waited for its pieces of slab k+1 before barrier k; slab k+3 is issued in interval k into the slot
+// of slab k-1, whose last reads (other groups, interval k-1) completed before barrier k.
+// KS: MFMA k-steps per slab (2 = 32-deep slabs, 64-byte LDS rows; 4 = 64-deep, 128-byte rows).  The deep form halves the
+// number of barrier intervals of a K loop; the small-M tiles use it, where an interval holds only 2-4 MFMAs per wave and the
+// loop is barrier-latency bound (the 256-wide tiles cannot: 4 slots x 64 KiB exceed the LDS).
+// AGPR: issue the MFMAs as inline assembly with the accumulators constrained to the AGPR file.  (The builtin lets the compiler
+// use the unified-VGPR form whenever the kernel fits 256 registers, which the 8-wave kernels do; the vendor library's kernels
+// keep their accumulators in AGPRs and run ~25 % faster clocks on the same problem - profiles/r01/vendor_vs_engine_pmc.log.)
+// Experiment knob of the 4-wave kernels (variants 10, 13, 14; lt_set_option("gemm_stagger", n)): workgroup b sleeps
+// ((b >> 3) & 7) * n * ~1024 cycles before its first load, which spreads the CUs of an XCD over eight tile phases.  All tiles of
+// a GEMM take the same time, so without it every CU of the chip is in its prologue / epilogue at the same moment; whether that
+// synchronised idle phase is what keeps the clock low is one of the next round's questions.  A __device__ word
+// instead of a GemmArgs field: the kernels of the product path do not read it and keep their argument layout.
+__device__ __forceinline__ void stagger_start(int n) {
+    if (n > 0) {
+        const int reps = ((blockIdx.x >> 3) & 7) * n;
+        for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+}
+
+template <int WM, int WN, int MT, int NT, int EPI, bool TRACE = false, int TAILN = 0, int MODE = 0, int KS = 2, bool AGPR = false>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(GemmArgs p) {
+    static_assert(MODE == 0 || TAILN == 0, "rendezvous mode has no hand-over barrier");
+    static_assert(KS == 2 || KS == 4, "slab depth 32 or 64");
+    static_assert(TAILN == 0 || KS == 2, "tail overlap is written for 32-deep slabs");
+    constexpr int RB = KS * 32;          // bytes per LDS row
+    constexpr int RPP = 1024 / RB;       // rows per 1-KiB staging piece
+    constexpr int LPR = RB / 16;         // lanes (16-byte chunks) per row
+    constexpr int NW = WM * WN, G = NW / 4;
+    static_assert(NW % 4 == 0 && ((G >= 2 && G <= 3) || (MODE == 2 && G == 1)), "ping-pong needs 2 or 3 waves per SIMD");
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int PA = BM / RPP, PW = BN / RPP, NP = PA + PW;  // 1-KiB pieces (RPP rows x RB bytes) per slab
+    constexpr int IP = (NP + NW - 1) / NW;                     // pieces per wave per slab (same for every wave)
+    constexpr int SLAB = (BM + BN) * RB, W_OFF = BM * RB;
+    static_assert(EPI != 1 || NT % 2 == 0, "SwiGLU epilogue pairs accumulator tiles");
+    static_assert(IP <= 8, "staging pieces per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long t_entry = 0;
+    if constexpr (TRACE) t_entry = __builtin_amdgcn_s_memtime();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, TM, TN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const long long a_left = (long long)(p.M - m0) * p.lda * 2;
+    const long long w_left = (long long)(p.N - n0) * p.ldw * 2;
+    const int a_bytes = (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left);
+    const int w_bytes = (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left);
+    const u16* Wg = p.W;
+    if (p.tile_expert) {  // grouped mode (see GemmArgs; the table is per 256 rows); uniform exit before any barrier
+        const int ex = p.tile_expert[(tm * BM) >> 8];
+        if (ex < 0) return;
+        Wg += (size_t)ex * p.w_expert_stride;
+    }
+    const u16* a_base = p.A + (size_t)m0 * p.lda;
+    const u16* w_base = Wg + (size_t)n0 * p.ldw;
+
+    // staging: wave w owns pieces w, w + NW, ... (a surplus slot re-loads the wave's previous piece: same bytes
+    // to the same place, so every wave issues exactly IP loads per slab and one vmcnt literal fits all).
+    // Piece q holds rows RPP q .. RPP q + RPP - 1 of A (q < PA) or of W; lane -> row RPP q + lane / LPR, 16-byte position
+    // lane % LPR, fetched from source chunk pos ^ key(row): key = (row >> 2) & 3 for 64-byte rows, (row >> 1) & 7 for
+    // 128-byte rows (the same keys the fragment reads apply, so a 32x32x16 fragment read is bank-conflict free).
+    __amdgpu_buffer_rsrc_t rs[8];  // fixed size: a dependent bound here breaks host-side substitution (hipcc 7.2)
+    int voff[8], ldsoff[8];
+#pragma unroll
+    for (int i = 0; i < IP; ++i) {
+        int q = wave + NW * i;
+        if (q >= NP) q -= NW;
+        const bool isA = q < PA;
+        const int r0 = RPP * (isA ? q : q - PA) + lane / LPR;
+        const int key = KS == 2 ? (r0 >> 2) & 3 : (r0 >> 1) & 7;
+        rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(isA ? a_base : w_base), 0, isA ? a_bytes : w_bytes, 0x00020000);
+        voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + (((lane % LPR) ^ key) << 4);
+        ldsoff[i] = q * 1024;
+    }
+    auto stage = [&](int slab) {
+        char* base = smem + (slab & 3) * SLAB;
+        const int soff = slab * RB;
+#pragma unroll
+        for (int i = 0; i < IP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i], LDS_PTR(base + ldsoff[i]), 16, voff[i], soff, 0, 0);
+    };
+
+    const int fswz = KS == 2 ? (l31 >> 2) & 3 : (l31 >> 1) & 7;
+    const int a_row_off = (wm * MT * 32 + l31) * RB;
+    const int w_row_off = W_OFF + (wn * NT * 32 + l31) * RB;
+    constexpr int TSTRIDE = 32 * RB;  // LDS bytes between two 32-row fragment tiles
+    int coff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) coff[s] = ((2 * s + hi) ^ fswz) << 4;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ns = p.K / (16 * KS);
+    if constexpr (MODE == 2 && G == 1) stagger_start(p.stagger);  // 4-wave kernel only (variant 10)
+    // prologue: slabs 0..2 in flight, slab 0 landed and visible
+    stage(0);
+    if (ns > 1) stage(1);
+    if (ns > 2) stage(2);
+    if (ns > 2) wait_vmcnt<2 * IP>();
+    else if (ns > 1) wait_vmcnt<IP>();
+    else wait_vmcnt<0>();
+    pp_barrier();
+    if constexpr (MODE == 0)
+        for (int g = 0; g < grp; ++g) pp_barrier();
+
+    bf16x8 wf[KS][NT], af[KS][MT];
+    // TRACE build only: per-wave cycle totals of the six sub-segments of a step (s_memtime stamps)
+    unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, ta = 0, tb = 0, tc = 0;
+    unsigned long long tstart = 0;
+    if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
+    constexpr int NM = KS * MT * NT;  // MFMAs of one segment
+    static_assert(TAILN >= 0 && TAILN < MT * NT, "tail MFMAs must all belong to k-step 1");
+    auto one_mfma = [&](int idx) __attribute__((always_inline)) {
+        const int k = idx / (MT * NT), mt = (idx / NT) % MT, nt = idx % NT;
+        if constexpr (AGPR)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wf[k][nt]), "v"(af[k][mt]));
+        else
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], af[k][mt], acc[mt][nt], 0, 0, 0);
+    };
+    // READ(s).  with_tail: the last TAILN MFMAs of the previous slab (k-step 1 fragments, registers only) are issued here,
+    // AFTER the hand-over barrier, interleaved with the k-step 0 fragment reads of slab s - so the barrier's release latency
+    // is covered by MFMA work of this group and this group's reads start at the hand-over, not TAILN MFMAs later.
+    auto read_seg = [&](int s, auto with_tail) __attribute__((always_inline)) {
+        const char* sb = smem + (s & 3) * SLAB;
+        constexpr bool WT = decltype(with_tail)::value && TAILN > 0;
+        constexpr int R0 = NT + MT;
+        auto read0 = [&](int r) __attribute__((always_inline)) {
+            if (r < NT) wf[0][r] = *(const bf16x8*)(sb + w_row_off + r * TSTRIDE + coff[0]);
+            else af[0][r - NT] = *(const bf16x8*)(sb + a_row_off + (r - NT) * TSTRIDE + coff[0]);
+        };
+        if constexpr (WT) {
+            constexpr int RPT = R0 / (TAILN > 0 ? TAILN : 1);  // k-step 0 reads per tail MFMA
+            static_assert(R0 % (TAILN > 0 ? TAILN : 1) == 0, "tail interleave");
+            // the tail must win the matrix pipe against the other group's freshly started segment (same-priority arbitration
+            // is oldest-wave-first: the younger group's tail would sit behind the older group's whole segment and hold up
+            // this in-order wave's fragment reads behind it)
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int i = 0; i < TAILN; ++i) {
+                one_mfma(NM - TAILN + i);
+#pragma unroll
+                for (int r = i * RPT; r < (i + 1) * RPT; ++r) read0(r);
+            }
+#pragma unroll
+            for (int i = 0; i < TAILN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RPT, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R0; ++r) read0(r);
+        }
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * TSTRIDE + coff[k]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * TSTRIDE + coff[k]);
+        }
+        if constexpr (TRACE) ta = __builtin_amdgcn_s_memtime();
+        if (s + 2 < ns) wait_vmcnt<IP>();  // slab s+1 landed (slab s+2 may still be in flight)
+        else wait_vmcnt<0>();
+        if constexpr (TRACE) tb = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (TRACE) {
+            tc = __builtin_amdgcn_s_memtime();
+            tr[0] += ta - tprev; tr[1] += tb - ta; tr[2] += tc - tb;
+        }
+        pp_barrier();
+        if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); }
+    };
+    auto mfma_seg = [&](int s, auto do_stage) __attribute__((always_inline)) {  // MFMAs [0, NM - TAILN) + the LDS-DMA of slab s+3
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int HEAD = NM - TAILN;
+        constexpr int EVERY = HEAD / IP > 0 ? HEAD / IP : 1;
+        int issued = 0;
+        char* base = smem + ((s + 3) & 3) * SLAB;
+        const int soff = (s + 3) * RB;
+#pragma unroll
+        for (int i = 0; i < HEAD; ++i) {
+            one_mfma(i);
+            if constexpr (decltype(do_stage)::value) {
+                if ((i + 1) % EVERY == 0 && issued < IP) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[issued], LDS_PTR(base + ldsoff[issued]), 16, voff[issued], soff, 0, 0);
+                    ++issued;
+                }
+            }
+        }
+        if constexpr (decltype(do_stage)::value) {
+            // pin the interleave: EVERY MFMAs, one LDS-DMA issue, ... (a clustered burst of DMA issues would
+            // starve the matrix pipe of this in-order wave for a few hundred cycles)
+#pragma unroll
+            for (int i = 0; i < IP; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, EVERY, 0);
+                __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+            }
+            if constexpr (HEAD - IP * EVERY > 0) __builtin_amdgcn_sched_group_barrier(0x8, HEAD - IP * EVERY, 0);
+        }
+        if constexpr (TRACE) {
+            __builtin_amdgcn_sched_barrier(0);
+            ta = __builtin_amdgcn_s_memtime();
+            if constexpr (MODE == 0) tr[3] += tprev - tc;
+            tr[4] += ta - tprev;
+            tprev = ta;
+        }
+    };
+    auto mfma_tail = [&]() __attribute__((always_inline)) {  // the last slab's tail (no hand-over follows)
+#pragma unroll
+        for (int i = NM - TAILN; i < NM; ++i) one_mfma(i);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto trace_gap = [&]() {  // after the post-MFMA barrier(s)
+        if constexpr (TRACE) {
+            ta = __builtin_amdgcn_s_memtime();
+            tr[5] += ta - tprev;
+            tprev = ta;
+        }
+    };
+
+    // every MFMA segment but the last one ends with the hand-over barrier; its tail is issued by the next READ
+    auto step = [&](int s, auto do_stage, auto with_tail) __attribute__((always_inline)) {
+        read_seg(s, with_tail);
+        mfma_seg(s, do_stage);
+        if (s + 1 < ns) {
+            pp_barrier();
+            if constexpr (TAILN == 0) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int g = 0; g < G - 2; ++g) pp_barrier();
+        } else {
+            mfma_tail();
+        }
+        trace_gap();
+    };
+    if constexpr (MODE == 0) {
+        int s = 0;
+        if (ns > 3) { step(0, std::true_type{}, std::false_type{}); s = 1; }
+        for (; s + 3 < ns; ++s) step(s, std::true_type{}, std::true_type{});
+        if (s == 0) { step(0, std::false_type{}, std::false_type{}); s = 1; }
+        for (; s < ns; ++s) step(s, std::false_type{}, std::true_type{});
+        for (int g = grp; g < G - 1; ++g) pp_barrier();  // equalise barrier counts before the (barrier-free) epilogue
+    } else if constexpr (MODE == 2) {
+        // MODE 2 ("register pipeline", small tiles): every wave runs the same stream, fragments double-buffered in registers -
+        // the reads of slab k+1 are issued BEFORE the MFMAs of slab k, so the LDS latency hides behind them and an interval
+        // is max(reads, MFMAs) + one barrier.  For tiles whose interval holds only 2-8 MFMAs per wave nothing is gained by
+        // giving the matrix pipe to one wave group at a time; the serial READ -> MFMA dependency per interval is what costs.
+        bf16x8 wf2[KS][NT], af2[KS][MT];
+        auto reads_to = [&](int s, bf16x8 (&w)[KS][NT], bf16x8 (&a)[KS][MT]) __attribute__((always_inline)) {
+            const char* sb = smem + (s & 3) * SLAB;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * TSTRIDE + coff[k]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * TSTRIDE + coff[k]);
+            }
+        };
+        auto body = [&](int k, bf16x8 (&wc)[KS][NT], bf16x8 (&ac)[KS][MT], bf16x8 (&wn_)[KS][NT], bf16x8 (&an)[KS][MT])
+                        __attribute__((always_inline)) {
+            if (k + 1 < ns) reads_to(k + 1, wn_, an);  // slab k+1: waited for + barrier at the end of interval k-1
+            const bool st = k + 3 < ns;
+            if (st) stage(k + 3);                      // slot of slab k-1: its reads completed before MFMA(k-1), two barriers ago
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[kk][nt], ac[kk][mt], acc[mt][nt], 0, 0, 0);
+            // the builtin (not an asm string): the compiler's own waitcnt pass must see that the next slab's fragments have
+            // landed here, otherwise it guards the next interval's MFMAs with lgkmcnt waits that drain that interval's fresh reads
+            __builtin_amdgcn_sched_barrier(0);   // keep the wait behind the MFMAs
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            if (k + 1 < ns) {
+                if (st) wait_vmcnt<IP>();  // slab k+2 landed, slab k+3 in flight
+                else wait_vmcnt<0>();
+                pp_barrier();
+            }
+        };
+        // Large wave tiles (one wave per SIMD, e.g. 2x2 waves of 128x128): the interval's work must be ONE interleaved stream -
+        // a burst of 16 ds_reads + 8 LDS-DMA issues in front of 32 MFMAs would leave the matrix pipe idle for hundreds of
+        // cycles - so the steady-state body pins "2 MFMA, 1 fragment read, 2 MFMA, 1 fragment read, 1 LDS-DMA" groups.
+        constexpr int RD = KS * (MT + NT);
+        constexpr bool PINNED = (G == 1) && (NM == 4 * IP) && (RD == 2 * IP);
+        auto body_pinned = [&](int k, bf16x8 (&wc)[KS][NT], bf16x8 (&ac)[KS][MT], bf16x8 (&wn_)[KS][NT], bf16x8 (&an)[KS][MT])
+                               __attribute__((always_inline)) {
+            // steady state only: slabs k+1 (read) and k+3 (staged) exist
+            const char* sb = smem + ((k + 1) & 3) * SLAB;
+            char* db = smem + ((k + 3) & 3) * SLAB;
+            const int soff = (k + 3) * RB;
+            auto rd = [&](int r) __attribute__((always_inline)) {  // fragment read r of slab k+1, k-step major
+                const int kk = r / (MT + NT), j = r % (MT + NT);
+                if (j < NT) wn_[kk][j] = *(const bf16x8*)(sb + w_row_off + j * TSTRIDE + coff[kk]);
+                else an[kk][j - NT] = *(const bf16x8*)(sb + a_row_off + (j - NT) * TSTRIDE + coff[kk]);
+            };
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const int kk = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[kk][nt], ac[kk][mt], acc[mt][nt], 0, 0, 0);
+                // all fragment reads of the next slab in the FIRST half of the MFMA stream (one per MFMA): by the end of the
+                // stream they have landed, so the lgkmcnt(0) in front of the barrier does not expose an LDS round trip
+                if (i < RD) rd(i);
+                if (i % 4 == 3)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i / 4], LDS_PTR(db + ldsoff[i / 4]), 16, voff[i / 4], soff, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < IP; ++j) {
+                if (4 * j < RD) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(ta));   // T1: MFMA stream issued
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): slab k+1's fragments are in registers
+            if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(tb));   // T2
+            wait_vmcnt<IP>();                    // slab k+2 landed, slab k+3 in flight
+            if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(tc));   // T3
+            pp_barrier();
+            if constexpr (TRACE) {  // buckets: 0 = MFMA / read / DMA stream, 2 = lgkmcnt wait, 1 = vmcnt wait, 3 = barrier
+                unsigned long long td;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td));  // T4 (the wait is the trace build's overhead)
+                tr[0] += ta - tprev; tr[2] += tb - ta; tr[1] += tc - tb; tr[3] += td - tc;
+                tprev = td;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        reads_to(0, wf, af);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (ns > 2) wait_vmcnt<IP>();  // slab 1 landed
+        else wait_vmcnt<0>();
+        pp_barrier();
+        int k = 0;
+        if constexpr (TRACE) { tprev = __builtin_amdgcn_s_memtime(); }
+        if constexpr (PINNED) {
+            for (; k + 4 < ns; k += 2) {  // both bodies of the pair are steady state: k + 1 + 3 < ns
+                body_pinned(k, wf, af, wf2, af2);
+                body_pinned(k + 1, wf2, af2, wf, af);
+            }
+        }
+        for (; k < ns; k += 2) {
+            body(k, wf, af, wf2, af2);
+            if (k + 1 < ns) body(k + 1, wf2, af2, wf, af);
+        }
+    } else {
+        auto reads = [&](int s) __attribute__((always_inline)) {
+            const char* sb = smem + (s & 3) * SLAB;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(sb + w_row_off + nt * TSTRIDE + coff[k]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(sb + a_row_off + mt * TSTRIDE + coff[k]);
+            }
+        };
+        const bool lead = __builtin_amdgcn_readfirstlane(grp == 0 ? 1 : 0) != 0;
+        auto stamp = [&](int i) __attribute__((always_inline)) {  // TRACE: cycles since the previous stamp -> bucket i
+            if constexpr (TRACE) {
+                __builtin_amdgcn_sched_barrier(0);
+                ta = __builtin_amdgcn_s_memtime();
+                tr[i] += ta - tprev;
+                tprev = ta;
+            }
+        };
+        auto sync = [&](int k, auto do_stage) __attribute__((always_inline)) {
+            if (k + 1 < ns) {
+                if constexpr (decltype(do_stage)::value) wait_vmcnt<IP>();  // slab k+2 landed, slab k+3 in flight
+                else wait_vmcnt<0>();
+                stamp(1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                stamp(2);
+                pp_barrier();
+                stamp(5);
+            }
+        };
+        if (lead) {  // MFMA(k) then READ(k+1)
+            reads(0);
+            if (ns > 2) wait_vmcnt<IP>();  // slab 1 landed
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pp_barrier();
+            auto interval = [&](int k, auto do_stage) __attribute__((always_inline)) {
+                mfma_seg(k, do_stage);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < ns) reads(k + 1);
+                stamp(0);
+                sync(k, do_stage);
+            };
+            int k = 0;
+            for (; k + 3 < ns; ++k) interval(k, std::true_type{});
+            for (; k < ns; ++k) interval(k, std::false_type{});
+        } else {     // READ(k) then MFMA(k)
+            if (ns > 2) wait_vmcnt<IP>();
+            else wait_vmcnt<0>();
+            pp_barrier();
+            auto interval = [&](int k, auto do_stage) __attribute__((always_inline)) {
+                reads(k);
+                stamp(0);
+                mfma_seg(k, do_stage);
+                __builtin_amdgcn_s_setprio(0);
+                sync(k, do_stage);
+            };
+            int k = 0;
+            for (; k + 3 < ns; ++k) interval(k, std::true_type{});
+            for (; k < ns; ++k) interval(k, std::false_type{});
+        }
+    }
+    unsigned long long t_loop_end = 0;
+    if constexpr (TRACE) t_loop_end = __builtin_amdgcn_s_memtime();
+
+    store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
+
+    if constexpr (TRACE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores acknowledged
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (p.trace && lane == 0 && (blockIdx.x & 63) == 5) {
+            unsigned long long* o = p.trace + ((size_t)(blockIdx.x >> 6) * NW + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] = tr[i];
+            o[6] = ((unsigned long long)ns << 32) | (unsigned)(tstart - t_entry);   // slabs | prologue cycles
+            o[7] = ((t_loop_end - tstart) << 20) | ((t_end - t_loop_end) & 0xfffff);  // main-loop cycles | epilogue cycles
+        }
+    }
+}
+
+// ---- persistent 4-wave kernel (EXPERIMENTAL, variant 13 - written without GPU time at the end of round 1) -----------------
+// Variant 10's steady-state body (one wave per SIMD, 128x128 per wave, LDS-DMA, fragments double-buffered in registers, one
+// barrier per slab: 83.5 % matrix-pipe duty in the s_memtime trace) loses 16 % of every tile at its two ends - a cold 3-slab
+// prologue (5.3 k ticks) and an epilogue (12.7 k) with nothing else resident on the CU (profiles/r01/gemm_trace_4wave_native.log).
+// Here one workgroup per CU walks its tiles with the slab stream running across tile boundaries, as in gemm_bf16_pp_persist:
+// the last three bodies of a tile issue the LDS-DMA of the next tile's slabs 0..2 and the last body reads the next tile's
+// first fragments, so a boundary is: epilogue stores (issued, not waited for), accumulators cleared, next body.
+//   * the epilogue stores go through a buffer descriptor over the tile's C rows (rows past M fall outside num_records, columns
+//     past N get an out-of-range offset): EVERY wave issues exactly NST store instructions per tile, so the one vmcnt literal
+//     that has to let them pass (first body after a boundary) is exact - a branchy `if (m < M)` store could issue fewer and
+//     the wait would then be too weak;
+//   * slabs are consumed in pairs (fragment register sets alternate), so K % 64 == 0; K >= 128.  No bias epilogue.
+//   * OVL (variant 14): a tile's epilogue is not a phase of its own but rides in the FIRST body of the next tile - that body's
+//     k-step-0 MFMAs take the constant 0 as accumulator input, each right after the old contents of its 32x32 accumulator tile
+//     were copied out, and the pack / store of that tile issues behind the MFMA.  Only the workgroup's last tile stores the plain way.
+template <int EPI, bool OVL = false>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmArgs p) {
+    constexpr int MT = 4, NT = 4, NW = 4, BM = 256, BN = 256, IP = 8;
+    constexpr int SLAB = (BM + BN) * 64, W_OFF = BM * 64, TSTRIDE = 2048;
+    constexpr int NM = 2 * MT * NT, RD = 2 * (MT + NT);
+    constexpr int NST = EPI == 0 ? MT * NT * 2 : MT * (NT / 2) * 2;  // 16-byte stores per wave and tile
+    static_assert(NM == 4 * IP && RD == 2 * IP, "body: one read per MFMA in the first half, one DMA per four MFMAs");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    const int ntiles = TM * TN;
+    const int ns = p.K / 32;
+
+    // staging: wave w copies pieces w + 4 i: i < 4 rows 16 w + 64 i .. of A, i >= 4 the same rows of W (tile-independent
+    // per-lane offsets; a tile only changes the descriptors)
+    const int sswz = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+    const int srow = 16 * wave + (lane >> 2);
+    int voff[IP], ldsoff[IP];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        voff[i] = (srow + 64 * i) * p.lda * 2 + sswz;
+        voff[4 + i] = (srow + 64 * i) * p.ldw * 2 + sswz;
+    }
+#pragma unroll
+    for (int i = 0; i < IP; ++i) ldsoff[i] = (wave + NW * i) * 1024;
+    const int ncols_out = EPI == 0 ? p.N : p.N / 2;
+    // a tile = its A / W / C panel pointers and the bytes left in each panel (descriptor num_records: rows past M / N read as
+    // zero, C rows past M are not written).  Plain scalars: the body picks "this tile" or "the next one" with scalar selects and
+    // builds the descriptor on the spot, so every slab of a tile runs through ONE loop body (a separate copy of the body for the
+    // last slabs made the compiler re-shuffle half of the accumulator registers between the two copies)
+    struct Tile { const u16* a; const u16* w; u16* c; int a_bytes, w_bytes, c_bytes, n0; };
+    auto setup = [&](int v) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_coords(v, ntiles, TM, TN, tm, tn);
+        const int m0 = tm * BM, n0_ = tn * BN;
+        const long long a_left = (long long)(p.M - m0) * p.lda * 2;
+        const long long w_left = (long long)(p.N - n0_) * p.ldw * 2;
+        const long long c_left = (long long)(p.M - m0) * p.ldc * 2;
+        Tile t;
+        t.a = p.A + (size_t)m0 * p.lda; t.w = p.W + (size_t)n0_ * p.ldw; t.c = p.C + (size_t)m0 * p.ldc;
+        t.a_bytes = (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left);
+        t.w_bytes = (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left);
+        t.c_bytes = (int)(c_left > 0x7fffffffLL ? 0x7fffffffLL : c_left);
+        t.n0 = n0_;
+        return t;
+    };
+    // no next tile: the last three bodies still issue their LDS-DMA (one code path) from empty descriptors - every lane is out of
+    // range, the ring slots they zero-fill hold slabs that were consumed already
+    const Tile t_null = {p.A, p.W, p.C, 0, 0, 0, 0};
+
+    const int fswz = (l31 >> 2) & 3;
+    const int a_row_off = (wm * MT * 32 + l31) * 64;
+    const int w_row_off = W_OFF + (wn * NT * 32 + l31) * 64;
+    int coff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) coff[k] = ((2 * k + hi) ^ fswz) << 4;
+
+    f32x16 acc[MT][NT];
+    bf16x8 wf[2][NT], af[2][MT], wf2[2][NT], af2[2][MT];
+
+    int v = blockIdx.x;
+    if (v >= ntiles) return;  // uniform
+    const int my_tiles = (ntiles - 1 - v) / (int)gridDim.x + 1;
+    Tile cur = setup(v);
+    bool has_next = v + (int)gridDim.x < ntiles;
+    Tile nxt = has_next ? setup(v + gridDim.x) : t_null;
+
+    auto stage_from = [&](int g, int slab_in_tile, const Tile& t) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)t.a, 0, t.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)t.w, 0, t.w_bytes, 0x00020000);
+        char* base = smem + (g & 3) * SLAB;
+        const int soff = slab_in_tile * 64;
+#pragma unroll
+        for (int i = 0; i < IP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < 4 ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, voff[i], soff, 0, 0);
+    };
+    stagger_start(p.stagger);
+    // prologue (once per workgroup): slabs 0..2 in flight, slab 0 read into the first fragment set, slab 1 landed and visible
+    stage_from(0, 0, cur);
+    stage_from(1, 1, cur);
+    stage_from(2, 2, cur);
+    wait_vmcnt<2 * IP>();
+    pp_barrier();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(smem + w_row_off + nt * TSTRIDE + coff[k]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[k][mt] = *(const bf16x8*)(smem + a_row_off + mt * TSTRIDE + coff[k]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    wait_vmcnt<IP>();
+    pp_barrier();
+
+    int g = 0;               // global slab index of the stream
+    bool after_epilogue = false;
+    // one slab: MFMAs of slab g from (wc, ac) | fragment reads of slab g+1 into (wn_, an) | LDS-DMA of the slab three ahead
+    // (slab_in_tile of the tile rA / rW describe) - the instruction mix of gemm_bf16_pp's body_pinned
+    auto body = [&](int s3, bf16x8 (&wc)[2][NT], bf16x8 (&ac)[2][MT], bf16x8 (&wn_)[2][NT], bf16x8 (&an)[2][MT]) __attribute__((always_inline)) {
+        // s3 = in-tile index of the slab three ahead; past the tile's end it is slab s3 - ns of the next tile
+        const bool own = s3 < ns;
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(own ? cur.a : nxt.a), 0, own ? cur.a_bytes : nxt.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(own ? cur.w : nxt.w), 0, own ? cur.w_bytes : nxt.w_bytes, 0x00020000);
+        const char* sb = smem + ((g + 1) & 3) * SLAB;
+        char* db = smem + ((g + 3) & 3) * SLAB;
+        const int soff = (own ? s3 : s3 - ns) * 64;
+        auto rd = [&](int r) __attribute__((always_inline)) {
+            const int kk = r / (MT + NT), j = r % (MT + NT);
+            if (j < NT) wn_[kk][j] = *(const bf16x8*)(sb + w_row_off + j * TSTRIDE + coff[kk]);
+            else an[kk][j - NT] = *(const bf16x8*)(sb + a_row_off + (j - NT) * TSTRIDE + coff[kk]);
+        };
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int kk = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
+            // OVL: every MFMA of the kernel is the in-place inline-assembly form, so that the accumulators stay in one fixed set
+            // of AGPRs through the boundary body as well (mixing it with the builtin made the allocator move them around the
+            // loop); the written order is pinned by scheduling fences instead of sched_group_barrier masks
+            if constexpr (OVL) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wc[kk][nt]), "v"(ac[kk][mt]));
+            else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[kk][nt], ac[kk][mt], acc[mt][nt], 0, 0, 0);
+            if (i < RD) rd(i);
+            if (i % 4 == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(i / 4 < 4 ? rA : rW, LDS_PTR(db + ldsoff[i / 4]), 16, voff[i / 4], soff, 0, 0);
+            if constexpr (OVL) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!OVL) {
+#pragma unroll
+            for (int j = 0; j < IP; ++j) {
+                if (4 * j < RD) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): slab g+1's fragments are in registers
+        // slab g+2 landed; still allowed in flight: this body's 8 DMAs and, right after a tile boundary, the NST stores
+        // issued between slab g+2's DMAs and them (loads and stores retire in issue order, one counter)
+        if (after_epilogue) wait_vmcnt<IP + NST>();
+        else wait_vmcnt<IP>();
+        after_epilogue = false;
+        pp_barrier();
+        ++g;
+    };
+    // epilogue through the tile's C descriptor: lane holds, per 32x32 MFMA tile, row l31 and columns 8 q + 4 hi + j (as store_tile).
+    // emit: the two 16-byte stores of output group (mt, ng) - EPI 0: accumulator tile (mt, ng) in `x`; EPI 1: silu(x) * y of the
+    // tile pair (mt, 2 ng), (mt, 2 ng + 1)
+    auto emit = [&](__amdgpu_buffer_rsrc_t rC, int n0_, int mt, int ng, const f32x16& x, const f32x16& y) __attribute__((always_inline)) {
+        const int row_off = (wm * MT * 32 + mt * 32 + l31) * p.ldc * 2;  // bytes from the tile's first C row (< 2^31: launcher)
+        const int cbase = EPI == 0 ? n0_ + wn * NT * 32 + ng * 32 : (n0_ + wn * NT * 32 + ng * 64) / 2;
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            float vv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (EPI == 0) {
+                    vv[j] = x[8 * qp + j];
+                } else {  // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
+                    const float a = bfr(x[8 * qp + j]);
+                    const float b = bfr(y[8 * qp + j]);
+                    vv[j] = bfr(silu_f(a)) * b;
+                }
+            }
+            unsigned ax = pack2bf_pk(vv[0], vv[1]), ay = pack2bf_pk(vv[2], vv[3]);
+            unsigned bx = pack2bf_pk(vv[4], vv[5]), by = pack2bf_pk(vv[6], vv[7]);
+            auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            const int col = cbase + 16 * qp + 8 * hi;
+            const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+            // columns past the end: an offset no descriptor covers (the store is issued and dropped)
+            const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(o, rC, off, 0, 0);
+        }
+    };
+    auto store_out = [&](const Tile& t) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)t.c, 0, t.c_bytes, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            constexpr int NG = EPI == 0 ? NT : NT / 2;
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) {
+                if constexpr (EPI == 0) emit(rC, t.n0, mt, ng, acc[mt][ng], acc[mt][ng]);
+                else emit(rC, t.n0, mt, ng, acc[mt][2 * ng], acc[mt][2 * ng + 1]);
+            }
+        }
+    };
+    // OVL: first body of a tile whose predecessor `done` still sits in the accumulators (see the kernel comment)
+    auto body_first = [&](const Tile& done, bf16x8 (&wc)[2][NT], bf16x8 (&ac)[2][MT], bf16x8 (&wn_)[2][NT], bf16x8 (&an)[2][MT]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)cur.a, 0, cur.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)cur.w, 0, cur.w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)done.c, 0, done.c_bytes, 0x00020000);
+        const char* sb = smem + ((g + 1) & 3) * SLAB;
+        char* db = smem + ((g + 3) & 3) * SLAB;
+        const int soff = 3 * 64;  // this tile's slab 3 (ns >= 4)
+        f32x16 keep;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep[r] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int kk = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
+            if (kk == 0) {
+                // copy-out, pinned in front of its MFMA by an empty volatile asm that wants the copy in VGPRs right here (left to
+                // itself the allocator hoisted the reads of eleven tiles to the top of the body and spilled around them)
+                f32x16 old = acc[mt][nt];
+                asm volatile("" : "+v"(old));
+                // in place ("+a": same registers in and out, although the instruction only writes them) - the builtin form let
+                // the allocator put the new tile into a different register tuple, and the loop then paid for rotating them back
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "+a"(acc[mt][nt]) : "v"(wc[0][nt]), "v"(ac[0][mt]));
+                if constexpr (EPI == 0) {
+                    emit(rC, done.n0, mt, nt, old, old);
+                } else {
+                    if ((nt & 1) == 0) keep = old;
+                    else emit(rC, done.n0, mt, nt >> 1, keep, old);
+                }
+            } else {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wc[kk][nt]), "v"(ac[kk][mt]));
+            }
+            if (i < RD) {
+                const int rk = i / (MT + NT), j = i % (MT + NT);
+                if (j < NT) wn_[rk][j] = *(const bf16x8*)(sb + w_row_off + j * TSTRIDE + coff[rk]);
+                else an[rk][j - NT] = *(const bf16x8*)(sb + a_row_off + (j - NT) * TSTRIDE + coff[rk]);
+            }
+            if (i % 4 == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(i / 4 < 4 ? rA : rW, LDS_PTR(db + ldsoff[i / 4]), 16, voff[i / 4], soff, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // one accumulator tile at a time (register budget), in this order
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        wait_vmcnt<IP + NST>();  // slab g+2 landed; younger: this body's 8 DMAs and NST stores, in whatever interleaving
+        pp_barrier();
+        ++g;
+    };
+
+    auto clear_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (has_next) {
+            cur = nxt;
+            v += gridDim.x;
+            has_next = v + (int)gridDim.x < ntiles;
+            nxt = has_next ? setup(v + gridDim.x) : t_null;
+        }
+    };
+    if constexpr (OVL) {
+        clear_acc();
+        // ONE code path for every tile (two copies of the loop made the allocator permute the accumulator tuples between them): the
+        // first tile runs the boundary body too, "storing" the cleared accumulators through the empty descriptor of t_null
+        Tile done = t_null;
+        for (int t = 0; t < my_tiles; ++t) {
+            body_first(done, wf, af, wf2, af2);
+            body(4, wf2, af2, wf, af);
+            for (int s = 2; s < ns; s += 2) {
+                body(s + 3, wf, af, wf2, af2);
+                body(s + 4, wf2, af2, wf, af);
+            }
+            done = cur;
+            advance();
+        }
+        store_out(done);  // the workgroup's last tile
+    } else {
+        for (int t = 0; t < my_tiles; ++t) {
+            clear_acc();
+            for (int s = 0; s < ns; s += 2) {  // slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
+                body(s + 3, wf, af, wf2, af2);
+                body(s + 4, wf2, af2, wf, af);
+            }
+            store_out(cur);
+            after_epilogue = true;
+            advance();
+        }
+    }
+    wait_vmcnt<0>();  // no LDS-DMA (the null ones of the last bodies included) may outlive the workgroup's LDS allocation
+}
+
+}  // namespace lt_gemm

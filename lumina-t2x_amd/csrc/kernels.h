@@ -17,6 +17,10 @@ struct GemmArgs {
     // tile_expert[tm] < 0 -> the tile is padding and the workgroup exits.  Device array of ceil(M / 256) ints.
     const int* tile_expert = nullptr;
     long long w_expert_stride = 0;
+    // epilogue 2 (V^T): C is the attention kernels' transposed, key-permuted V image [M / vt_tokens][N / vt_hd][vt_hd][vt_npad]
+    // (AttnArgs::vt) instead of a row-major matrix: the V projection lands in the layout the PV MFMA reads, no transpose pass
+    int vt_tokens = 0, vt_hd = 0, vt_npad = 0;
+    int stagger = 0;  // experiment knob of the 4-wave kernels (lt_set_option "gemm_stagger"), filled by the launcher
 };
 // ev0 / ev1: optional start / stop events carried by the dispatch packet itself (profiling without extra queue packets)
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0 = nullptr,
@@ -118,10 +122,10 @@ int launch_attention(const AttnArgs& a, hipStream_t stream);
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
-int lt_set_gemm_stagger(int v);         // 4-wave kernels (variants 10, 13, 14): start-phase spread per XCD, units of ~1024 cycles (0 = off)
-void lt_set_gemm_pp_tail(int v);        // 8-wave ping-pong kernel: 1 = tail MFMAs issued after the hand-over barrier, 0 = plain (default)
-void lt_set_gemm_persist(int v);         // 1 = persistent ping-pong kernel for multi-round SwiGLU GEMMs
-void lt_set_gemm_pipeline(int v);      // 0 = classic double-buffered loop, 1 = ping-pong wave groups
+void lt_set_gemm_swiglu_w4p(int v);    // 1 (default): dense multi-round SwiGLU GEMMs on the persistent 4-wave kernel; 0: 8-wave ping-pong
+int lt_set_gemm_stagger(int v);        // 4-wave kernels (variants 10, 13, 14): start-phase spread per XCD, units of ~1024 cycles (0 = off)
+bool lt_gemm_has_experimental();       // built with EXPERIMENTAL=1 (variants 4-6, 9-12, trace builds, pipeline knobs)
+const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant);  // name of the kernel launch_gemm_bf16 would run
 
 // ---- mixture-of-experts routing (moe.hip; Next-DiT-MoE/models/models2.py:451-506) --------------------------------
 struct MoeArgs {

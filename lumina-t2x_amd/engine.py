@@ -44,11 +44,19 @@ class _SourceCache:
     def _describe(tensors, extra):
         return (tuple((t._version, tuple(t.shape), t.dtype, t.device) for t in tensors), tuple(extra))
 
+    @staticmethod
+    def _trackable(tensors) -> bool:
+        # inference tensors (torch.inference_mode) carry no version counter: in-place edits cannot be seen, so never cache them
+        return not any(t.is_inference() for t in tensors)
+
     def hit(self, tensors, extra=()) -> bool:
-        return (self._src is not None and len(self._src) == len(tensors) and all(a is b for a, b in zip(self._src, tensors))
-                and self._key == self._describe(tensors, extra))
+        return (self._src is not None and self._trackable(tensors) and len(self._src) == len(tensors)
+                and all(a is b for a, b in zip(self._src, tensors)) and self._key == self._describe(tensors, extra))
 
     def store(self, tensors, extra=()) -> None:
+        if not self._trackable(tensors):
+            self.clear()
+            return
         self._src, self._key = tuple(tensors), self._describe(tensors, extra)
 
     def clear(self) -> None:
@@ -104,6 +112,9 @@ class DiTEngine:
     # ---- weights ---------------------------------------------------------------------------------
     def load_state_dict(self, state: Dict[str, torch.Tensor], skip: Iterable[str] = ()) -> None:
         """Upload every tensor of a reference-format state_dict into the engine."""
+        # the hoisted conditioning (text K / V of every layer, caption / label embedding) was computed from the OLD weights:
+        # forget which tensors it came from, so the next call prepares it again (lt_set_weight also invalidates it engine-side)
+        self._prompt.clear()
         s = _stream_ptr(self.device)
         skip = set(skip)
         with torch.cuda.device(self.device):

@@ -23,7 +23,8 @@ class EngineBackedModel(nn.Module):
         self._weights_sig = None
 
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # (inference tensors carry no version counter: in-place edits of such parameters are not seen - rebuild the model then)
+        return tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self.parameters())
 
     def _engine_kwargs(self) -> dict:
         raise NotImplementedError

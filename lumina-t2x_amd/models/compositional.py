@@ -69,7 +69,7 @@ class NextDiT(_base.NextDiT):
                         scale_watershed=kw.pop("scale_watershed", 1.0), base_seqlen=kw.pop("base_seqlen", None),
                         proportional_attn=kw.pop("proportional_attn", False))
         else:
-            args = dict(scale_factor=self.scale_factor, scale_watershed=0.0)
+            args = self._plain_forward_args()
         if kw:
             raise TypeError(f"unexpected model kwargs for the engine path: {sorted(kw)}")
         return eng.sample_ode(x, tgrid, method, use_cfg=use_cfg, t_round_to_state_dtype=t_round, **args)

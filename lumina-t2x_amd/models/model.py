@@ -154,7 +154,8 @@ class NextDiT(nn.Module):
 
     # ---- engine plumbing ------------------------------------------------------------------------------
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # (inference tensors carry no version counter: in-place edits of such parameters are not seen - rebuild the model then)
+        return tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self.parameters())
 
     def engine(self, x: torch.Tensor, text_len: int) -> DiTEngine:
         """Create / resize the engine for this call's shapes and make sure it holds the current weights."""
@@ -199,12 +200,17 @@ class NextDiT(nn.Module):
     def forward(self, x, t, cap_feats, cap_mask):
         """reference model.py:836-864; ``x`` is a [B, C, H, W] tensor or a list of [C, H_b, W_b] tensors of different sizes
         (returns a list then)"""
+        return self._call(x, t, cap_feats, cap_mask, False, **self._plain_forward_args())
+
+    def _plain_forward_args(self) -> dict:
+        """what the reference's plain ``forward`` reads off the module (model.py:836-864): the attention flags left on the
+        layers by the last forward_with_cfg (:891-899), and the RoPE table left in self.freqs_cis - after construction
+        that is the NTK branch at the constructor's scale_factor (:732-736) -> watershed 0 selects it for any t.  (The
+        reference also re-uses a table rebuilt by a forward_with_cfg with OTHER scaling arguments; the engine keeps the
+        constructor's - documented difference, the reference's samplers never mix the two on one module.)"""
         pa = self.layers[0].attention.proportional_attn if self.n_layers else False
         bs = self.layers[0].attention.base_seqlen if self.n_layers else None
-        # the reference's plain forward uses the table left in self.freqs_cis; after construction that is the
-        # NTK branch at the constructor's scale_factor (model.py:732-736) -> watershed 0 selects it for any t
-        return self._call(x, t, cap_feats, cap_mask, False, scale_factor=self.scale_factor, scale_watershed=0.0,
-                          proportional_attn=pa, base_seqlen=bs)
+        return dict(scale_factor=self.scale_factor, scale_watershed=0.0, proportional_attn=pa, base_seqlen=bs)
 
     @torch.no_grad()
     def forward_with_cfg(self, x, t, cap_feats, cap_mask, cfg_scale, scale_factor=1.0, scale_watershed=1.0,
@@ -226,7 +232,7 @@ class NextDiT(nn.Module):
                         scale_watershed=kw.pop("scale_watershed", 1.0), base_seqlen=kw.pop("base_seqlen", None),
                         proportional_attn=kw.pop("proportional_attn", False))
         else:
-            args = dict(scale_factor=self.scale_factor, scale_watershed=0.0)
+            args = self._plain_forward_args()  # the same module state a per-step forward() would read
         if kw:
             raise TypeError(f"unexpected model kwargs for the engine path: {sorted(kw)}")
         eng = self.engine(x, cap_feats.shape[1])

@@ -1,6 +1,14 @@
-"""Next-DiT with time + space mixture-of-experts FFNs behind the reference's construction / checkpoint / call API.
+"""Next-DiT with mixture-of-experts FFNs behind the reference's construction / checkpoint / call API.
 
-Source compatibility target: ``Next-DiT-MoE/models/models2.py`` (``DiT_Llama_600M_patch2_Both``, BASELINE configs[4]):
+The reference package ``Next-DiT-MoE/models`` exports three model files (``models/__init__.py:1-3``):
+  ``models.py``   ``DiT_Llama_600M_patch2`` ...  ONE MoE FFN per block routed by the TIMESTEP embedding (8 experts; the "TimeMoE"
+                  whose FID the sub-project publishes, README.md:34-37)              -> ``DiT_Llama_TimeMoE`` here
+  ``models1.py``  ``DiT_Llama_600M_patch2_Spatial``  ONE MoE FFN per block routed per TOKEN (8 experts)  -> ``DiT_Llama_SpaceMoE``
+  ``models2.py``  ``DiT_Llama_600M_patch2_Both``  time MoE + space MoE per block (4 + 4 experts)        -> ``DiT_Llama``
+(the three files each call their class ``DiT_Llama``; a script that does ``models.__dict__[name]`` finds the builders below
+under the reference's builder names).
+
+Source compatibility target of ``DiT_Llama``: ``Next-DiT-MoE/models/models2.py`` (``DiT_Llama_600M_patch2_Both``, BASELINE configs[4]):
 same constructor / ``forward(x, t, y)`` / ``forward_with_cfg(x, t, y, cfg_scale, rope_scaling_factor, ntk_factor)`` as the
 ImageNet model, blocks with three residual branches (attention, TimeMoeLayer, SpaceMoeLayer; models2.py:692-820).
 Parameters only; the forward runs on the HIP engine (variant ``LT_VARIANT_NEXT_MOE``: device-side top-2 routing,
@@ -70,6 +78,84 @@ class DiT_Llama(_ImageNetDiT):
         kw = super()._engine_kwargs()
         kw["num_experts"] = self.num_experts
         return kw
+
+
+class TransformerBlockSandwichNorm2Single(nn.Module):
+    """reference models.py / models1.py:662-740 (num_experts > 0 branch): the ImageNet block with ``feed_forward`` = one MoeLayer"""
+
+    def __init__(self, layer_id, dim, n_heads, n_kv_heads, multiple_of, ffn_dim_multiplier, norm_eps, qk_norm, gate_in: int,
+                 num_experts: int = 8, num_experts_per_tok: int = 2):
+        super().__init__()
+        assert num_experts > 0 and num_experts_per_tok == 2, "the engine routes top-2 of 2..8 experts"
+        self.dim, self.head_dim, self.layer_id, self.num_experts = dim, dim // n_heads, layer_id, num_experts
+        hidden = ffn_hidden_dim(dim, multiple_of, ffn_dim_multiplier)
+        self.attention = Attention(dim, n_heads, n_kv_heads, qk_norm)
+        self.feed_forward = MoeLayer(dim, hidden, gate_in, num_experts, num_experts_per_tok)
+        self.attention_norm = RMSNorm(dim, eps=norm_eps)
+        self.ffn_norm = RMSNorm(dim, eps=norm_eps)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), Linear(min(dim, 1024), 4 * dim, bias=True, init=nn.init.zeros_))
+
+
+class _SingleMoE(_ImageNetDiT):
+    _time_routed = True
+    num_experts_default = 8  # models.py:666 / models1.py:666
+
+    def __init__(self, input_size: int = 32, patch_size: int = 2, in_channels: int = 4, dim: int = 4096, n_layers: int = 32,
+                 n_heads: int = 32, n_kv_heads: Optional[int] = None, multiple_of: int = 256,
+                 ffn_dim_multiplier: Optional[float] = None, norm_eps: float = 1e-5, class_dropout_prob: float = 0.1,
+                 num_classes: int = 1000, learn_sigma: bool = True, qk_norm: bool = False) -> None:
+        super().__init__(input_size, patch_size, in_channels, dim, 0, n_heads, n_kv_heads, multiple_of, ffn_dim_multiplier,
+                         norm_eps, class_dropout_prob, num_classes, learn_sigma, qk_norm)
+        self.n_layers = n_layers
+        self.num_experts = self.num_experts_default
+        gate_in = min(dim, 1024) if self._time_routed else dim
+        self.layers = nn.ModuleList([
+            TransformerBlockSandwichNorm2Single(i, dim, n_heads, n_kv_heads, multiple_of, ffn_dim_multiplier, norm_eps, qk_norm,
+                                                gate_in, self.num_experts)
+            for i in range(n_layers)])
+
+    def _engine_kwargs(self) -> dict:
+        kw = super()._engine_kwargs()
+        kw["num_experts"] = self.num_experts
+        return kw
+
+
+class DiT_Llama_TimeMoE(_SingleMoE):
+    """``Next-DiT-MoE/models/models.py`` DiT_Llama: gate(t_embedder(t)) picks the same two experts for every token of a sample
+    (models.py:459-477) - engine variant ``LT_VARIANT_NEXT_MOE_TIME``"""
+    _variant = _lib.LT_VARIANT_NEXT_MOE_TIME
+    _time_routed = True
+
+
+class DiT_Llama_SpaceMoE(_SingleMoE):
+    """``Next-DiT-MoE/models/models1.py`` DiT_Llama: per-token top-2 routing - engine variant ``LT_VARIANT_NEXT_MOE_SPACE``"""
+    _variant = _lib.LT_VARIANT_NEXT_MOE_SPACE
+    _time_routed = False
+
+
+def DiT_Llama_600M_patch2(**kwargs):
+    """reference models.py:1015-1018 (Next-DiT-TimeMoE 600M, README.md:34-37)"""
+    return DiT_Llama_TimeMoE(patch_size=2, dim=1536, n_layers=16, n_heads=32, **kwargs)
+
+
+def DiT_Llama_2B_patch2(**kwargs):
+    """reference models.py:1027-1030"""
+    return DiT_Llama_TimeMoE(patch_size=2, dim=2304, n_layers=24, n_heads=32, **kwargs)
+
+
+def DiT_Llama_3B_patch2(**kwargs):
+    """reference models.py:1033-1036"""
+    return DiT_Llama_TimeMoE(patch_size=2, dim=3072, n_layers=32, n_heads=32, **kwargs)
+
+
+def DiT_Llama_7B_patch2(**kwargs):
+    """reference models.py:1039-1042"""
+    return DiT_Llama_TimeMoE(patch_size=2, dim=4096, n_layers=32, n_heads=32, **kwargs)
+
+
+def DiT_Llama_600M_patch2_Spatial(**kwargs):
+    """reference models1.py:1015-1018"""
+    return DiT_Llama_SpaceMoE(patch_size=2, dim=1536, n_layers=16, n_heads=32, **kwargs)
 
 
 def DiT_Llama_600M_patch2_Both(**kwargs):

@@ -247,6 +247,7 @@ def family_case(name, cfg, latent_hw, seed_w, seed_x, text_len=16, uncond_len=8)
     sd = synth.synth_state_dict(cfg, seed=seed_w)
     ins = synth.synth_inputs(cfg, latent_hw=latent_hw, text_len=text_len, uncond_len=uncond_len, seed=seed_x)
     pkg, module = {"imagenet": ("Next-DiT-ImageNet", "models.models"), "moe": ("Next-DiT-MoE", "models.models2"),
+                   "moe_time": ("Next-DiT-MoE", "models.models"), "moe_space": ("Next-DiT-MoE", "models.models1"),
                    "flag_t2i": ("lumina_t2i", "models.model")}[cfg.family]
     mod = _fresh_import(pkg, module)
     kw = cfg.ctor_kwargs()
@@ -321,6 +322,8 @@ def main():
     model_case("nextdit_tiny_gqa", synth.TINY_GQA, "lumina_next_t2i_mini", (16, 16), 16, 8, 5, 6)
     family_case("imagenet_tiny", synth.TINY_IMAGENET, (16, 16), 7, 8)
     family_case("moe_tiny", synth.TINY_MOE, (16, 16), 9, 10)
+    family_case("moe_time_tiny", synth.TINY_MOE_TIME, (16, 16), 19, 20)
+    family_case("moe_space_tiny", synth.TINY_MOE_SPACE, (16, 16), 23, 24)
     family_case("flag_tiny", synth.TINY_FLAG, (16, 24), 11, 12)
     mini_ode_kats()
     transport_kats()

@@ -29,6 +29,8 @@ class NextDiTConfig:
     #   "imagenet"  Next-DiT-ImageNet/models/models.py DiT_Llama       (class-conditional Next-DiT, BASELINE configs[0])
     #   "flag_t2i"  lumina_t2i/models/model.py DiT_Llama               (Flag-DiT, BASELINE configs[2])
     #   "moe"       Next-DiT-MoE/models/models2.py DiT_Llama           (time + space MoE, BASELINE configs[4])
+    #   "moe_time"  Next-DiT-MoE/models/models.py  DiT_Llama           (one time-routed MoE FFN per block; 8 experts)
+    #   "moe_space" Next-DiT-MoE/models/models1.py DiT_Llama           (one token-routed MoE FFN per block; 8 experts)
     family: str = "next_t2i"
     num_classes: int = 1000
     num_experts: int = 4
@@ -36,7 +38,7 @@ class NextDiTConfig:
 
     @property
     def chunks(self) -> int:
-        return {"next_t2i": 4, "imagenet": 4, "flag_t2i": 6, "moe": 6}[self.family]
+        return {"next_t2i": 4, "imagenet": 4, "flag_t2i": 6, "moe": 6, "moe_time": 4, "moe_space": 4}[self.family]
 
     @property
     def has_text(self) -> bool:
@@ -84,6 +86,8 @@ IMAGENET_600M = NextDiTConfig(dim=1536, n_layers=16, n_heads=32, family="imagene
 TINY_FLAG = NextDiTConfig(dim=768, n_layers=2, n_heads=8, cap_feat_dim=128, family="flag_t2i")    # hd 96
 FLAG_5B = NextDiTConfig(dim=3072, n_layers=32, n_heads=32, cap_feat_dim=4096, family="flag_t2i")  # BASELINE cfg 3
 TINY_MOE = NextDiTConfig(dim=384, n_layers=2, n_heads=8, family="moe", num_classes=10)            # hd 48
+TINY_MOE_TIME = NextDiTConfig(dim=384, n_layers=2, n_heads=8, family="moe_time", num_classes=10, num_experts=8)
+TINY_MOE_SPACE = NextDiTConfig(dim=384, n_layers=2, n_heads=8, family="moe_space", num_classes=10, num_experts=8)
 
 
 def _state_shapes_next_t2i(cfg: NextDiTConfig) -> Dict[str, tuple]:
@@ -166,7 +170,13 @@ def state_shapes(cfg: NextDiTConfig) -> Dict[str, tuple]:
             for nm, w in norms:
                 s[p + f"attention.{nm}.weight"] = (w,)
                 s[p + f"attention.{nm}.bias"] = (w,)
-        if fam == "moe":
+        if fam in ("moe_time", "moe_space"):
+            s[p + "feed_forward.gate.weight"] = (cfg.num_experts, A if fam == "moe_time" else d)
+            for e in range(cfg.num_experts):
+                s[p + f"feed_forward.experts.{e}.w1.weight"] = (F, d)
+                s[p + f"feed_forward.experts.{e}.w2.weight"] = (d, F)
+                s[p + f"feed_forward.experts.{e}.w3.weight"] = (F, d)
+        elif fam == "moe":
             for br, gate_in in (("feed_forward_time", A), ("feed_forward_space", d)):
                 s[p + br + ".gate.weight"] = (cfg.num_experts, gate_in)
                 for e in range(cfg.num_experts):
@@ -180,7 +190,8 @@ def state_shapes(cfg: NextDiTConfig) -> Dict[str, tuple]:
         norm_names = {"next_t2i": ("attention_norm1", "attention_norm2", "ffn_norm1", "ffn_norm2"),
                       "imagenet": ("attention_norm", "ffn_norm"),   # the *_norm1 pre-norms are weight-free (PFRMSNorm)
                       "flag_t2i": ("attention_norm", "ffn_norm"),
-                      "moe": ("attention_norm", "ffn_norm_time", "ffn_norm_space")}[fam]
+                      "moe": ("attention_norm", "ffn_norm_time", "ffn_norm_space"),
+                      "moe_time": ("attention_norm", "ffn_norm"), "moe_space": ("attention_norm", "ffn_norm")}[fam]
         for nm in norm_names:
             s[p + nm + ".weight"] = (d,)
         s[p + "adaLN_modulation.1.weight"] = (cfg.chunks * d, A)
@@ -188,25 +199,45 @@ def state_shapes(cfg: NextDiTConfig) -> Dict[str, tuple]:
     return s
 
 
-def synth_state_dict(cfg: NextDiTConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+def _draw(rng, key: str, shape) -> np.ndarray:
+    if key.endswith("attention.gate"):
+        return rng.standard_normal(shape, dtype=np.float32) * 0.5
+    if key.endswith(".gate.weight"):  # MoE routers: spread the logits so top-2 choices differ per token / sample
+        return rng.standard_normal(shape, dtype=np.float32) * (4.0 / np.sqrt(shape[-1]))
+    if len(shape) == 1 and key.endswith(".weight"):  # every 1-D weight is a norm weight
+        return 1.0 + rng.standard_normal(shape, dtype=np.float32) * 0.02
+    if len(shape) == 1:  # biases, pad_token
+        return rng.standard_normal(shape, dtype=np.float32) * 0.02
+    return rng.standard_normal(shape, dtype=np.float32) * min(0.06, 1.0 / np.sqrt(shape[-1]))
+
+
+def synth_state_dict(cfg: NextDiTConfig, seed: int = 0, dtype=torch.float32, streams: bool = False) -> Dict[str, torch.Tensor]:
     """SURVEY.md 8d recipe: matrices ~ N(0, s^2) with s = min(0.02 * 3, 1/sqrt(fan_in)) so activations stay O(1)
     through deep stacks, norm weights 1 + N(0, 0.02^2), biases N(0, 0.02^2), attention.gate ~ N(0, 0.5^2).
     (The reference zero-initialises adaLN / final / cap-embedder / gate - model.py:567,643,652,709,201 - which
-    would make every block an identity and parity vacuous.)"""
-    rng = np.random.default_rng(seed)
+    would make every block an identity and parity vacuous.)
+    streams=False: ONE PCG64 stream consumed in key order (what the seed-only fixtures of tests/golden/*_tiny.npz rely on).
+    streams=True: one child stream per key (SeedSequence(seed).spawn), drawn by a thread pool - the multi-billion-parameter
+    draws of the full-depth fixtures (tests/golden/full_*.npz) take minutes on one core; same values on any core count."""
+    shapes = state_shapes(cfg)
     out: Dict[str, torch.Tensor] = {}
-    for key, shape in state_shapes(cfg).items():
-        if key.endswith("attention.gate"):
-            a = rng.standard_normal(shape, dtype=np.float32) * 0.5
-        elif key.endswith(".gate.weight"):  # MoE routers: spread the logits so top-2 choices differ per token / sample
-            a = rng.standard_normal(shape, dtype=np.float32) * (4.0 / np.sqrt(shape[-1]))
-        elif len(shape) == 1 and key.endswith(".weight"):  # every 1-D weight is a norm weight
-            a = 1.0 + rng.standard_normal(shape, dtype=np.float32) * 0.02
-        elif len(shape) == 1:  # biases, pad_token
-            a = rng.standard_normal(shape, dtype=np.float32) * 0.02
-        else:
-            a = rng.standard_normal(shape, dtype=np.float32) * min(0.06, 1.0 / np.sqrt(shape[-1]))
-        out[key] = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    if not streams:
+        rng = np.random.default_rng(seed)
+        for key, shape in shapes.items():
+            out[key] = torch.from_numpy(np.ascontiguousarray(_draw(rng, key, shape))).to(dtype)
+        return out
+    import concurrent.futures as cf
+    import os
+    keys = list(shapes)
+    children = np.random.SeedSequence(seed).spawn(len(keys))
+
+    def one(i):
+        a = _draw(np.random.default_rng(children[i]), keys[i], shapes[keys[i]])
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+
+    with cf.ThreadPoolExecutor(max(1, min(48, os.cpu_count() or 1))) as ex:  # numpy releases the GIL while it draws
+        for key, t in zip(keys, ex.map(one, range(len(keys)))):
+            out[key] = t
     return out
 
 

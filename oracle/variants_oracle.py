@@ -137,6 +137,12 @@ def imagenet_block(sd, i, cfg: NextDiTConfig, x, freqs_cis, adaln_input, time_in
     if cfg.family == "imagenet":
         f = feed_forward(sd, p + "feed_forward.", mod1(pf_rmsnorm(h, eps, bf16), ch[2]), bf16)
         return gated(h, ch[3], f, "ffn_norm.weight")
+    if cfg.family == "moe_time":   # Next-DiT-MoE/models/models.py:755-758: `feed_forward` is ONE time-routed MoeLayer
+        f = moe_time(sd, p + "feed_forward.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[2]), time_input, bf16)
+        return gated(h, ch[3], f, "ffn_norm.weight")
+    if cfg.family == "moe_space":  # Next-DiT-MoE/models/models1.py:755-758: ONE token-routed MoeLayer
+        f = moe_space(sd, p + "feed_forward.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[2]), bf16)
+        return gated(h, ch[3], f, "ffn_norm.weight")
     ft = moe_time(sd, p + "feed_forward_time.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[2]), time_input, bf16)
     h = gated(h, ch[3], ft, "ffn_norm_time.weight")
     fs = moe_space(sd, p + "feed_forward_space.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[4]), bf16)

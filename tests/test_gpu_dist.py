@@ -1,0 +1,75 @@
+"""-m gpu: the N > 1 sampling path over RCCL (backend "nccl") - runs when the box exposes >= 2 GPUs, skips otherwise (the
+authoring leases are single-GPU; the CPU twin of this test is tests/test_dist_gloo.py, world size 2 over gloo).
+
+1. parallel.broadcast_prompts / gather_latents / max_over_ranks across 2 ranks, one per GPU;
+2. `python bench.py --gpus 2` exactly as the driver invokes it for N = 1 (no torchrun, no WORLD_SIZE in the environment): bench.py
+   must launch its own ranks and rank 0 must print one JSON line with n_gpus = 2."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import lumina_t2x_amd  # noqa: F401
+from lumina_t2x_amd import parallel
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+needs2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL over xGMI)")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r, w, local = parallel.init_distributed("nccl")
+    dev = torch.device("cuda", local)
+    n_img, T, C = 5, 16, 64
+    feats = mask = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(3)
+        feats = torch.randn(n_img, 2, T, C, generator=g).to(dev, torch.bfloat16)
+        mask = (torch.rand(n_img, 2, T, generator=g) > 0.3).int().to(dev)
+    feats, mask = parallel.broadcast_prompts(feats, mask, src=0, device=dev)
+    g = torch.Generator().manual_seed(3)
+    want = torch.randn(n_img, 2, T, C, generator=g).to(torch.bfloat16)
+    assert feats.device == dev and torch.equal(feats.cpu(), want) and mask.dtype == torch.int32
+    mine = parallel.shard_range(n_img, rank, world)
+    local_lat = torch.stack([feats[i, 0].float().mean().expand(4, 2, 2) + i for i in mine]) if len(mine) else torch.zeros(0, 4, 2, 2, device=dev)
+    full = parallel.gather_latents(local_lat, n_img, dst=0)
+    assert parallel.max_over_ranks(1.0 + rank, dev) == float(world)
+    parallel.barrier()
+    if rank == 0:
+        expect = torch.stack([want[i, 0].float().mean().expand(4, 2, 2) + i for i in range(n_img)])
+        assert torch.allclose(full.cpu(), expect)
+        open(os.path.join(out_dir, "ok"), "w").write("1")
+    torch.distributed.destroy_process_group()
+
+
+@needs2
+def test_two_rank_prompt_broadcast_and_gather_over_rccl(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+@needs2
+def test_bench_launches_its_own_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0

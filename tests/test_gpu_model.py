@@ -240,29 +240,6 @@ def test_cfg4_2048px_gqa_ntk_one_layer_vs_oracle():
     assert rel_l2(got_lo, want_lo) < TOL_CFG4, rel_l2(got_lo, want_lo)
 
 
-@pytest.mark.skipif(os.environ.get("LUMINA_SLOW_TESTS") != "1", reason="~2 min of CPU oracle time; set LUMINA_SLOW_TESTS=1")
-def test_full_2b_24_layers_vs_oracle():
-    """The complete BASELINE configs[1] model: NextDiT_2B_patch2, 24 layers, 1024^2 (4096 tokens), T = 128, CFG 4,
-    proportional attention - one forward_with_cfg against the fp32 oracle, gated at 1.5 x the reference's own bf16
-    noise floor on this weight draw (oracle with the reference's bf16 rounding points vs its fp32 self)."""
-    cfg = synth.NEXT_2B
-    sd = synth.synth_state_dict(cfg, seed=61)
-    z, t, cap, mask = synth.synth_inputs(cfg, latent_hw=(128, 128), text_len=128, uncond_len=8, seed=62)
-    model = models.NextDiT_2B_patch2(qk_norm=True, cap_feat_dim=2048)
-    model.load_state_dict(sd, strict=True)
-    model = model.eval().to("cuda", torch.bfloat16)
-    zb, capb = z.to("cuda", torch.bfloat16), cap.to("cuda", torch.bfloat16)
-    kw = dict(base_seqlen=4096, proportional_attn=True)
-    got = model.forward_with_cfg(zb, t.cuda(), capb, mask.cuda(), 4.0, **kw).float().cpu()
-    want = O.forward_with_cfg(sd, cfg, zb.float().cpu(), t, capb.float().cpu(), mask, 4.0, **kw)
-    floor = O.forward_with_cfg(sd, cfg, zb.float().cpu(), t, capb.float().cpu(), mask, 4.0, bf16=True, **kw)
-    f_all, f_c3 = rel_l2(floor, want), rel_l2(floor[:, 3], want[:, 3])
-    e_all, e_c3, e_floor = rel_l2(got, want), rel_l2(got[:, 3], want[:, 3]), rel_l2(got, floor)
-    print(f"2B/24L: engine vs fp32 {e_all:.3e} (ch3 {e_c3:.3e}); bf16-choreography oracle vs fp32 {f_all:.3e} (ch3 {f_c3:.3e}); "
-          f"engine vs bf16 oracle {e_floor:.3e}")
-    assert e_all < 1.5 * f_all and e_c3 < 1.5 * f_c3, (e_all, f_all, e_c3, f_c3)
-
-
 def test_sample_driver_end_to_end_with_injected_encoder(golden_dir, tmp_path):
     """lumina_t2x_amd.sample.run (reference sample.py:85-265 flow) on the engine: checkpoint directory -> model ->
     per-caption CFG sampling -> output files.  The third-party stages (text encoder, VAE) are injected; the latent the
@@ -318,9 +295,6 @@ def test_sample_driver_end_to_end_with_injected_encoder(golden_dir, tmp_path):
     assert torch.equal(decoded[0], want / 0.13025)
 
 
-@pytest.mark.skipif(os.environ.get("LUMINA_EXPERIMENTAL") != "1",
-                    reason="written after the last GPU minute of round 1 (the CPU half of the CLI is covered by tests/test_host_logic.py); "
-                           "scripts/gpu_round2_first.sh runs it, then the gate goes")
 def test_lumina_next_cli_infer_with_injected_encoder(golden_dir, tmp_path):
     """lumina_t2x_amd.cli.infer (reference utils/cli.py:161-333 flow): yaml settings -> sampler + model kwargs -> one CFG solve
     on the engine -> decoded file named after the caption.  The latent handed to the (injected) VAE must equal a direct Sampler

@@ -21,7 +21,23 @@ def _default_kernel_variants():
     yield
     set_option("attention_variant", 3)
     set_option("gemm_variant", 0)
-    set_option("gemm_pipeline", 0)
+
+
+def _experimental_build():
+    return b"+experimental" in lib().lt_version()
+
+
+PRODUCT_VARIANTS = [1, 2, 3, 7, 8]
+EXPERIMENTAL_VARIANTS = [4, 5, 6, 9, 10, 11]  # round-1 study kernels (csrc/experimental/, `make EXPERIMENTAL=1`)
+
+
+def _variant_params():
+    return PRODUCT_VARIANTS + [pytest.param(v, marks=pytest.mark.experimental) for v in EXPERIMENTAL_VARIANTS]
+
+
+def _skip_unless_built(variant):
+    if variant in EXPERIMENTAL_VARIANTS + [12] and not _experimental_build():
+        pytest.skip(f"gemm variant {variant} lives in csrc/experimental/ (library built without EXPERIMENTAL=1)")
 
 
 def _gemm(A, W, bias=None, epilogue=0, variant=0):
@@ -46,12 +62,13 @@ def test_gemm_plain(M, N, K):
     assert max_abs(out, ref) < 0.04 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", _variant_params())
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 2304), (300, 576, 128), (1024, 6912, 2304), (256, 288, 64), (257, 296, 192),
                                    (512, 512, 6144)])
 def test_gemm_tile_variants(variant, M, N, K):
-    """both tile shapes (256x256 / 8 waves, 256x288 / 12 waves) x both pipelines (classic double buffer, ping-pong wave
-    groups = variants 3 / 4) on tile-multiple and ragged problems; K = 64 ... 6144 covers 2 ... 192 ring slabs"""
+    """both tile shapes (256x256 / 8 waves, 256x288 / 12 waves), the 8-wave ping-pong loop (3) and the small-M tiles (7 / 8) on
+    tile-multiple and ragged problems; K = 64 ... 6144 covers 2 ... 192 ring slabs.  (4-6, 9-11: experimental builds only)"""
+    _skip_unless_built(variant)
     if variant == 9 and K < 96:
         pytest.skip("the persistent kernel carries a 3-slab prefetch across tiles: K >= 96")
     g = torch.Generator(device="cpu").manual_seed(M + N + K + variant)
@@ -64,9 +81,10 @@ def test_gemm_tile_variants(variant, M, N, K):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", _variant_params() + [13, 14])
 def test_gemm_identity_asymmetric(variant):
     """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
+    _skip_unless_built(variant)
     K, N = 320, 576
     A = bf(torch.eye(320, K))
     W = bf((torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 64.0)
@@ -89,29 +107,32 @@ def test_gemm_bias_and_edges():
     assert torch.all(big[200:] == 7.0)
 
 
-@pytest.mark.parametrize("pipeline", [1, 2, 3])  # 1 = ping-pong wave groups, 2 = classic loop, 3 = single-barrier rendezvous
-@pytest.mark.parametrize("M,F_,K", [(256, 128, 64), (300, 1536, 576), (4096, 6144, 2304)])
-def test_gemm_swiglu(M, F_, K, pipeline):
-    set_option("gemm_pipeline", pipeline)
+@pytest.mark.parametrize("variant", [0, 1, 3, 7, 14])  # auto, classic loop, 8-wave ping-pong, small tiles, persistent 4 waves
+@pytest.mark.parametrize("M,F_,K", [(256, 128, 64), (300, 1536, 576), (4096, 6144, 2304), (8192, 6144, 2304)])
+def test_gemm_swiglu(M, F_, K, variant):
+    if variant == 14 and K < 128:
+        pytest.skip("persistent 4-wave kernel: K >= 128")
     g = torch.Generator().manual_seed(F_ + K)
     A = bf(torch.randn(M, K, generator=g))
     w1 = bf(torch.randn(F_, K, generator=g) / math.sqrt(K))
     w3 = bf(torch.randn(F_, K, generator=g) / math.sqrt(K))
     packed = torch.empty(2 * F_, K, device="cuda", dtype=torch.bfloat16)
     ok(lib().lt_op_pack_w13(P(w1), P(w3), P(packed), F_, K, stream()))
-    out = _gemm(A, packed, None, 1)
+    out = _gemm(A, packed, None, 1, variant=variant)
     a = r16(A.float() @ w1.float().t())
     b = r16(A.float() @ w3.float().t())
     ref = r16(r16(F.silu(a)) * b)
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("M,N,K,epi", [(8192, 12288, 2304, 1), (8300, 6912, 2304, 0), (2100, 1280, 128, 1), (16384, 2304, 6144, 0)])
 def test_gemm_persistent_pingpong(M, N, K, epi):
     """persistent ping-pong kernel (variant 9): several 256x256 tiles per workgroup with the LDS ring, the DMA prefetch and the
     vmcnt bookkeeping carried across tile boundaries (stores of the previous tile's epilogue in flight); uneven tile counts
     per workgroup, ragged M / N edges, a K of only 4 slabs, both epilogues - against the classic kernel bit for bit
     (same MFMA order) and against fp32."""
+    _skip_unless_built(9)
     g = torch.Generator().manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g))
     W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
@@ -122,36 +143,25 @@ def test_gemm_persistent_pingpong(M, N, K, epi):
     assert torch.equal(_gemm(A, W, None, epi, variant=11), ref)  # ping-pong with AGPR accumulators
     if epi == 0:
         assert rel_l2(out, A.float() @ W.float().t()) < 4e-3
-    # and through the process-wide switch the engine uses
-    set_option("gemm_persist", 1)
-    try:
-        assert torch.equal(_gemm(A, W, None, epi), ref)
-    finally:
-        set_option("gemm_persist", 0)
 
 
-@pytest.mark.skipif(os.environ.get("LUMINA_EXPERIMENTAL") != "1",
-                    reason="variant 12 (4 waves, VGPR-staged): ran once on hardware at the very end of round 1 (6 / 6 bit-identical, "
-                           "profiles/r01/opbench_gemm_vgpr_staged.log); kept out of the default suite until it has seen a full run")
+@pytest.mark.experimental
 @pytest.mark.parametrize("M,N,K,epi", [(8192, 12288, 2304, 1), (8300, 6912, 2304, 0), (2100, 1280, 128, 1), (512, 512, 64, 0),
                                        (300, 576, 192, 0), (16384, 2304, 6144, 0)])
 def test_gemm_experimental_4wave_vgpr_staged(M, N, K, epi):
-    """gemm_bf16_w4s (DESIGN.md 5.1, next-round item): same MFMA order as every other kernel -> bit-identical to variant 1"""
+    """gemm_bf16_w4s (DESIGN.md 5.1): same MFMA order as every other kernel -> bit-identical to variant 1"""
+    _skip_unless_built(12)
     g = torch.Generator().manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g))
     W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     assert torch.equal(_gemm(A, W, None, epi, variant=12), _gemm(A, W, None, epi, variant=1))
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("LUMINA_EXPERIMENTAL") != "1",
-                    reason="variant 13 (persistent 4 waves) was written after the last GPU minute of round 1: compiled and ISA-checked, "
-                           "not yet run on hardware (scripts/gpu_round2_first.sh runs it)")
 @pytest.mark.parametrize("M,N,K,epi", [(8192, 12288, 2304, 1), (8300, 6912, 2304, 0), (2100, 1280, 128, 1), (512, 512, 128, 0),
                                        (300, 576, 192, 0), (16384, 2304, 6144, 0), (70000, 520, 256, 0), (256, 131072, 128, 1)])
 @pytest.mark.parametrize("variant", [13, 14])
-def test_gemm_experimental_4wave_persistent(M, N, K, epi, variant):
-    """gemm_bf16_w4p: one workgroup per CU walks its tiles, slab stream and LDS ring carried across tile boundaries; same MFMA
+def test_gemm_4wave_persistent(M, N, K, epi, variant):
+    """gemm_bf16_w4p (the engine's SwiGLU kernel = variant 14 with epilogue 1): one workgroup per CU walks its tiles, slab stream and LDS ring carried across tile boundaries; same MFMA
     order as every other kernel -> bit-identical to variant 1.  Shapes: 6 tiles per CU, ragged M, one tile per workgroup and
     fewer tiles than CUs, K = 128 (every body is a boundary body), more than two tiles per CU with ragged edges both ways.
     Variant 14 stores a tile from inside the next tile's first body (in-place C = 0 MFMAs behind explicit accumulator copy-outs)."""
@@ -163,9 +173,32 @@ def test_gemm_experimental_4wave_persistent(M, N, K, epi, variant):
     if M == 8300:  # and with the workgroups' start phases spread (experiment knob of the 4-wave kernels)
         set_option("gemm_stagger", 2)
         try:
-            assert torch.equal(_gemm(A, W, None, epi, variant=variant), ref) and torch.equal(_gemm(A, W, None, epi, variant=10), ref)
+            assert torch.equal(_gemm(A, W, None, epi, variant=variant), ref)
         finally:
             set_option("gemm_stagger", 0)
+
+
+@pytest.mark.parametrize("tokens,B,kvh,hd,K,variant", [(4096, 2, 32, 72, 2304, 0), (64, 3, 2, 72, 128, 1), (128, 2, 8, 72, 576, 2),
+                                                       (4160, 2, 32, 96, 3072, 0), (1024, 2, 32, 48, 1536, 0), (64, 1, 4, 72, 64, 2)])
+def test_gemm_vt_epilogue_matches_gemm_plus_transpose(tokens, B, kvh, hd, K, variant):
+    """epilogue 2: the V projection written straight into the attention kernels' transposed, key-permuted V image
+    [B, kv heads, hd, tokens] must equal (bit for bit: same products in the same order, one bf16 rounding) the plain GEMM
+    followed by lt_op_v_transpose - on both tile shapes, ragged N (288-wide tiles over N = 2304 / 576 / 3072), a ragged last
+    row tile (M = 8320), heads that straddle 32-column MFMA tiles (hd 72), and every sample boundary inside the launch."""
+    M, N = B * tokens, kvh * hd
+    g = torch.Generator().manual_seed(tokens + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    plain = _gemm(A, W, variant=1)
+    want = torch.full((B, kvh, hd, tokens), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_v_transpose(P(plain), N, 0, P(want), B, tokens, tokens, kvh, hd, stream()))
+    guard = 128
+    buf = torch.full((B * kvh * hd * tokens + 2 * guard,), 7.0, device="cuda", dtype=torch.bfloat16)
+    got = buf[guard:-guard].view(B, kvh, hd, tokens)
+    ok(lib().lt_op_gemm_vt(P(A), P(W), P(got), M, N, K, tokens, hd, variant, stream()), "gemm_vt")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), rel_l2(got, want)
+    assert torch.all(buf[:guard] == 7.0) and torch.all(buf[-guard:] == 7.0), "stray store outside the V^T image"
 
 
 @pytest.mark.parametrize("variant", [0, 1, 3, 7])
@@ -259,9 +292,6 @@ def test_gated_residual_norm(next_mode):
         assert rel_l2(h, ref) < 3e-3, rel_l2(h, ref)
 
 
-@pytest.mark.skipif(os.environ.get("LUMINA_EXPERIMENTAL") != "1",
-                    reason="mode-specialised gated_residual_norm (lt_set_option norm_specialize, default off): written after the last "
-                           "GPU minute of round 1, same statements as the generic kernel; scripts/gpu_round2_first.sh runs it")
 @pytest.mark.parametrize("d", [1536, 2304, 3072, 576])
 @pytest.mark.parametrize("post_mode,next_mode", [(1, 1), (1, 2), (0, 1), (0, 2)])
 def test_gated_residual_norm_specialised_is_bit_identical(d, post_mode, next_mode):
@@ -283,7 +313,7 @@ def test_gated_residual_norm_specialised_is_bit_identical(d, post_mode, next_mod
                                                P(nw) if next_mode == 1 else None, P(mod[:, 2 * d:]), P(mod[:, 3 * d:]), next_mode, ld, P(hs),
                                                B, N, d, 1e-5, 1e-6, 1, stream()))
         finally:
-            set_option("norm_specialize", 0)
+            set_option("norm_specialize", 1)  # the default
         torch.cuda.synchronize()
         outs.append((xs, hs))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

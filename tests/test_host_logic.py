@@ -439,3 +439,40 @@ def test_imagenet_driver_command_line_and_grid():
     assert torch.all(grid[:, 2:6, 2:7] == 1 / 16.0) and torch.all(grid[:, 8:12, 16:21] == 11 / 16.0) and torch.all(grid[:, :2] == 0)
     assert torch.all(grid[:, 8:12, 23:] == 0)  # the unused cells of the last row stay black
     assert S.make_grid(imgs[:3], nrow=8).shape == (3, 4 + 4, 3 * 7 + 2)
+
+
+# ---- bench.py plumbing (no GPU): self-launch command line, product-side FLOP count ----------------------------------------------
+
+def test_bench_self_launch_command_and_flop_count():
+    import importlib.util
+    import sys as _sys
+
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "5", "--warmup", "1"], 4, port=29999)
+    assert cmd[:3] == [_sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+
+    class A:
+        gpus = 1
+    bench.maybe_self_launch(A(), [])          # N = 1: runs in process
+    A.gpus = 2
+    os.environ["WORLD_SIZE"] = "2"            # already under a launcher (the driver's torch.distributed.run form): no re-launch
+    try:
+        bench.maybe_self_launch(A(), [])
+    finally:
+        del os.environ["WORLD_SIZE"]
+    # the product's own FLOP count (lumina_t2x_amd/flops.py) against the oracle's independent statement of SURVEY.md 8d
+    from lumina_t2x_amd.flops import ffn_hidden, flops_per_nfe
+    from oracle import nextdit_oracle as O
+    from oracle import synth
+    for cfg, n, t in ((synth.NEXT_2B, 4096, 128), (synth.NextDiTConfig(n_kv_heads=8), 16384, 128), (synth.TINY, 64, 16)):
+        mine = flops_per_nfe(dim=cfg.dim, n_layers=cfg.n_layers, n_heads=cfg.n_heads, n_kv_heads=cfg.n_kv_heads, ffn=cfg.ffn_hidden,
+                             cap_feat_dim=cfg.cap_feat_dim, n_tokens=n, text_len=t, batch=2)
+        assert mine == O.flops_per_nfe(cfg, n, t, 2)
+        assert ffn_hidden(cfg.dim) == cfg.ffn_hidden
+    assert 32.5e12 < flops_per_nfe(dim=2304, n_layers=24, n_heads=32, cap_feat_dim=2048, n_tokens=4096, text_len=128) < 34.0e12
