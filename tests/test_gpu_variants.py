@@ -175,8 +175,19 @@ def test_single_moe_engine_matches_reference_golden(golden_dir, name, ctor):
     fc = rel_l2(V.imagenet_forward_with_cfg(sd, cfg, z.float().cpu(), t.cpu(), y.cpu(), 4.0, bf16=True), ref)
     assert rel_l2(got, ref) < max(TOL_CFG4, 1.5 * fc), (rel_l2(got, ref), fc)
     assert torch.equal(got[0, :3], got[1, :3])
-    got = model.forward_with_cfg(z, t, y, 4.0, rope_scaling_factor=2.0, ntk_factor=1.5)
-    assert rel_l2(got, torch.from_numpy(g["cfg4_rope"])) < max(TOL_CFG4, 1.5 * fc)
+    # second call with RoPE scaling.  Per-token routing is discrete: which near-ties flip depends on sub-ulp details, and on this
+    # 128-token model a handful of flipped tokens moves the rel-L2 a lot - the reference's bf16 choreography lands anywhere in
+    # 0.16 .. 0.35 of its fp32 self when its weights are jittered by a fraction of a bf16 ulp.  Yardstick = the largest of a few
+    # such realisations (seeded), gate = 1.5 x that, as everywhere
+    ref = torch.from_numpy(g["cfg4_rope"])
+    kw = dict(rope_scaling_factor=2.0, ntk_factor=1.5)
+    gen = torch.Generator().manual_seed(5)
+    floors = [rel_l2(V.imagenet_forward_with_cfg(sd, cfg, z.float().cpu(), t.cpu(), y.cpu(), 4.0, bf16=True, **kw), ref)]
+    for _ in range(4):
+        sdj = {k: v * (1 + (torch.rand(v.shape, generator=gen) - 0.5) * 2.0 ** -9) for k, v in sd.items()}
+        floors.append(rel_l2(V.imagenet_forward_with_cfg(sdj, cfg, z.float().cpu(), t.cpu(), y.cpu(), 4.0, bf16=True, **kw), ref))
+    got = model.forward_with_cfg(z, t, y, 4.0, **kw)
+    assert rel_l2(got, ref) < max(TOL_CFG4, 1.5 * max(floors)), (rel_l2(got, ref), floors)
 
 
 def test_single_moe_600m_builders_and_width():
@@ -302,7 +313,13 @@ def test_imagenet_sample_driver_with_injected_decoder(golden_dir, tmp_path, mode
     else:
         fn = sampler.sample_sde(sampling_method="Euler", diffusion_form="sigma", diffusion_norm=1.0, last_step="Mean", last_step_size=0.04,
                                 num_steps=4)
-        torch.manual_seed(9)  # the SDE draws its noise from the global generator after z: replay the same stream
+        # the SDE draws its noise from torch's CPU generator (integrators.py:37), which the driver seeded BEFORE it built the
+        # model (as the reference does, sample.py:84): the constructor's parameter initialisers consume that stream first.
+        # Replay exactly that: seed, construct, draw z on the device, sample
+        torch.manual_seed(9)
+        model = models.imagenet.DiT_Llama(**{**kw, "input_size": ls})
+        model.load_state_dict(synth.synth_state_dict(cfg, seed=seed_w), strict=True)
+        model = model.eval().to("cuda", torch.bfloat16)
         z = torch.randn(n, 4, ls, ls, dtype=torch.bfloat16, device="cuda")
         z = torch.cat([z, z], 0)
     want = fn(z, model.forward_with_cfg, y=y, cfg_scale=4.0)[-1].chunk(2, dim=0)[0]
