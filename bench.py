@@ -316,6 +316,7 @@ def main():
             "kernel_time_ms_per_step": dict(breakdown, note=f"untimed pass of {nb} NFE with events around every launch"),
             "attention_tflops_per_s": attn_fl_b / (attn_ms_b * 1e-3) / 1e12 if attn_ms_b > 0 else 0.0,
             "kernel_variants": {"attention": args.attn_variant or 3, "gemm": args.gemm_variant or 0},
+            "hip_graph_replays": eng.graph_replays(),
             "ode_stepping_parity": "unpinned (torchdiffeq is neither vendored, pinned nor installed; fixed-grid solvers restated "
                                    "from its published algorithm, DESIGN.md 6)",
         }

@@ -160,6 +160,8 @@ int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, void* final_d
 
 /* number of model evaluations issued by the last lt_sample_ode call */
 int64_t lt_last_nfe(lt_engine* e);
+/* model evaluations served by replaying a captured HIP graph since lt_create (0 with lt_set_option("graph", 0)) */
+int64_t lt_graph_replays(lt_engine* e);
 
 /* ---- profiling hooks (bench.py roofline object) ----------------------------------------------- */
 /* class 0 = MFMA GEMM kernel, 1 = attention kernel, 2 = everything else.  When enabled, every

@@ -478,15 +478,26 @@ namespace lt_attn {
 //   K(t+3) / V(t+2) are issued in Y(t), waited for at the end of X(t+2) (leaving Y(t+1)'s batch in flight) and
 //   first read in X(t+3) - a barrier all waves pass lies between wait and read for either group; they overwrite
 //   the slots of K(t-1) / V(t-2), last read in X(t-1) = interval 2t-2+g' < 2t+g+1.
+// HD = 96 (Flag-DiT 5B, lumina_t2i/models/model.py:507-621) runs the same two-group ping-pong with three differences (FOLD = false):
+//  * there are no spare slots: QK^T is 6 exact k-steps, O^T is 3 exact row tiles.  The running max is subtracted on the VALU
+//    (p = exp2(s - m), one v_sub per score) and the row sum is accumulated on the VALU (one v_add per score); both sit in
+//    the Y phase, which stays shorter than the partner group's X phase (24 MFMAs = 768 matrix-pipe cycles);
+//  * a K row is 192 bytes = 12 sixteen-byte chunks: rows 4 apart would share an LDS slot in a fragment read (4-way conflict), so
+//    chunk c of row r is stored at position c ^ ((r >> 2) & 3) - applied to the per-lane SOURCE address of the LDS-DMA (the
+//    LDS image of a DMA is lane-linear) and again on the fragment reads (guide rule 21);
+//  * 24 one-KiB pieces per (K, V^T) tile pair = exactly three per wave, no duplicates.
 template <int HD, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
-    static_assert(HD == 72, "v3 relies on hd % 16 == 8 (pad slots in the last QK^T k-step, spare row in O^T)");
-    constexpr int KS = 5, DT = 3, CPR = HD / 8;
-    constexpr int KTILE = 64 * HD * 2;      // 9216
-    constexpr int VTILE = HD * 128 + 128;   // 9344 incl. the row of ones
+    static_assert(HD == 72 || HD == 96, "v3 is built for hd 72 (max / row sum folded into the MFMAs through the pad slots) and hd 96");
+    constexpr bool FOLD = (HD == 72);
+    constexpr int KS = (HD + 15) / 16, DT = 3;
+    constexpr int NKP = 64 * HD * 2 / 1024, NVP = HD / 8;   // 1-KiB pieces of a K tile / a V^T tile: 9 + 9 or 12 + 12
+    constexpr int KTILE = 64 * HD * 2;                      // 9216 / 12288
+    constexpr int VTILE = HD * 128 + (FOLD ? 128 : 0);      // incl. the row of ones (FOLD)
     constexpr int V_BASE = 0, K_BASE = 4 * VTILE, CONST_OFF = K_BASE + 4 * KTILE;
     constexpr float THR = 8.0f;
-    constexpr int LI = HD % 32, L_DT = HD / 32, L_HI = (LI >> 2) & 1, L_REG = (LI & 3) + 4 * (LI >> 3);
+    constexpr int LI = HD % 32, L_DT = FOLD ? HD / 32 : 0, L_HI = (LI >> 2) & 1, L_REG = (LI & 3) + 4 * (LI >> 3);
+    static_assert(NKP + NVP <= 24, "three staging pieces per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -510,8 +521,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     const int bhk = b * p.Hkv + h / (p.H / p.Hkv);
 
     // constants in LDS: ones rows behind each V^T slot, and the K-side pad chunk (1, 1, 0, ...)
-    if (tid < 128) *(unsigned*)(smem + V_BASE + (tid >> 5) * VTILE + HD * 128 + (tid & 31) * 4) = 0x3F803F80u;
-    if (tid >= 128 && tid < 132) *(unsigned*)(smem + CONST_OFF + (tid - 128) * 4) = (tid == 128) ? 0x3F803F80u : 0u;
+    if constexpr (FOLD) {
+        if (tid < 128) *(unsigned*)(smem + V_BASE + (tid >> 5) * VTILE + HD * 128 + (tid & 31) * 4) = 0x3F803F80u;
+        if (tid >= 128 && tid < 132) *(unsigned*)(smem + CONST_OFF + (tid - 128) * 4) = (tid == 128) ? 0x3F803F80u : 0u;
+    }
 
     // ---- Q fragments, pre-scaled to the log2 domain -------------------------------------------------
     int qrow = qb * 256 + wave * 32 + l31;
@@ -539,13 +552,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     }
 
     // ---- staging ------------------------------------------------------------------------------------
-    // 18 one-KiB pieces per (K, V^T) tile pair: K piece j = K-tile bytes [1024 j, +1024) (j < 9), V piece j = V^T rows
-    // 8j..8j+7 (j < 9).  Every wave issues exactly three LDS-DMA loads per batch, branch-free, so one vmcnt literal
-    // fits all waves:  A = K piece w;  B = K piece 8 (wave 0) or V piece w-1;  C = V piece 7 (wave 0), 8 (wave 1) or
-    // V piece w-1 again (waves 2..7: same bytes to the same place, harmless).
-    const bool b_is_k = (wave == 0);
-    const int jb = b_is_k ? 8 : wave - 1;
-    const int jc = (wave == 0) ? 7 : (wave == 1 ? 8 : wave - 1);
+    // NKP + NVP one-KiB pieces per (K, V^T) tile pair: K piece j = bytes [1024 j, +1024) of the K tile's LDS image (j < NKP),
+    // V piece j = V^T rows 8j..8j+7 (j < NVP).  Every wave issues exactly three LDS-DMA loads per batch, branch-free, so one
+    // vmcnt literal fits all waves.
+    //   hd 72 (9 + 9):   A = K piece w;  B = K piece 8 (wave 0) or V piece w-1;  C = V piece 7 (wave 0), 8 (wave 1) or V piece
+    //                    w-1 again (waves 2..7: same bytes to the same place, harmless)
+    //   hd 96 (12 + 12): A = K piece w;  B = K piece 8 + w (waves 0..3) or V piece w - 4;  C = V piece 4 + w
+    const bool b_is_k = FOLD ? (wave == 0) : (wave < 4);
+    const int jb = FOLD ? (b_is_k ? 8 : wave - 1) : (b_is_k ? 8 + wave : wave - 4);
+    const int jc = FOLD ? ((wave == 0) ? 7 : (wave == 1 ? 8 : wave - 1)) : 4 + wave;
+    // per-lane source offset of K piece j: lane-linear at hd 72; at hd 96 chunk position 64 j + lane = (row, c') is filled from
+    // source chunk c = c' ^ ((row >> 2) & 3) of that row
+    auto k_voff = [&](int j) __attribute__((always_inline)) {
+        if constexpr (FOLD) return j * 1024 + lane * 16;
+        const int pos = 64 * j + lane, row = pos / 12, c = (pos - 12 * row) ^ ((row >> 2) & 3);
+        return row * (HD * 2) + c * 16;
+    };
     // two K / V^T sources to stage from: [0] the image keys, [1] the text keys of the fused cross-attention
     // (plain arrays with constant indices: a local class holding buffer descriptors breaks hipcc 7.2's host-side pass)
     __amdgpu_buffer_rsrc_t srcA[2], srcB[2], srcC[2];
@@ -559,17 +581,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
         srcA[which] = __builtin_amdgcn_make_buffer_rsrc((void*)k_head, 0, kbytes, 0x00020000);
         srcB[which] = __builtin_amdgcn_make_buffer_rsrc((void*)(b_is_k ? k_head : v_head), 0, b_is_k ? kbytes : vbytes, 0x00020000);
         srcC[which] = __builtin_amdgcn_make_buffer_rsrc((void*)v_head, 0, vbytes, 0x00020000);
-        svoffB[which] = b_is_k ? 8 * 1024 + lane * 16 : v_voff(jb);
+        svoffB[which] = b_is_k ? k_voff(jb) : v_voff(jb);
         svoffC[which] = v_voff(jc);
     };
     make_src(0, p.k + (size_t)bhk * p.Nk * HD, p.Nk, p.vt + (size_t)bhk * HD * p.Nkpad, p.Nkpad);
-    const int voffA = wave * 1024 + lane * 16;
+    const int voffA = k_voff(wave);
     // batch = {K(tk), V(tv)}; slots are tile index & 3
     auto dma_a_from = [&](int sr, int tk) __attribute__((always_inline)) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA[sr], LDS_PTR(smem + K_BASE + (tk & 3) * KTILE + wave * 1024), 16, voffA, tk * KTILE, 0, 0);
     };
     auto dma_b_from = [&](int sr, int tk, int tv) __attribute__((always_inline)) {
-        const int lds = b_is_k ? K_BASE + (tk & 3) * KTILE + 8 * 1024 : V_BASE + (tv & 3) * VTILE + jb * 1024;
+        const int lds = b_is_k ? K_BASE + (tk & 3) * KTILE + jb * 1024 : V_BASE + (tv & 3) * VTILE + jb * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB[sr], LDS_PTR(smem + lds), 16, svoffB[sr], b_is_k ? tk * KTILE : tv * 128, 0, 0);
     };
     auto dma_c_from = [&](int sr, int tv) __attribute__((always_inline)) {
@@ -583,17 +605,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     // prologue: K(0); K(1), V(0); K(2), V(1)  (the batches X(-3), X(-2), X(-1) would have issued; tile indices past
     // the end read zeros through the descriptor bounds and are never consumed)
     dma_a(0);
-    if (wave == 0) dma_b(0, 0);
+    if (b_is_k) dma_b(0, 0);  // (the K-piece part of batch 0; its V half would be "V(-1)")
     dma_a(1); dma_b(1, 0); dma_c(0);
     dma_a(2); dma_b(2, 1); dma_c(1);
 
     // ---- per-lane LDS read offsets ------------------------------------------------------------------
-    const int kb_lane = K_BASE + l31 * (HD * 2) + hi * 16;  // + slot * KTILE + kt2 * 32 * HD * 2 + s * 32 (s < 4)
+    const int kb_lane = K_BASE + l31 * (HD * 2) + (FOLD ? hi * 16 : 0);  // + slot * KTILE + kt2 * 32 * HD * 2 + chunk offset
+    int kco[KS];  // byte offset of k-step s inside the lane's K row: hd 72 plain (2 s chunks on top of the hi chunk), hd 96 swizzled
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) kco[s_] = FOLD ? s_ * 32 : (((2 * s_ + hi) ^ ((l31 >> 2) & 3)) << 4);
     int voff[DT][4];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         int d = dt * 32 + l31;
-        if (d > HD) d = HD;  // row HD is the row of ones; rows past it are never stored
+        if (FOLD && d > HD) d = HD;  // row HD is the row of ones; rows past it are never stored
 #pragma unroll
         for (int g = 0; g < 4; ++g) voff[dt][g] = V_BASE + d * 128 + (((2 * g + hi) ^ ((d >> 1) & 7)) << 4);
     }
@@ -605,7 +630,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     f32x16 sc[2];
     bf16x8 pa[4];
-    float m_run = 0.f;
+    float m_run = FOLD ? 0.f : -1.0e30f;  // FOLD: scores leave the MFMA relative to the running max already
+    float l_run = 0.f;                    // !FOLD: this lane's half of the row sum (the other half lives on lane ^ 32)
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // DMA landed, constant rows written
     __builtin_amdgcn_sched_barrier(0);
@@ -637,8 +663,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
         __builtin_amdgcn_s_setprio(1);
         const char* kb = smem + (t & 3) * KTILE + kb_lane;
         const char* vb = smem + ((t + 3) & 3) * VTILE;
-        const char* kpad = hi ? (const char*)(smem + CONST_OFF) : kb + (KS - 1) * 32;
-        bf16x8 fr[22];
+        const char* kpad = hi ? (const char*)(smem + CONST_OFF) : kb + (KS - 1) * 32;  // FOLD only
+        bf16x8 fr[12 + 2 * KS];
         int n = 0;
         // LDS-DMA writes cannot be scheduled across LDS reads they might alias, so their place among the reads is
         // fixed here in source order (beside MFMAs 2 / 6 / 10 of the pinned pipeline)
@@ -667,8 +693,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
 #pragma unroll
                 for (int kt2 = 0; kt2 < 2; ++kt2) {
                     dma_at(n);
-                    fr[n++] = (s < KS - 1) ? *(const bf16x8*)(kb + kt2 * 32 * HD * 2 + s * 32)
-                                           : *(const bf16x8*)(kpad + (hi ? 0 : kt2 * 32 * HD * 2));
+                    if constexpr (FOLD)
+                        fr[n++] = (s < KS - 1) ? *(const bf16x8*)(kb + kt2 * 32 * HD * 2 + s * 32)
+                                               : *(const bf16x8*)(kpad + (hi ? 0 : kt2 * 32 * HD * 2));
+                    else
+                        fr[n++] = *(const bf16x8*)(kb + kt2 * 32 * HD * 2 + kco[s]);
                 }
         }
         n = 0;
@@ -688,7 +717,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
         }
         if constexpr (PV && QK) {  // the first six fragments are already in flight (pre_reads): one read per MFMA
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 6 + 2 * KS; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 if (DMA && (i == 2 || i == 6 || i == 10)) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
@@ -727,6 +756,34 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
         {
             auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if constexpr (!FOLD) {
+            // explicit running max / row sum (no spare MFMA slots at hd 96): m only moves when a tile max exceeds it by 2^THR
+            // (then O and l are rescaled - rare wave-uniform branch, guide T13 order: the previous tile's PV is complete)
+            const bool raise = mx > m_run + THR;
+            if (__builtin_expect(__any(raise), 0)) {
+                const float m_new = raise ? mx : m_run;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(sc[g >> 1][8 * (g & 1) + e] - m_run);
+                    if (e & 1) s1 += pe; else s0 += pe;
+                    pa[g][e] = (__bf16)pe;
+                }
+            l_run += s0 + s1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(pa[g]));
+            return;
         }
         const bool first = (t == 0);
         const bool raise = first || (mx > THR);
@@ -818,8 +875,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
     phase_x(ntile, T_{}, F_{}, F_{});  // PV of the last tile (V slot (ntile + 3) & 3 = (ntile - 1) & 3)
     if (grp == 0) bar();                       // the barrier group 1 still needs after its last Y phase
 
-    // l = O^T[HD][q] lives in register L_REG of tile L_DT on the hi == L_HI lane of this query row
-    float inv = 1.0f / __shfl(o[L_DT][L_REG], l31 + 32 * L_HI, 64);
+    // FOLD: l = O^T[HD][q] lives in register L_REG of tile L_DT on the hi == L_HI lane of this query row; else the two halves'
+    // partial sums are added
+    auto row_inv = [&]() __attribute__((always_inline)) {
+        if constexpr (FOLD) return 1.0f / __shfl(o[L_DT][L_REG], l31 + 32 * L_HI, 64);
+        else return 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    };
+    float inv = row_inv();
     u32x2 res[DT][4];  // self-attention result, bf16 (flash-attn output dtype, model.py:392-405)
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -840,8 +902,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-        m_run = 0.f;
-        if (hi) {
+        m_run = FOLD ? 0.f : -1.0e30f;
+        l_run = 0.f;
+        if (FOLD && hi) {
             qf[KS - 1][0] = (__bf16)0.0f;
             qf[KS - 1][1] = (__bf16)0.0f;
         }
@@ -862,7 +925,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
                 phase_x(tt + 1, T_{}, F_{}, F_{});             // O_txt += V_txt(tt)^T P   (V slot (tt + 4) & 3 = tt & 3)
             }
         }
-        inv = 1.0f / __shfl(o[L_DT][L_REG], l31 + 32 * L_HI, 64);
+        inv = row_inv();
         const float gate = bfr(tanhf(bf2f(p.tgate[h])));
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -891,6 +954,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs p) {
 
 template __global__ void attn_fwd_kernel_v3<72, false>(AttnArgs);
 template __global__ void attn_fwd_kernel_v3<72, true>(AttnArgs);
+template __global__ void attn_fwd_kernel_v3<96, false>(AttnArgs);
 
 }  // namespace lt_attn
 
@@ -900,7 +964,7 @@ static int g_attn_variant = 3;  // 3: ping-pong kernel where it applies (hd 72 s
 void lt_set_attention_variant(int v) { g_attn_variant = v; }
 
 // true when launch_attention() can take the text keys along with the image keys (one kernel instead of two)
-bool attention_fuses_text(int hd) { return g_attn_variant == 3 && hd == 72; }
+bool attention_fuses_text(int hd) { return g_attn_variant == 3 && (hd == 72 || hd == 96); }
 
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.H % a.Hkv == 0, "attention: H=%d not a multiple of Hkv=%d", a.H, a.Hkv);
@@ -916,28 +980,33 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
         LT_REQUIRE(a.k_prescaled && a.tvt && a.tbias && a.tgate && a.Tk > 0 && a.Tkpad % 64 == 0 && a.Tkpad >= a.Tk,
                    "attention: incomplete fused text arguments");
     }
-    if (g_attn_variant == 3 && a.hd == 72 && a.bias == nullptr && !a.accumulate) {
-        constexpr int SMEM3 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16;
+    if (g_attn_variant == 3 && (a.hd == 72 || a.hd == 96) && a.bias == nullptr && !a.accumulate) {
+        constexpr int SMEM72 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16, SMEM96 = 4 * (96 * 128) + 4 * (64 * 96 * 2) + 16;
         static bool attr_done = false;
         if (!attr_done) {
-            LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<72>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3));
+            LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<72>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM72));
+            LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<96>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM96));
             attr_done = true;
         }
         const int nqb3 = (a.N + 255) / 256;
         if (a.trace) {
+            LT_REQUIRE(a.hd == 72, "attention trace: the hd 72 kernel is the instrumented one");
             static bool tdone = false;
             if (!tdone) {
-                LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<72, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3));
+                LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<72, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM72));
                 tdone = true;
             }
-            hipLaunchKernelGGL((attn_fwd_kernel_v3<72, true>), dim3(a.B * a.H * nqb3), dim3(512), SMEM3, stream, a);
-        } else
-        hipLaunchKernelGGL(attn_fwd_kernel_v3<72>, dim3(a.B * a.H * nqb3), dim3(512), SMEM3, stream, a);
+            hipLaunchKernelGGL((attn_fwd_kernel_v3<72, true>), dim3(a.B * a.H * nqb3), dim3(512), SMEM72, stream, a);
+        } else if (a.hd == 72) {
+            hipLaunchKernelGGL(attn_fwd_kernel_v3<72>, dim3(a.B * a.H * nqb3), dim3(512), SMEM72, stream, a);
+        } else {
+            hipLaunchKernelGGL(attn_fwd_kernel_v3<96>, dim3(a.B * a.H * nqb3), dim3(512), SMEM96, stream, a);
+        }
         LT_CHECK_HIP(hipGetLastError());
         return 0;
     }
     LT_REQUIRE(a.trace == nullptr, "attention trace: only the hd 72 self-attention kernel (variant 3) is instrumented");
-    LT_REQUIRE(a.tk == nullptr, "attention: fused text cross-attention needs the hd 72 ping-pong kernel (use attention_fuses_text())");
+    LT_REQUIRE(a.tk == nullptr, "attention: fused text cross-attention needs the ping-pong kernel (hd 72 / 96, use attention_fuses_text())");
     const bool v2 = g_attn_variant >= 2;  // (variant 3 falls back to v2 for text attention and other head dims)
     switch (a.hd) {
         case 48: if (v2) LAUNCH_V2(48); else LAUNCH_V1(48); break;

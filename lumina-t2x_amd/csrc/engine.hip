@@ -40,6 +40,10 @@ int g_qkv_post_fused = 0;
 // lt_set_option("qkv_vt_epilogue"): 1 = the V projection is its own GEMM launch whose epilogue writes the attention kernels' V^T
 // image (no v_transpose pass: 15.6 us per layer at cfg 2, and the 37.7 MB V slice is never written row-major / re-read)
 int g_qkv_vt_epilogue = 1;
+// lt_set_option("graph"): 1 = a model evaluation (~250 launches) is captured into a HIP graph per (arguments, shapes) and replayed.
+// Every lt_set_option bumps g_option_gen, which is part of the graph key (kernel selection is baked into a captured graph).
+int g_graph = 1;
+int g_option_gen = 0;
 
 struct DevBuf {
     void* p = nullptr;
@@ -134,6 +138,8 @@ struct lt_engine {
     // ode
     void *ys[2] = {nullptr, nullptr}, *ymid = nullptr, *kbuf[4] = {nullptr, nullptr, nullptr, nullptr};
     float* t_dev = nullptr;
+    float* t_pinned = nullptr;       // page-locked staging of the stage times (an async copy from pageable memory synchronises)
+    hipEvent_t t_copied = nullptr;   // the previous call's copy out of t_pinned has executed
     int t_cap = 0;
     // compositional (regional) text conditioning (lt_prepare_prompt_regional): Y captions, the first Y-1 belong to regions of
     // the cond row, the last to the uncond row; 0 = off
@@ -143,8 +149,15 @@ struct lt_engine {
     int* reg_qmap = nullptr;   // [max_batch] query batch of each caption
     int* pk_dev = nullptr;     // packed batches: [0,64) token counts, [64,128) grid widths
     int pk_host[128] = {0};
-    std::vector<float> t_host;
     long long last_nfe = 0;
+    // HIP graphs of one model evaluation (forward_graphed): fixed staging buffers the captured kernels read / write, a private
+    // stream to capture on (the caller's stream may be the legacy null stream, which cannot capture), cached executables
+    struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int uses = 0; bool failed = false; };
+    std::vector<GraphEntry> graphs;
+    void *g_x = nullptr, *g_out = nullptr;
+    float* g_t = nullptr;
+    hipStream_t cap_stream = nullptr;
+    long long graph_replays = 0;
     // profiling
     int prof_mask = 0;  // bit k: class k launches are bracketed by HIP events
     bool prof_on = false;
@@ -643,6 +656,64 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
     return 0;
 }
 
+// One model evaluation through a cached HIP graph.  The first call for a key runs eagerly (it also performs the one-time
+// hipFuncSetAttribute calls of the launchers), the second captures the same launch sequence on the engine's private stream
+// with the staging buffers as input / output and instantiates it, later calls replay: copy in, one graph launch, copy out.
+// Kernel arguments are baked into a graph, so the key holds everything they depend on: the step arguments (shapes, cfg scale,
+// RoPE scaling, softmax scale inputs), the prompt dimensions, cfg on / off and the option generation.  Weights and prompt
+// CONTENTS live behind fixed pointers and may change freely.
+int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* out, const lt_step_args* a, int use_cfg, hipStream_t s) {
+    if (!g_graph || e->prof_on) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+    const int B = a->batch;
+    if (B < 1 || B > e->cfg.max_batch || a->latent_h <= 0 || a->latent_w <= 0 || (a->io_dtype != LT_BF16 && a->io_dtype != LT_F32))
+        return run_forward(e, x_in, t_dev, out, a, use_cfg, s);  // let the eager path produce the error message
+    const size_t sbytes = (size_t)B * e->cfg.in_channels * a->latent_h * a->latent_w * (a->io_dtype == LT_BF16 ? 2 : 4);
+    const size_t cap_bytes = (size_t)e->cfg.max_batch * e->cfg.in_channels * e->cfg.max_tokens * e->cfg.patch_size * e->cfg.patch_size * 4;
+    if (sbytes > cap_bytes) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+    const int extra[8] = {use_cfg, e->prompt_B, e->prompt_T, e->prompt_Tpad, e->reg_Y, e->reg_h, e->reg_w, g_option_gen};
+    std::vector<char> key(sizeof(lt_step_args) + sizeof(extra));
+    memcpy(key.data(), a, sizeof(lt_step_args));
+    memcpy(key.data() + sizeof(lt_step_args), extra, sizeof(extra));
+    lt_engine::GraphEntry* ge = nullptr;
+    for (auto& g : e->graphs) if (g.key == key) { ge = &g; break; }
+    if (!ge) {
+        if (e->graphs.size() >= 16) {  // bound the cache: drop the oldest entry
+            if (e->graphs.front().exec) (void)hipGraphExecDestroy(e->graphs.front().exec);
+            e->graphs.erase(e->graphs.begin());
+        }
+        e->graphs.emplace_back();
+        ge = &e->graphs.back();
+        ge->key = key;
+    }
+    if (ge->failed || ge->uses++ == 0) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+    if (!ge->exec) {
+        if (ensure_rope(e, a, s)) return 1;  // the table build must not be part of the graph (it runs only when its arguments change)
+        if (!e->cap_stream) LT_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        int rc = 0;
+        if (ok) {
+            rc = run_forward(e, e->g_x, e->g_t, e->g_out, a, use_cfg, e->cap_stream);
+            ok = hipStreamEndCapture(e->cap_stream, &graph) == hipSuccess && rc == 0 && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {  // capture is an optimisation: fall back to eager launches for this key
+            (void)hipGetLastError();
+            ge->exec = nullptr;
+            ge->failed = true;
+            if (rc) return rc;
+            return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+        }
+    }
+    LT_CHECK_HIP(hipMemcpyAsync(e->g_x, x_in, sbytes, hipMemcpyDeviceToDevice, s));
+    LT_CHECK_HIP(hipMemcpyAsync(e->g_t, t_dev, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    LT_CHECK_HIP(hipGraphLaunch(ge->exec, s));
+    LT_CHECK_HIP(hipMemcpyAsync(out, e->g_out, sbytes, hipMemcpyDeviceToDevice, s));
+    ++e->graph_replays;
+    return 0;
+}
+
 float bf16_round_host(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -781,6 +852,18 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         const size_t state = Bm * cfg->in_channels * Nm * cfg->patch_size * cfg->patch_size * sizeof(float);
         for (int i = 0; i < 2; ++i) { if (dev_alloc(e, &e->ys[i], state)) return fail(); }
         if (dev_alloc(e, &e->ymid, state)) return fail();
+        // stage times of lt_sample_ode: room for a 256-point grid of 4-stage steps without a (synchronising) reallocation
+        if (hipMalloc((void**)&e->t_dev, (size_t)1024 * Bm * sizeof(float)) != hipSuccess) return fail();
+        if (hipHostMalloc((void**)&e->t_pinned, (size_t)1024 * Bm * sizeof(float), hipHostMallocDefault) != hipSuccess) return fail();
+        if (hipEventCreateWithFlags(&e->t_copied, hipEventDisableTiming) != hipSuccess) return fail();
+        e->t_cap = (int)(1024 * Bm);
+        if (dev_alloc(e, &e->g_x, state)) return fail();
+        if (dev_alloc(e, &e->g_out, state)) return fail();
+        {
+            void* q;
+            if (dev_alloc(e, &q, Bm * sizeof(float))) return fail();
+            e->g_t = (float*)q;
+        }
         for (int i = 0; i < 4; ++i) { if (dev_alloc(e, &e->kbuf[i], state)) return fail(); }
     }
 #undef A16
@@ -790,8 +873,12 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
 
 extern "C" void lt_destroy(lt_engine* e) {
     if (!e) return;
+    for (auto& ge : e->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (auto& b : e->allocs) (void)hipFree(b.p);
     if (e->t_dev) (void)hipFree(e->t_dev);
+    if (e->t_pinned) (void)hipHostFree(e->t_pinned);
+    if (e->t_copied) (void)hipEventDestroy(e->t_copied);
     if (e->pk_dev) (void)hipFree(e->pk_dev);
     if (e->reg_txt) (void)hipFree(e->reg_txt);
     if (e->reg_qmap) (void)hipFree(e->reg_qmap);
@@ -930,7 +1017,7 @@ extern "C" int lt_prepare_labels(lt_engine* e, const int32_t* labels_dev, int32_
 
 extern "C" int lt_forward(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev, const lt_step_args* a, void* stream) {
     LT_REQUIRE(e && x_dev && t_dev && out_dev && a, "lt_forward: null argument");
-    return run_forward(e, x_dev, t_dev, out_dev, a, 0, (hipStream_t)stream);
+    return forward_graphed(e, x_dev, t_dev, out_dev, a, 0, (hipStream_t)stream);
 }
 
 extern "C" int lt_forward_packed(lt_engine* e, const void* const* x_ptrs, const int32_t* hw_host, const float* t_dev,
@@ -945,7 +1032,7 @@ extern "C" int lt_forward_packed(lt_engine* e, const void* const* x_ptrs, const 
 
 extern "C" int lt_forward_cfg(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev, const lt_step_args* a, void* stream) {
     LT_REQUIRE(e && x_dev && t_dev && out_dev && a, "lt_forward_cfg: null argument");
-    return run_forward(e, x_dev, t_dev, out_dev, a, 1, (hipStream_t)stream);
+    return forward_graphed(e, x_dev, t_dev, out_dev, a, 1, (hipStream_t)stream);
 }
 
 extern "C" int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, void* final_dev, const float* tgrid_host,
@@ -972,7 +1059,18 @@ extern "C" int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, vo
     const bool bf = a->io_dtype == LT_BF16;
     // stage times; torchdiffeq's _PerturbFunc casts t to the state dtype before calling the model, then
     // integrators.py:108 broadcasts it to an fp32 [B] vector
-    e->t_host.assign((size_t)ncalls * B, 0.f);
+    // (grids beyond the staging buffers' 1024 stage times per batch row - a 257-point rk4 grid - grow them: the one case in which
+    //  this call synchronises)
+    if (e->t_cap < ncalls * B) {
+        LT_CHECK_HIP(hipStreamSynchronize(s));
+        if (e->t_dev) LT_CHECK_HIP(hipFree(e->t_dev));
+        if (e->t_pinned) LT_CHECK_HIP(hipHostFree(e->t_pinned));
+        e->t_dev = nullptr; e->t_pinned = nullptr; e->t_cap = 0;
+        LT_CHECK_HIP(hipMalloc((void**)&e->t_dev, (size_t)ncalls * B * sizeof(float)));
+        LT_CHECK_HIP(hipHostMalloc((void**)&e->t_pinned, (size_t)ncalls * B * sizeof(float), hipHostMallocDefault));
+        e->t_cap = ncalls * B;
+    }
+    LT_CHECK_HIP(hipEventSynchronize(e->t_copied));  // the previous trajectory's copy has left the staging buffer (normally long ago)
     std::vector<float> dts(n_grid - 1);
     for (int i = 0; i + 1 < n_grid; ++i) {
         const float t0 = tgrid_host[i], t1 = tgrid_host[i + 1];
@@ -984,22 +1082,18 @@ extern "C" int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, vo
         else { ts[0] = t0; ts[1] = t0 + dt * (float)(1.0 / 3.0); ts[2] = t0 + dt * (float)(2.0 / 3.0); ts[3] = t1; }
         for (int k = 0; k < stages; ++k) {
             const float tv = (t_round && bf) ? bf16_round_host(ts[k]) : ts[k];
-            for (int b = 0; b < B; ++b) e->t_host[((size_t)i * stages + k) * B + b] = tv;
+            for (int b = 0; b < B; ++b) e->t_pinned[((size_t)i * stages + k) * B + b] = tv;
         }
     }
-    if (e->t_cap < ncalls * B) {
-        if (e->t_dev) LT_CHECK_HIP(hipFree(e->t_dev));
-        LT_CHECK_HIP(hipMalloc((void**)&e->t_dev, (size_t)ncalls * B * sizeof(float)));
-        e->t_cap = ncalls * B;
-    }
-    LT_CHECK_HIP(hipMemcpyAsync(e->t_dev, e->t_host.data(), (size_t)ncalls * B * sizeof(float), hipMemcpyHostToDevice, s));
+    LT_CHECK_HIP(hipMemcpyAsync(e->t_dev, e->t_pinned, (size_t)ncalls * B * sizeof(float), hipMemcpyHostToDevice, s));
+    LT_CHECK_HIP(hipEventRecord(e->t_copied, s));
     LT_CHECK_HIP(hipMemcpyAsync(e->ys[0], z_dev, sbytes, hipMemcpyDeviceToDevice, s));
     if (traj_dev) LT_CHECK_HIP(hipMemcpyAsync(traj_dev, z_dev, sbytes, hipMemcpyDeviceToDevice, s));
     int cur = 0;
     long long nfe = 0;
     auto model = [&](const void* y, int call, void* out) {
         ++nfe;
-        return run_forward(e, y, e->t_dev + (size_t)call * B, out, a, use_cfg, s);
+        return forward_graphed(e, y, e->t_dev + (size_t)call * B, out, a, use_cfg, s);
     };
     const int dt_code = bf ? 1 : 0;
     for (int i = 0; i + 1 < n_grid; ++i) {
@@ -1037,6 +1131,7 @@ extern "C" int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, vo
 }
 
 extern "C" int64_t lt_last_nfe(lt_engine* e) { return e ? e->last_nfe : -1; }
+extern "C" int64_t lt_graph_replays(lt_engine* e) { return e ? e->graph_replays : -1; }
 
 // ---- profiling ------------------------------------------------------------------------------------------
 extern "C" int lt_profile_enable(lt_engine* e, int32_t on) {
@@ -1102,11 +1197,14 @@ extern "C" int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t*
 
 extern "C" int lt_set_option(const char* name, int32_t value) {
     LT_REQUIRE(name, "lt_set_option: null name");
+    ++g_option_gen;  // captured graphs bake the kernel selection: every option change starts new graph keys
+    if (strcmp(name, "graph") == 0) { g_graph = value != 0; return 0; }
     if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 3, "attention_variant must be 1, 2 or 3"); lt_set_attention_variant(value); return 0; }
     if (strcmp(name, "qkv_post_fused") == 0) { g_qkv_post_fused = value != 0; return 0; }
     if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_swiglu_w4p") == 0) { lt_set_gemm_swiglu_w4p(value != 0); return 0; }
+    if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }
     if (strcmp(name, "gemm_stagger") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_stagger must be 0..64"); return lt_set_gemm_stagger(value); }
     if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }
     if (strcmp(name, "gemm_pipeline") == 0 || strcmp(name, "gemm_pp_tail") == 0 || strcmp(name, "gemm_persist") == 0) {
@@ -1233,7 +1331,7 @@ extern "C" int lt_op_attention_fused(const void* q, const void* k, const void* v
                                      const float* tbias, const void* tgate, void* out, int32_t B, int32_t H, int32_t Hkv, int32_t N,
                                      int32_t Nk, int32_t Nkpad, int32_t Tk, int32_t Tkpad, int32_t hd, void* stream) {
     LT_REQUIRE(q && k && vt && tk && tvt && tbias && tgate && out, "lt_op_attention_fused: null pointer");
-    LT_REQUIRE(attention_fuses_text(hd), "lt_op_attention_fused: needs head_dim 72 and attention_variant 3");
+    LT_REQUIRE(attention_fuses_text(hd), "lt_op_attention_fused: needs head_dim 72 or 96 and attention_variant 3");
     AttnArgs a;
     a.q = (const u16*)q; a.k = (const u16*)k; a.vt = (const u16*)vt; a.bias = nullptr; a.out = (u16*)out; a.gate = nullptr;
     a.accumulate = 0; a.B = B; a.H = H; a.Hkv = Hkv; a.N = N; a.Nk = Nk; a.Nkpad = Nkpad; a.hd = hd; a.scale = 1.f; a.k_prescaled = 1;

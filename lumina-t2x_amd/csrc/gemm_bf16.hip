@@ -36,6 +36,9 @@ template __global__ void gemm_bf16_w4p<0, true>(GemmArgs);        // persistent 
 template __global__ void gemm_bf16_w4p<1, true>(GemmArgs);        // ... the dense SwiGLU GEMM (default)
 template __global__ void gemm_bf16_w4p<0>(GemmArgs);              // variant 13 (epilogue as its own phase)
 template __global__ void gemm_bf16_w4p<1>(GemmArgs);
+template __global__ void gemm_bf16_w4q<0, 8>(GemmArgs);           // persistent 4 waves on 16x16x32 MFMAs: 256 x 256 tiles
+template __global__ void gemm_bf16_w4q<0, 9>(GemmArgs);           // ... 256 x 288 tiles (N = 2304 / 6912: whole rounds over 256 CUs)
+template __global__ void gemm_bf16_w4q<1, 8>(GemmArgs);           // ... SwiGLU
 template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0, false, 0, 1, 4>(GemmArgs);  // 128 x 128, small-M problems, one barrier per 64-deep slab
 template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1, false, 0, 1, 4>(GemmArgs);  // 128 x 128 with the SwiGLU epilogue (needs NT even)
 template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0, false, 0, 1, 4>(GemmArgs);  //  64 x 128
@@ -45,6 +48,7 @@ namespace {
 using lt_gemm::gemm_bf16_tn;
 using lt_gemm::gemm_bf16_pp;
 using lt_gemm::gemm_bf16_w4p;
+using lt_gemm::gemm_bf16_w4q;
 
 // w1/w3 -> 32-row interleaved packed weight (row P: block = P/64; P%64 < 32 -> w1 else w3)
 __global__ void pack_w13_kernel(const u16* __restrict__ w1, const u16* __restrict__ w3, u16* __restrict__ out,
@@ -116,10 +120,27 @@ int launch_w4p(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     return 0;
 }
 
+template <int EPI, int NW16>
+int launch_w4q(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    constexpr int BN = 32 * NW16, SMEM = 4 * (256 + BN) * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4q<EPI, NW16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_done = true;
+    }
+    const int tiles = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN);
+    const int cus = num_cus();
+    const dim3 grid(tiles < cus ? tiles : cus), block(256);
+    if (ev0) hipExtLaunchKernelGGL((gemm_bf16_w4q<EPI, NW16>), grid, block, SMEM, stream, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((gemm_bf16_w4q<EPI, NW16>), grid, block, SMEM, stream, a);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- kernel selection (one place: launch_gemm_bf16 launches what choose() names, lt_gemm_describe prints it) -------------
 enum GemmKernel {
     GK_TN256, GK_TN288, GK_TN256_VT, GK_TN288_VT, GK_TN256_SWIGLU, GK_PP256, GK_PP256_SWIGLU, GK_W4P, GK_W4P_SWIGLU,
-    GK_W4P13, GK_W4P13_SWIGLU, GK_S128, GK_S128_SWIGLU, GK_S64, GK_EXPERIMENTAL, GK_NONE
+    GK_W4P13, GK_W4P13_SWIGLU, GK_S128, GK_S128_SWIGLU, GK_S64, GK_W4Q256, GK_W4Q288, GK_W4Q256_SWIGLU, GK_EXPERIMENTAL, GK_NONE
 };
 const char* const kGemmKernelName[] = {
     "gemm_bf16_tn<2,4,4,2,0> (256x256, 8 waves)", "gemm_bf16_tn<4,3,2,3,0> (256x288, 12 waves)",
@@ -128,18 +149,26 @@ const char* const kGemmKernelName[] = {
     "gemm_bf16_pp<2,4,4,2,1> (256x256 ping-pong, SwiGLU)", "gemm_bf16_w4p<0,true> (persistent 4x(128x128))",
     "gemm_bf16_w4p<1,true> (persistent 4x(128x128), SwiGLU)", "gemm_bf16_w4p<0,false>", "gemm_bf16_w4p<1,false>",
     "gemm_bf16_pp<2,4,2,1,0,..,1,4> (128x128)", "gemm_bf16_pp<4,2,1,2,1,..,1,4> (128x128, SwiGLU)",
-    "gemm_bf16_pp<2,4,1,1,0,..,1,4> (64x128)", "experimental", "none"};
+    "gemm_bf16_pp<2,4,1,1,0,..,1,4> (64x128)", "gemm_bf16_w4q<0,8> (persistent 4 waves, 16x16x32 MFMA, 256x256)",
+    "gemm_bf16_w4q<0,9> (persistent 4 waves, 16x16x32 MFMA, 256x288)", "gemm_bf16_w4q<1,8> (persistent 4 waves, 16x16x32 MFMA, 256x256, SwiGLU)",
+    "experimental", "none"};
 
 int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 256x256, 2 = 256x288
 int g_gemm_swiglu_w4p = 1;  // 1: dense SwiGLU GEMMs with >= 2 tile rounds run on the persistent 4-wave kernel (default)
 int g_gemm_stagger = 0;
+int g_gemm_w4q = 1;  // 1 (default): large dense GEMMs (>= one tile per CU) run on the persistent 16x16x32 kernel (256 / 288-wide tiles)
 
 // variant: 0 = auto; 1 / 2 = 256x256 / 256x288 classic loop; 3 = 256x256 8-wave ping-pong; 7 / 8 = 128x128 / 64x128 small-M tiles;
 //          13 / 14 = persistent 4 waves x (128 x 128) (14: a tile's epilogue rides in the next tile's first slab);
+//          15 / 16 = persistent 4 waves on 16x16x32 MFMAs, 256x256 / 256x288 tiles;
 //          4, 5, 6, 9, 10, 11, 12 = experimental builds only
 GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     const bool w4p_ok = !a.tile_expert && !a.trace && a.bias_dtype < 0 && a.K % 64 == 0 && a.K >= 128 &&
                         255LL * a.ldc * 2 + (long long)a.N * 2 < 0x7fffffffLL && epilogue != 2;
+    if (variant == 15 || variant == 16) {
+        if (!w4p_ok || (epilogue == 1 && variant == 16)) return GK_NONE;
+        return epilogue == 1 ? GK_W4Q256_SWIGLU : (variant == 15 ? GK_W4Q256 : GK_W4Q288);
+    }
     if (variant == 13) return w4p_ok ? (epilogue == 1 ? GK_W4P13_SWIGLU : GK_W4P13) : GK_NONE;
     if (variant == 14) return w4p_ok ? (epilogue == 1 ? GK_W4P_SWIGLU : GK_W4P) : GK_NONE;
     if (a.trace || variant == 4 || variant == 5 || variant == 6 || (variant >= 9 && variant <= 12)) return GK_EXPERIMENTAL;
@@ -161,6 +190,11 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     if (small) {
         if (epilogue == 1) return GK_S128_SWIGLU;
         return (variant == 8 || (variant == 0 && 2 * t128 <= cus)) ? GK_S64 : GK_S128;
+    }
+    if (variant == 0 && g_gemm_variant == 0 && g_gemm_w4q && w4p_ok && t256 >= cus) {
+        if (epilogue == 1) return GK_W4Q256_SWIGLU;
+        const long long t288 = (long long)((a.M + 255) / 256) * ((a.N + 287) / 288);
+        return ((t288 + cus - 1) / cus) * 288 < ((t256 + cus - 1) / cus) * 256 ? GK_W4Q288 : GK_W4Q256;
     }
     if (epilogue == 1) {
         if (variant == 1) return GK_TN256_SWIGLU;
@@ -186,6 +220,7 @@ int launch_gemm_experimental(const GemmArgs& a, int epilogue, int variant, hipSt
 
 void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
 void lt_set_gemm_swiglu_w4p(int v) { g_gemm_swiglu_w4p = v; }
+void lt_set_gemm_w4q(int v) { g_gemm_w4q = v; }
 int lt_set_gemm_stagger(int v) { g_gemm_stagger = v; return 0; }
 bool lt_gemm_has_experimental() {
 #ifdef LT_EXPERIMENTAL
@@ -212,7 +247,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     }
     LT_REQUIRE(epilogue != 1 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 14, "gemm: unknown variant %d", variant);
+    LT_REQUIRE(variant >= 0 && variant <= 16, "gemm: unknown variant %d", variant);
     const GemmKernel k = choose(a, epilogue, variant);
     switch (k) {
         case GK_TN256: return launch_cfg<2, 4, 4, 2, 0, false>(a, stream, ev0, ev1);
@@ -229,6 +264,9 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         case GK_S128: return launch_cfg<2, 4, 2, 1, 0, true, 1, 4>(a, stream, ev0, ev1);
         case GK_S128_SWIGLU: return launch_cfg<4, 2, 1, 2, 1, true, 1, 4>(a, stream, ev0, ev1);
         case GK_S64: return launch_cfg<2, 4, 1, 1, 0, true, 1, 4>(a, stream, ev0, ev1);
+        case GK_W4Q256: return launch_w4q<0, 8>(a, stream, ev0, ev1);
+        case GK_W4Q288: return launch_w4q<0, 9>(a, stream, ev0, ev1);
+        case GK_W4Q256_SWIGLU: return launch_w4q<1, 8>(a, stream, ev0, ev1);
         case GK_EXPERIMENTAL:
 #ifdef LT_EXPERIMENTAL
             return launch_gemm_experimental(a, epilogue, variant, stream, ev0, ev1);

@@ -1039,4 +1039,245 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmArgs p) {
     wait_vmcnt<0>();  // no LDS-DMA (the null ones of the last bodies included) may outlive the workgroup's LDS allocation
 }
 
+
+// ---- persistent 4-wave kernel on 16x16x32 MFMAs: 256 x 256 or 256 x 288 tiles (variants 15 / 16) ----------------------------------
+// What round 2's measurements asked for (profiles/r02/opbench_gemm_probe.log): the 4-wave kernels run their main loop
+// at 0.65-0.8 us per 256x256x32 slab (1.3-1.65 PFLOP/s) and the persistent form carries it across tiles, but with 32x32 MFMAs a
+// wave's 128-column half tile only comes in multiples of 32 columns, i.e. 256-wide tiles - and 8192 x 6912 / 2304 (QKV, O, W2 of the
+// 2B model) are 3.375 / 1.125 rounds of 256-wide tiles over 256 CUs.  With v_mfma_f32_16x16x32_bf16 the wave tile is 128 x 144 just as
+// well (8 x 9 accumulator tiles of 4 registers = 288 AGPRs, fragments double-buffered in 136 VGPRs): 256 x 288 tiles make those
+// shapes exactly 3 / 1 tiles per CU.  Structure = gemm_bf16_w4p (one workgroup per CU walks its tiles; 4-slot LDS ring of 32-deep
+// slabs filled by LDS-DMA three slabs ahead, running across tile boundaries; fragments of slab g+1 read while slab g multiplies;
+// one barrier per slab; epilogue stores issued and not waited for), with these differences:
+//  * one MFMA covers the slab's whole depth (K = 32): 8 x NT MFMAs of 16 cycles per slab, one fragment read per MFMA in the first
+//    8 + NT of them, one LDS-DMA per 8 MFMAs;
+//  * a 16-row fragment read (lane l: row l & 15, 16-byte chunk l >> 4 of the 64-byte row) is bank-conflict free when chunk c of row
+//    r sits at position c ^ (3 * ((r >> 3) & 1)) - on the LDS-DMA's source address and on the read (guide rule 21);
+//  * D' = W_frag x A_frag puts 4 consecutive columns of one C row in a lane; v_permlane16_swap of two neighbouring accumulator
+//    tiles widens that to 8 consecutive columns = one 16-byte store per lane and tile pair;
+//  * accumulation order inside a slab differs from the 32x32x16 kernels (one K = 32 MFMA instead of two K = 16), so results are
+//    equal to fp32 rounding, not bit-identical to variant 1.
+// EPI 1 (SwiGLU) needs NT % 4 == 0 (w1 / w3 interleaved in 32-row groups = pairs of 16-column tiles).  K % 64 == 0, K >= 128, no bias.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+template <int EPI, int NW16>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
+    constexpr int MT = 8, NT = NW16, NW = 4, BM = 256, BN = 2 * NW16 * 16;
+    constexpr int PA = BM / 16, PW = BN / 16, NP = PA + PW;   // 1-KiB staging pieces (16 rows x 64 B) per slab
+    constexpr int IP = (NP + NW - 1) / NW;                    // pieces per wave and slab (a surplus slot re-loads the wave's last piece)
+    constexpr int SLAB = (BM + BN) * 64, W_OFF = BM * 64;
+    constexpr int NM = MT * NT, RD = MT + NT, EVERY = NM / IP;
+    constexpr bool SPLIT_ACC = NM * 4 > 256;  // more accumulator registers than AGPRs
+    constexpr int NST = EPI == 0 ? MT * (NT / 2) + (NT % 2 ? MT : 0) : MT * (NT / 4);  // store instructions per wave and tile
+    static_assert(NM % IP == 0 && RD <= NM, "one LDS-DMA per EVERY MFMAs, one fragment read per MFMA in the first RD");
+    static_assert(EPI == 0 || NT % 4 == 0, "SwiGLU pairs 32-column groups");
+    static_assert(PA % NW == 0, "A pieces first: slot i < PA / NW is an A piece for every wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    const int ntiles = TM * TN;
+    const int ns = p.K / 32;
+
+    // staging: wave w copies pieces w + 4 i; piece q < PA = A rows 16 q .., else W rows 16 (q - PA) ..; lane -> row lane >> 2, 16-byte
+    // position lane & 3, fetched from source chunk pos ^ (3 * ((row >> 3) & 1))
+    const int sswz = ((lane & 3) ^ (((lane >> 5) & 1) * 3)) * 16;
+    static_assert(IP <= 9, "staging slots per wave");
+    int voff[9], ldsoff[9];  // fixed size: a dependent bound here breaks host-side substitution (hipcc 7.2)
+#pragma unroll
+    for (int i = 0; i < IP; ++i) {
+        int q = wave + NW * i;
+        if (q >= NP) q -= NW;
+        const bool isA = i < PA / NW;
+        const int r0 = 16 * (isA ? q : q - PA) + (lane >> 2);
+        voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + sswz;
+        ldsoff[i] = q * 1024;
+    }
+    const int ncols_out = EPI == 0 ? p.N : p.N / 2;
+    struct Tile { const u16* a; const u16* w; u16* c; int a_bytes, w_bytes, c_bytes, n0; };
+    auto setup = [&](int v) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_coords(v, ntiles, TM, TN, tm, tn);
+        const int m0 = tm * BM, n0_ = tn * BN;
+        const long long a_left = (long long)(p.M - m0) * p.lda * 2;
+        const long long w_left = (long long)(p.N - n0_) * p.ldw * 2;
+        const long long c_left = (long long)(p.M - m0) * p.ldc * 2;
+        Tile t;
+        t.a = p.A + (size_t)m0 * p.lda; t.w = p.W + (size_t)n0_ * p.ldw; t.c = p.C + (size_t)m0 * p.ldc;
+        t.a_bytes = (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left);
+        t.w_bytes = (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left);
+        t.c_bytes = (int)(c_left > 0x7fffffffLL ? 0x7fffffffLL : c_left);
+        t.n0 = n0_;
+        return t;
+    };
+    const Tile t_null = {p.A, p.W, p.C, 0, 0, 0, 0};  // no next tile: the last bodies' DMAs read nothing (all lanes out of range)
+
+    // fragment reads: lane -> row l15 of the 16-row tile, chunk q4 (swizzled)
+    const int csw = (q4 ^ (((l15 >> 3) & 1) * 3)) << 4;
+    const int a_row_off = (wm * (MT * 16) + l15) * 64 + csw;          // + mt * 1024
+    const int w_row_off = W_OFF + (wn * (NT * 16) + l15) * 64 + csw;  // + nt * 1024
+
+    f32x4 acc[MT][NT];
+    bf16x8 wf[NT], af[MT], wf2[NT], af2[MT];
+
+    int v = blockIdx.x;
+    if (v >= ntiles) return;  // uniform
+    const int my_tiles = (ntiles - 1 - v) / (int)gridDim.x + 1;
+    Tile cur = setup(v);
+    bool has_next = v + (int)gridDim.x < ntiles;
+    Tile nxt = has_next ? setup(v + gridDim.x) : t_null;
+
+    auto stage_from = [&](int g, int slab_in_tile, const Tile& t) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)t.a, 0, t.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)t.w, 0, t.w_bytes, 0x00020000);
+        char* base = smem + (g & 3) * SLAB;
+        const int soff = slab_in_tile * 64;
+#pragma unroll
+        for (int i = 0; i < IP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, voff[i], soff, 0, 0);
+    };
+    stagger_start(p.stagger);
+    // prologue (once per workgroup): slabs 0..2 in flight, slab 0 read into the first fragment set, slab 1 landed and visible
+    stage_from(0, 0, cur);
+    stage_from(1, 1, cur);
+    stage_from(2, 2, cur);
+    wait_vmcnt<2 * IP>();
+    pp_barrier();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(smem + w_row_off + nt * 1024);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf16x8*)(smem + a_row_off + mt * 1024);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    wait_vmcnt<IP>();
+    pp_barrier();
+
+    int g = 0;               // global slab index of the stream
+    bool after_epilogue = false;
+    // one slab: MFMAs of slab g from (wc, ac) | fragment reads of slab g+1 into (wn_, an) | LDS-DMA of the slab three ahead
+    auto body = [&](int s3, bf16x8 (&wc)[NT], bf16x8 (&ac)[MT], bf16x8 (&wn_)[NT], bf16x8 (&an)[MT]) __attribute__((always_inline)) {
+        const bool own = s3 < ns;  // past the tile's end: slab s3 - ns of the next tile
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(own ? cur.a : nxt.a), 0, own ? cur.a_bytes : nxt.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(own ? cur.w : nxt.w), 0, own ? cur.w_bytes : nxt.w_bytes, 0x00020000);
+        const char* sb = smem + ((g + 1) & 3) * SLAB;
+        char* db = smem + ((g + 3) & 3) * SLAB;
+        const int soff = (own ? s3 : s3 - ns) * 64;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int mt = i / NT, nt = i % NT;
+            if constexpr (SPLIT_ACC) {
+                // 288 accumulator registers do not fit the 256 AGPRs: tiles 0..63 live there, the last 8 in arch VGPRs (the VGPR
+                // form of the instruction).  Written as inline assembly so that each accumulator has ONE home - with the builtin
+                // the compiler bounced the overflow tiles through a[80:83] around every MFMA (100 v_accvgpr_read + 96 _write per
+                // slab pair: 272 us instead of 216 us on the QKV GEMM); the written order is pinned by scheduling fences
+                if (i < 64) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
+            } else {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], ac[mt], acc[mt][nt], 0, 0, 0);
+            }
+            if (i < NT) wn_[i] = *(const bf16x8*)(sb + w_row_off + i * 1024);
+            else if (i < RD) an[i - NT] = *(const bf16x8*)(sb + a_row_off + (i - NT) * 1024);
+            if (i % EVERY == EVERY - 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(i / EVERY < PA / NW ? rA : rW, LDS_PTR(db + ldsoff[i / EVERY]), 16, voff[i / EVERY], soff, 0, 0);
+            if constexpr (SPLIT_ACC) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!SPLIT_ACC) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {  // pin the written interleave
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                if (i < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (i % EVERY == EVERY - 1) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): slab g+1's fragments are in registers
+        // slab g+2 landed; still allowed in flight: this body's IP DMAs and, right after a tile boundary, the NST stores issued
+        // between slab g+2's DMAs and them (loads and stores retire in issue order, one counter)
+        if (after_epilogue) wait_vmcnt<IP + NST>();
+        else wait_vmcnt<IP>();
+        after_epilogue = false;
+        pp_barrier();
+        ++g;
+    };
+    // epilogue through the tile's C descriptor (rows past M fall outside num_records, columns past N get an out-of-range offset):
+    // every wave issues exactly NST store instructions per tile.  Lane holds, per 16x16 accumulator tile, C row l15 and columns
+    // 4 q4 + r (register r).
+    auto store_out = [&](const Tile& t) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)t.c, 0, t.c_bytes, 0x00020000);
+        const int nbase = t.n0 + wn * (NT * 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row_off = (wm * (MT * 16) + mt * 16 + l15) * p.ldc * 2;  // bytes from the tile's first C row (< 2^31: launcher)
+            if constexpr (EPI == 0) {
+#pragma unroll
+                for (int np = 0; np < NT / 2; ++np) {
+                    const f32x4 a = acc[mt][2 * np], b = acc[mt][2 * np + 1];
+                    const unsigned a0 = pack2bf_pk(a[0], a[1]), a1 = pack2bf_pk(a[2], a[3]);
+                    const unsigned b0 = pack2bf_pk(b[0], b[1]), b1 = pack2bf_pk(b[2], b[3]);
+                    auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    // lane rows 0 / 2 hold tile 2 np, columns 0..7 / 8..15; lane rows 1 / 3 tile 2 np + 1
+                    const int col = nbase + (2 * np + (q4 & 1)) * 16 + (q4 >> 1) * 8;
+                    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                    const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rC, off, 0, 0);
+                }
+                if constexpr (NT % 2 == 1) {  // the unpaired last tile: 8 bytes per lane
+                    const f32x4 a = acc[mt][NT - 1];
+                    const u32x2_t o = {pack2bf_pk(a[0], a[1]), pack2bf_pk(a[2], a[3])};
+                    const int col = nbase + (NT - 1) * 16 + 4 * q4;
+                    const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rC, off, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT / 4; ++j) {  // 64 input columns = 32 of w1 | 32 of w3 -> 32 output columns
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const f32x4 x = acc[mt][4 * j + u], y = acc[mt][4 * j + 2 + u];
+                        float vv[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)  // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
+                            vv[r] = bfr(silu_f(bfr(x[r]))) * bfr(y[r]);
+                        pk[u][0] = pack2bf_pk(vv[0], vv[1]);
+                        pk[u][1] = pack2bf_pk(vv[2], vv[3]);
+                    }
+                    auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                    const int col = nbase / 2 + j * 32 + (q4 & 1) * 16 + (q4 >> 1) * 8;
+                    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                    const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rC, off, 0, 0);
+                }
+            }
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (has_next) {
+            cur = nxt;
+            v += gridDim.x;
+            has_next = v + (int)gridDim.x < ntiles;
+            nxt = has_next ? setup(v + gridDim.x) : t_null;
+        }
+    };
+    for (int t = 0; t < my_tiles; ++t) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < ns; s += 2) {  // slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
+            body(s + 3, wf, af, wf2, af2);
+            body(s + 4, wf2, af2, wf, af);
+        }
+        store_out(cur);
+        after_epilogue = true;
+        advance();
+    }
+    wait_vmcnt<0>();  // no LDS-DMA (the null ones of the last bodies included) may outlive the workgroup's LDS allocation
+}
+
 }  // namespace lt_gemm

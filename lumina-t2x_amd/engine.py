@@ -261,6 +261,10 @@ class DiTEngine:
     def last_nfe(self) -> int:
         return int(self.lib.lt_last_nfe(self.handle))
 
+    def graph_replays(self) -> int:
+        """model evaluations served by a captured HIP graph so far"""
+        return int(self.lib.lt_graph_replays(self.handle))
+
     # ---- profiling hooks used by bench.py -----------------------------------------------------------
     def profile_enable(self, on) -> None:
         """False / 0: off; True: every kernel class; int: bit mask (1 GEMM, 2 attention, 4 other)"""

@@ -57,6 +57,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="*", default=["cfg1", "cfg5", "cfg4"])
     ap.add_argument("--nfe", type=int, default=8)
+    ap.add_argument("--pairs", type=int, default=1, help="cfg1 / cfg5: image pairs per call (rows = 2 x pairs <= 8; every kernel is "
+                    "row-parallel, so batching amortises the latency-bound launches of a 256-token image)")
     ap.add_argument("--opt", action="append", default=[])
     a = ap.parse_args()
     for opt in a.opt:
@@ -70,20 +72,20 @@ def main():
             with torch.device(dev):
                 m = models.imagenet.DiT_Llama_600M_patch2(qk_norm=True).to(torch.bfloat16)
             random_init_(m, 0)
-            z = torch.randn(1, 4, 32, 32, device=dev, generator=g).repeat(2, 1, 1, 1)  # fp32 state (BASELINE: fp32 for cfg 1)
-            y = torch.tensor([207, 1000], device=dev)
+            z = torch.randn(a.pairs, 4, 32, 32, device=dev, generator=g).repeat(2, 1, 1, 1)  # fp32 state (BASELINE: fp32 for cfg 1)
+            y = torch.tensor([207] * a.pairs + [1000] * a.pairs, device=dev)
             ms = timed(m.eval(), z, a.nfe, 2, y=y, cfg_scale=4.0)
-            fl = flops_per_nfe(synth.IMAGENET_600M, 256, 0, 2)
-            toks = 256
+            fl = flops_per_nfe(synth.IMAGENET_600M, 256, 0, 2 * a.pairs)
+            toks = 256 * a.pairs
         elif which == "cfg5":
             with torch.device(dev):
                 m = models.moe.DiT_Llama_600M_patch2_Both(qk_norm=True).to(torch.bfloat16)
             random_init_(m, 0)
-            z = torch.randn(1, 4, 32, 32, device=dev, generator=g).to(torch.bfloat16).repeat(2, 1, 1, 1)
-            y = torch.tensor([207, 1000], device=dev)
+            z = torch.randn(a.pairs, 4, 32, 32, device=dev, generator=g).to(torch.bfloat16).repeat(2, 1, 1, 1)
+            y = torch.tensor([207] * a.pairs + [1000] * a.pairs, device=dev)
             ms = timed(m.eval(), z, a.nfe, 2, y=y, cfg_scale=4.0)
-            fl = 1.41e12  # SURVEY.md 8d (both-MoE, 600 M dims, N = 256)
-            toks = 256
+            fl = 1.41e12 * a.pairs  # SURVEY.md 8d (both-MoE, 600 M dims, N = 256)
+            toks = 256 * a.pairs
         elif which == "cfg4":
             with torch.device(dev):
                 m = models.NextDiT_2B_GQA_patch2(qk_norm=True, cap_feat_dim=2048).to(torch.bfloat16)
@@ -106,6 +108,8 @@ def main():
             toks = 4160
         else:
             raise SystemExit(f"unknown config {which}")
+        if which in ("cfg1", "cfg5") and a.pairs > 1:
+            which = f"{which} x{a.pairs} pairs ({ms / a.pairs:.3f} ms/NFE per pair)"
         print(f"{which}: {ms:9.3f} ms/NFE  {1e3 / ms:8.2f} NFE/s  {toks / ms * 1e3:12.0f} latent-tokens/s  "
               f"{fl / ms / 1e9:8.1f} model TFLOP/s", flush=True)
         del m

@@ -384,3 +384,41 @@ def test_engine_packed_variable_resolution_vs_reference_list_path(golden_dir, dt
     assert rel_l2(yp[short], torch.from_numpy(g[f"solo_prop{short}"])) > rel_l2(yp[short], torch.from_numpy(g[f"yprop{short}"]))
     with pytest.raises(TypeError):
         model.forward_with_cfg(xs, t, cap, mask, 4.0)
+
+
+def test_hip_graph_replay_is_bit_identical_to_eager_launches(golden_dir):
+    """lt_set_option("graph", 1) (default): the third evaluation with one set of arguments replays a captured HIP graph of the
+    ~250 launches.  Replays must be bit-identical to eager launches, pick up NEW inputs / prompts / weights
+    (contents sit behind fixed pointers), and a change of arguments must start a new graph, not reuse the old one."""
+    from gpu_util import set_option
+    g, cfg = _golden(golden_dir, "nextdit_tiny")
+    model = _model(cfg, int(g["seed_w"]))
+    t = torch.from_numpy(g["t"]).cuda()
+    cap, mask = torch.from_numpy(g["cap"]).to("cuda", torch.bfloat16), torch.from_numpy(g["mask"]).cuda()
+    gen = torch.Generator().manual_seed(4)
+    xs = [torch.randn(1, 4, 16, 16, generator=gen).repeat(2, 1, 1, 1).to("cuda", torch.bfloat16) for _ in range(5)]
+    kw = dict(base_seqlen=16, proportional_attn=True)
+
+    def runs():
+        outs = [model.forward_with_cfg(x, t, cap, mask, 4.0, **kw) for x in xs]                  # one key, five inputs
+        outs.append(model.forward_with_cfg(xs[0], t, cap, mask, 2.5, **kw))                     # other cfg scale: other key
+        outs.append(model.forward_with_cfg(xs[1], t * 0.5, cap, mask, 4.0, **kw))               # other time: same key, new t
+        cap2 = (cap * 0.5).contiguous()
+        outs.append(model.forward_with_cfg(xs[2], t, cap2, mask, 4.0, **kw))                    # new prompt, same shapes: same key
+        fn = Sampler(create_transport()).sample_ode(sampling_method="midpoint", num_steps=4, time_shifting_factor=4)
+        outs.append(fn(xs[3], model.forward_with_cfg, cap_feats=cap, cap_mask=mask, cfg_scale=4.0, **kw))
+        return outs
+
+    try:
+        set_option("graph", 1)
+        before = model._engine.graph_replays() if model._engine is not None else 0
+        with_graph = runs()
+        replays = model._engine.graph_replays() - before
+        set_option("graph", 0)
+        eager = runs()
+        assert model._engine.graph_replays() - before == replays  # no replay while switched off
+    finally:
+        set_option("graph", 1)
+    assert replays >= 8, replays  # 5 + 1 + 1 + 6 evaluations on the main key, minus warm-up and capture
+    for a, b in zip(with_graph, eager):
+        assert torch.equal(a, b)

@@ -81,7 +81,7 @@ def test_gemm_tile_variants(variant, M, N, K):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("variant", _variant_params() + [13, 14])
+@pytest.mark.parametrize("variant", _variant_params() + [13, 14, 15, 16])
 def test_gemm_identity_asymmetric(variant):
     """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
     _skip_unless_built(variant)
@@ -107,11 +107,11 @@ def test_gemm_bias_and_edges():
     assert torch.all(big[200:] == 7.0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 7, 14])  # auto, classic loop, 8-wave ping-pong, small tiles, persistent 4 waves
+@pytest.mark.parametrize("variant", [0, 1, 3, 7, 14, 15])  # auto, classic loop, 8-wave ping-pong, small tiles, persistent 4 waves (32x32 / 16x16 MFMA)
 @pytest.mark.parametrize("M,F_,K", [(256, 128, 64), (300, 1536, 576), (4096, 6144, 2304), (8192, 6144, 2304)])
 def test_gemm_swiglu(M, F_, K, variant):
-    if variant == 14 and K < 128:
-        pytest.skip("persistent 4-wave kernel: K >= 128")
+    if variant in (14, 15) and K < 128:
+        pytest.skip("persistent 4-wave kernels: K >= 128")
     g = torch.Generator().manual_seed(F_ + K)
     A = bf(torch.randn(M, K, generator=g))
     w1 = bf(torch.randn(F_, K, generator=g) / math.sqrt(K))
@@ -176,6 +176,29 @@ def test_gemm_4wave_persistent(M, N, K, epi, variant):
             assert torch.equal(_gemm(A, W, None, epi, variant=variant), ref)
         finally:
             set_option("gemm_stagger", 0)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(8192, 12288, 2304, 1), (8300, 6912, 2304, 0), (2100, 1280, 128, 1), (512, 512, 128, 0),
+                                       (300, 576, 192, 0), (16384, 2304, 6144, 0), (70000, 520, 256, 0), (256, 131072, 128, 1),
+                                       (8320, 3072, 3072, 0), (8192, 2304, 2304, 0)])
+@pytest.mark.parametrize("variant", [15, 16])
+def test_gemm_4wave_persistent_16x16x32(M, N, K, epi, variant):
+    """gemm_bf16_w4q: the persistent 4-wave structure on v_mfma_f32_16x16x32_bf16 with 256-wide (15) or 288-wide (16) tiles -
+    XOR-swizzled 16-row fragment reads, v_permlane16_swap epilogue, ragged M / N against both tile widths, several tiles per
+    CU and fewer tiles than CUs, K = 128 (four slabs).  One K = 32 MFMA per slab instead of two K = 16 ones: equal to the classic
+    kernel up to fp32 summation order (compared after the same bf16 rounding), and to the fp32 reference at the GEMM tolerance."""
+    if epi == 1 and variant == 16:
+        pytest.skip("SwiGLU pairs 32-column groups: 256-wide tiles only")
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    got = _gemm(A, W, None, epi, variant=variant)
+    ref = _gemm(A, W, None, epi, variant=1)
+    assert not torch.isnan(got.float()).any(), "unwritten outputs"
+    assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
+    assert float((got.float() != ref.float()).float().mean()) < 0.05  # different summation order flips the odd last bit, no more
+    if epi == 0:
+        assert rel_l2(got, A.float() @ W.float().t()) < 4e-3
 
 
 @pytest.mark.parametrize("tokens,B,kvh,hd,K,variant", [(4096, 2, 32, 72, 2304, 0), (64, 3, 2, 72, 128, 1), (128, 2, 8, 72, 576, 2),
@@ -415,7 +438,10 @@ def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None, fold_scale=False)
 @pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("B,H,Hkv,N,hd", [(1, 8, 8, 128, 72), (2, 8, 2, 320, 72), (2, 4, 4, 200, 72), (1, 3, 3, 64, 72),
                                           (2, 32, 32, 4096, 72), (1, 8, 8, 256, 48), (1, 8, 8, 192, 96),
-                                          (1, 8, 8, 1000, 72), (1, 2, 2, 40, 72)])
+                                          (1, 8, 8, 1000, 72), (1, 2, 2, 40, 72),
+                                          # hd 96 (Flag-DiT 5B): variant 3 = the ping-pong kernel with VALU-side max / row sum and the
+                                          # XOR-swizzled K image; 4160 = 64 rows x 65 tokens (cfg 3), ragged tails, GQA, one tile
+                                          (2, 32, 32, 4160, 96), (2, 8, 2, 321, 96), (1, 4, 4, 1000, 96), (1, 3, 3, 64, 96), (1, 2, 2, 40, 96)])
 @pytest.mark.parametrize("fold", [False, True])
 def test_attention_self(variant, B, H, Hkv, N, hd, fold):
     set_option("attention_variant", variant)
@@ -430,13 +456,14 @@ def test_attention_self(variant, B, H, Hkv, N, hd, fold):
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
 
 
+@pytest.mark.parametrize("hd", [72, 96])
 @pytest.mark.parametrize("variant", [1, 2, 3])
-def test_attention_softmax_outlier_keys(variant):
+def test_attention_softmax_outlier_keys(variant, hd):
     """forces large running-max jumps mid-sequence, above and below the deferred-rescale threshold (guide 5.4
-    rule 26); v1 (rescale every tile), v2 (threshold 8 in log2 units) and v3 (same threshold, max folded into the
-    QK^T MFMA as a bf16 pair) must all match the exact softmax"""
+    rule 26); v1 (rescale every tile), v2 (threshold 8 in log2 units) and v3 (same threshold; hd 72: max folded into the
+    QK^T MFMA as a bf16 pair, hd 96: explicit VALU max with O / l rescale) must all match the exact softmax"""
     set_option("attention_variant", variant)
-    B, H, N, hd = 1, 8, 256, 72
+    B, H, N = 1, 8, 256
     g = torch.Generator().manual_seed(9)
     q = bf(torch.randn(B, H, N, hd, generator=g))
     k = bf(torch.randn(B, H, N, hd, generator=g))
@@ -472,12 +499,12 @@ def test_attention_text_accumulate(variant, T, valid1, fold):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
+@pytest.mark.parametrize("hd", [72, 96])
 @pytest.mark.parametrize("B,H,Hkv,N,T,valid1", [(2, 8, 8, 320, 128, 8), (2, 8, 2, 200, 77, 30), (1, 4, 4, 4096, 256, 256),
                                                   (2, 4, 4, 96, 300, 130)])
-def test_attention_fused_text(B, H, Hkv, N, T, valid1):
+def test_attention_fused_text(B, H, Hkv, N, T, valid1, hd):
     """one launch = self-attention + gated text cross-attention (model.py:392-434), both K pre-scaled (engine path)"""
     set_option("attention_variant", 3)
-    hd = 72
     g = torch.Generator().manual_seed(N + T)
     q = bf(torch.randn(B, H, N, hd, generator=g))
     k = bf(torch.randn(B, Hkv, N, hd, generator=g))
