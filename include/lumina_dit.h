@@ -167,6 +167,8 @@ int64_t lt_graph_replays(lt_engine* e);
 /* class 0 = MFMA GEMM kernel, 1 = attention kernel, 2 = everything else.  When enabled, every
  * launch of that class is bracketed by HIP events on the launch stream. */
 int lt_profile_enable(lt_engine* e, int32_t on); /* 0 off, 1 all classes, else bit mask: 1 GEMM | 2 attention | 4 other (1 alone = all) */
+/* exact class selection: bit 0 GEMM, bit 1 attention, bit 2 everything else (mask 1 = GEMM launches ONLY; 0 = off) */
+int lt_profile_enable_mask(lt_engine* e, int32_t mask);
 /* after the caller synchronised the stream: total ms, launches and algorithmic flops per class */
 int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t* launches, double* flops);
 int lt_profile_reset(lt_engine* e);
@@ -174,6 +176,9 @@ int lt_profile_reset(lt_engine* e);
  * lt_profile_read scales the measured time to all launches: every NFE has the same launch mix); < 0 = no limit.
  * Event brackets serialise the queue (~1.4 ms per NFE when every launch is bracketed), so bench.py samples. */
 int lt_profile_set_budget(lt_engine* e, int32_t klass, int64_t max_event_launches);
+/* the same with the bracketed launches taken from the MIDDLE of a run: launches skip_launches .. skip_launches + max_event_launches
+ * after a reset (the first launches after an idle queue run in a different power state than the steady stream) */
+int lt_profile_set_window(lt_engine* e, int32_t klass, int64_t skip_launches, int64_t max_event_launches);
 
 /* ---- operator-level entry points (parity tests call each kernel through these) ---------------- */
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in/out, fp32 accumulate.  K % 64 == 0.

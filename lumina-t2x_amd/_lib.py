@@ -77,7 +77,9 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_profile_enable": (_i32, [_vp, _i32]),
     "lt_profile_read": (_i32, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "lt_profile_reset": (_i32, [_vp]),
+    "lt_profile_enable_mask": (_i32, [_vp, _i32]),
     "lt_profile_set_budget": (_i32, [_vp, _i32, _i64]),
+    "lt_profile_set_window": (_i32, [_vp, _i32, _i64, _i64]),
     "lt_op_gemm_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_vt": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_describe": (_i32, [_i32, _i32, _i32, _i32, _i32, C.c_char_p, _i32]),

@@ -7,6 +7,7 @@
 // Step-invariant work is hoisted: text K/V of all layers and the caption embedding are computed once per
 // prompt (lt_prepare_prompt); the adaLN vectors of all layers are one GEMV per NFE; the RoPE table is
 // a 2 x 384 x hd/4 (cos,sin) table rebuilt only when scale_factor changes.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -67,6 +68,7 @@ struct ProfClass {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
     size_t budget = (size_t)-1;  // bracket at most this many launches with events, count the rest (same launch mix every step)
+    long long skip = 0;          // ... starting with launch number `skip` after a reset (a window in the middle of a timed region)
 };
 
 }  // namespace
@@ -152,7 +154,9 @@ struct lt_engine {
     long long last_nfe = 0;
     // HIP graphs of one model evaluation (forward_graphed): fixed staging buffers the captured kernels read / write, a private
     // stream to capture on (the caller's stream may be the legacy null stream, which cannot capture), cached executables
-    struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int uses = 0; bool failed = false; };
+    struct GraphTally { double flops[3] = {0, 0, 0}; long long launches[3] = {0, 0, 0}; };  // what one replay stands for, per kernel class
+    struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int uses = 0; bool failed = false; GraphTally tally; };
+    GraphTally* tally = nullptr;  // set while a graph is being captured: ProfScope counts into it instead of timing
     std::vector<GraphEntry> graphs;
     void *g_x = nullptr, *g_out = nullptr;
     float* g_t = nullptr;
@@ -184,11 +188,16 @@ struct ProfScope {
     hipEvent_t ev0() const { return on ? e->prof[k].ev[slot].first : nullptr; }
     hipEvent_t ev1() const { return on ? e->prof[k].ev[slot].second : nullptr; }
     ProfScope(lt_engine* e_, int klass, double flops, hipStream_t s_, bool attach_ = false) : e(e_), k(klass), s(s_), attach(attach_) {
+        if (e->tally) {  // graph capture: no events inside a graph, only the bookkeeping a replay will add
+            e->tally->flops[k] += flops;
+            e->tally->launches[k] += 1;
+            return;
+        }
         if (!e->prof_on || !((e->prof_mask >> k) & 1)) return;
         ProfClass& pc = e->prof[k];
         pc.flops += flops;
         pc.launches += 1;
-        if (pc.used < pc.ev.size() && pc.used < pc.budget) {
+        if (pc.launches > pc.skip && pc.used < pc.ev.size() && pc.used < pc.budget) {
             on = true;
             slot = pc.used++;
             if (!attach) (void)hipEventRecord(pc.ev[slot].first, s);
@@ -662,8 +671,20 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
 // Kernel arguments are baked into a graph, so the key holds everything they depend on: the step arguments (shapes, cfg scale,
 // RoPE scaling, softmax scale inputs), the prompt dimensions, cfg on / off and the option generation.  Weights and prompt
 // CONTENTS live behind fixed pointers and may change freely.
+// profiling brackets launches with HIP events, which a graph cannot carry: while an enabled class still has event budget left the
+// evaluation runs eagerly; once the budgets are used up replays resume and only add their launch / flop counts (lt_profile_read
+// scales the measured time by launches / bracketed launches - every evaluation has the same launch mix)
+bool profiling_wants_events(const lt_engine* e) {
+    if (!e->prof_on) return false;
+    for (int k = 0; k < 3; ++k) {
+        const ProfClass& pc = e->prof[k];
+        if (((e->prof_mask >> k) & 1) && pc.used < std::min(pc.ev.size(), pc.budget)) return true;  // (also before the window opens)
+    }
+    return false;
+}
+
 int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* out, const lt_step_args* a, int use_cfg, hipStream_t s) {
-    if (!g_graph || e->prof_on) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+    if (!g_graph || profiling_wants_events(e)) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
     const int B = a->batch;
     if (B < 1 || B > e->cfg.max_batch || a->latent_h <= 0 || a->latent_w <= 0 || (a->io_dtype != LT_BF16 && a->io_dtype != LT_F32))
         return run_forward(e, x_in, t_dev, out, a, use_cfg, s);  // let the eager path produce the error message
@@ -693,7 +714,10 @@ int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* ou
         bool ok = hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
         int rc = 0;
         if (ok) {
+            ge->tally = lt_engine::GraphTally();
+            e->tally = &ge->tally;
             rc = run_forward(e, e->g_x, e->g_t, e->g_out, a, use_cfg, e->cap_stream);
+            e->tally = nullptr;
             ok = hipStreamEndCapture(e->cap_stream, &graph) == hipSuccess && rc == 0 && graph != nullptr;
         }
         if (ok) ok = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -711,6 +735,9 @@ int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* ou
     LT_CHECK_HIP(hipGraphLaunch(ge->exec, s));
     LT_CHECK_HIP(hipMemcpyAsync(out, e->g_out, sbytes, hipMemcpyDeviceToDevice, s));
     ++e->graph_replays;
+    if (e->prof_on)
+        for (int k = 0; k < 3; ++k)
+            if ((e->prof_mask >> k) & 1) { e->prof[k].flops += ge->tally.flops[k]; e->prof[k].launches += ge->tally.launches[k]; }
     return 0;
 }
 
@@ -1166,8 +1193,23 @@ extern "C" int lt_profile_enable(lt_engine* e, int32_t on) {
     return 0;
 }
 
+extern "C" int lt_profile_enable_mask(lt_engine* e, int32_t mask) {
+    LT_REQUIRE(e && mask >= 0 && mask <= 7, "lt_profile_enable_mask: mask 0..7");
+    if (lt_profile_enable(e, mask ? 7 : 0)) return 1;  // event pools; honours LT_NO_EVENT_PROFILE
+    if (e->prof_on) e->prof_mask = mask;
+    return 0;
+}
+
 extern "C" int lt_profile_set_budget(lt_engine* e, int32_t klass, int64_t max_event_launches) {
     LT_REQUIRE(e && klass >= 0 && klass < 3, "lt_profile_set_budget: bad class");
+    e->prof[klass].budget = max_event_launches < 0 ? (size_t)-1 : (size_t)max_event_launches;
+    e->prof[klass].skip = 0;
+    return 0;
+}
+
+extern "C" int lt_profile_set_window(lt_engine* e, int32_t klass, int64_t skip_launches, int64_t max_event_launches) {
+    LT_REQUIRE(e && klass >= 0 && klass < 3 && skip_launches >= 0, "lt_profile_set_window: bad arguments");
+    e->prof[klass].skip = skip_launches;
     e->prof[klass].budget = max_event_launches < 0 ? (size_t)-1 : (size_t)max_event_launches;
     return 0;
 }
@@ -1205,6 +1247,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_swiglu_w4p") == 0) { lt_set_gemm_swiglu_w4p(value != 0); return 0; }
     if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }
+    if (strcmp(name, "gemm_group") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_group must be 0..64"); lt_set_gemm_group(value); return 0; }
     if (strcmp(name, "gemm_stagger") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_stagger must be 0..64"); return lt_set_gemm_stagger(value); }
     if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }
     if (strcmp(name, "gemm_pipeline") == 0 || strcmp(name, "gemm_pp_tail") == 0 || strcmp(name, "gemm_persist") == 0) {

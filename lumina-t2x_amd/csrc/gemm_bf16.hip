@@ -156,6 +156,7 @@ const char* const kGemmKernelName[] = {
 int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 256x256, 2 = 256x288
 int g_gemm_swiglu_w4p = 1;  // 1: dense SwiGLU GEMMs with >= 2 tile rounds run on the persistent 4-wave kernel (default)
 int g_gemm_stagger = 0;
+int g_gemm_group = 0;
 int g_gemm_w4q = 1;  // 1 (default): large dense GEMMs (>= one tile per CU) run on the persistent 16x16x32 kernel (256 / 288-wide tiles)
 
 // variant: 0 = auto; 1 / 2 = 256x256 / 256x288 classic loop; 3 = 256x256 8-wave ping-pong; 7 / 8 = 128x128 / 64x128 small-M tiles;
@@ -222,6 +223,7 @@ void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
 void lt_set_gemm_swiglu_w4p(int v) { g_gemm_swiglu_w4p = v; }
 void lt_set_gemm_w4q(int v) { g_gemm_w4q = v; }
 int lt_set_gemm_stagger(int v) { g_gemm_stagger = v; return 0; }
+void lt_set_gemm_group(int v) { g_gemm_group = v; }
 bool lt_gemm_has_experimental() {
 #ifdef LT_EXPERIMENTAL
     return true;
@@ -235,6 +237,7 @@ const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant) { ret
 int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     GemmArgs a = a0;
     a.stagger = g_gemm_stagger;
+    a.group_rows = g_gemm_group;
     LT_REQUIRE(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue >= 0 && epilogue <= 2, "gemm: unknown epilogue %d", epilogue);

@@ -11,12 +11,11 @@ namespace {
 
 constexpr int BK = 64;
 
-__device__ __forceinline__ void tile_coords(int bid, int nwg, int TM, int TN, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords(int bid, int nwg, int TM, int TN, int& tm, int& tn, int G = 4) {
     const int NX = 8;
     const int xcd = bid % NX, idx = bid / NX;
     const int q = nwg / NX, r = nwg % NX;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int G = 4;
     const int per_group = G * TN;
     const int g = L / per_group;
     const int first_m = g * G;
@@ -1099,7 +1098,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     struct Tile { const u16* a; const u16* w; u16* c; int a_bytes, w_bytes, c_bytes, n0; };
     auto setup = [&](int v) __attribute__((always_inline)) {
         int tm, tn;
-        tile_coords(v, ntiles, TM, TN, tm, tn);
+        tile_coords(v, ntiles, TM, TN, tm, tn, p.group_rows > 0 ? p.group_rows : 4);
         const int m0 = tm * BM, n0_ = tn * BN;
         const long long a_left = (long long)(p.M - m0) * p.lda * 2;
         const long long w_left = (long long)(p.N - n0_) * p.ldw * 2;

@@ -20,6 +20,7 @@ struct GemmArgs {
     // epilogue 2 (V^T): C is the attention kernels' transposed, key-permuted V image [M / vt_tokens][N / vt_hd][vt_hd][vt_npad]
     // (AttnArgs::vt) instead of a row-major matrix: the V projection lands in the layout the PV MFMA reads, no transpose pass
     int vt_tokens = 0, vt_hd = 0, vt_npad = 0;
+    int group_rows = 0;  // experiment knob (lt_set_option "gemm_group"): tile rows per group of the XCD-aware tile order (0 = 4)
     int stagger = 0;  // experiment knob of the 4-wave kernels (lt_set_option "gemm_stagger"), filled by the launcher
 };
 // ev0 / ev1: optional start / stop events carried by the dispatch packet itself (profiling without extra queue packets)
@@ -124,6 +125,7 @@ void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
 void lt_set_gemm_w4q(int v);           // 1: large dense GEMMs on the persistent 16x16x32 kernel (variants 15 / 16)
 void lt_set_gemm_swiglu_w4p(int v);    // 1 (default): dense multi-round SwiGLU GEMMs on the persistent 4-wave kernel; 0: 8-wave ping-pong
+void lt_set_gemm_group(int v);          // tile rows per group in the tile order of the 16x16x32 kernel (experiment; 0 = default 4)
 int lt_set_gemm_stagger(int v);        // 4-wave kernels (variants 10, 13, 14): start-phase spread per XCD, units of ~1024 cycles (0 = off)
 bool lt_gemm_has_experimental();       // built with EXPERIMENTAL=1 (variants 4-6, 9-12, trace builds, pipeline knobs)
 const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant);  // name of the kernel launch_gemm_bf16 would run

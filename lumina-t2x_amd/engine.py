@@ -269,10 +269,13 @@ class DiTEngine:
     def profile_enable(self, on) -> None:
         """False / 0: off; True: every kernel class; int: bit mask (1 GEMM, 2 attention, 4 other)"""
         mask = 7 if on is True else int(on)
-        _lib.check(self.lib.lt_profile_enable(self.handle, mask), "lt_profile_enable")
+        _lib.check(self.lib.lt_profile_enable_mask(self.handle, mask), "lt_profile_enable_mask")
 
     def profile_set_budget(self, klass: int, max_event_launches: int) -> None:
         _lib.check(self.lib.lt_profile_set_budget(self.handle, klass, max_event_launches), "lt_profile_set_budget")
+
+    def profile_set_window(self, klass: int, skip_launches: int, max_event_launches: int) -> None:
+        _lib.check(self.lib.lt_profile_set_window(self.handle, klass, skip_launches, max_event_launches), "lt_profile_set_window")
 
     def profile_reset(self) -> None:
         _lib.check(self.lib.lt_profile_reset(self.handle), "lt_profile_reset")
