@@ -43,6 +43,7 @@ int g_qkv_post_fused = 0;
 int g_qkv_vt_epilogue = 1;
 // lt_set_option("graph"): 1 = a model evaluation (~250 launches) is captured into a HIP graph per (arguments, shapes) and replayed.
 // Every lt_set_option bumps g_option_gen, which is part of the graph key (kernel selection is baked into a captured graph).
+int g_qk_post_pair = 1;  // lt_set_option("qk_post_pair"): 1 = q and k post-processing share one persistent launch (large problems)
 int g_graph = 1;
 int g_option_gen = 0;
 
@@ -563,6 +564,9 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             pa.v_Npad = Npad; pa.v_kv_heads = Hkv; pa.v_hd = hd;
             if (g_qkv_post_fused && !vt_epi) {
                 if (launch_qkv_post(pa, s)) return 1;  // q, k post-processing and the V transpose in one launch
+            } else if (g_qk_post_pair && M >= 2048) {
+                if (launch_qk_norm_rope_pair(pa.q, pa.k, s)) return 1;  // q and k in one persistent launch
+                if (!vt_epi && launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
             } else {
                 if (launch_qk_norm_rope(pa.q, s)) return 1;
                 if (launch_qk_norm_rope(pa.k, s)) return 1;
@@ -1244,6 +1248,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 3, "attention_variant must be 1, 2 or 3"); lt_set_attention_variant(value); return 0; }
     if (strcmp(name, "qkv_post_fused") == 0) { g_qkv_post_fused = value != 0; return 0; }
     if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
+    if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_swiglu_w4p") == 0) { lt_set_gemm_swiglu_w4p(value != 0); return 0; }
     if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }

@@ -76,6 +76,7 @@ struct QkPostArgs {
     const int* grid_w_b = nullptr;
 };
 int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream);
+int launch_qk_norm_rope_pair(const QkPostArgs& q, const QkPostArgs& k, hipStream_t stream);  // both in one persistent launch
 int launch_v_transpose(const u16* src, int ld_src, int col0, u16* dst, int B, int N, int Npad, int kv_heads,
                        int hd, hipStream_t stream);
 // the three passes above in one launch (engine path)

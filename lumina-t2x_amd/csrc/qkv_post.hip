@@ -153,8 +153,7 @@ __global__ __launch_bounds__(64 * QK_WAVES) void qk_norm_rope_kernel(QkPostArgs 
 // idle between the phases (2.8 TB/s); staggered waves stream continuously.  LayerNorm weights are staged once per workgroup;
 // each wave stages its own row's rotary factors (36 x 8 bytes) in its private LDS strip.
 template <int MAXCH>
-__global__ __launch_bounds__(64 * QK_WAVES) void qk_norm_rope_persistent_kernel(QkPostArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void qk_norm_rope_persistent_body(const QkPostArgs& p, int block, int nblocks, char* smem) {
     const int rows = p.B * p.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int width = p.heads * p.hd;
@@ -164,8 +163,8 @@ __global__ __launch_bounds__(64 * QK_WAVES) void qk_norm_rope_persistent_kernel(
     u16* sw = (u16*)smem;
     u16* sb = sw + width;
     float2* st = (float2*)(smem + (size_t)width * 4) + wave * nslot;  // this wave's strip
-    const int stride = gridDim.x * QK_WAVES;
-    int row = blockIdx.x * QK_WAVES + wave;
+    const int stride = nblocks * QK_WAVES;
+    int row = block * QK_WAVES + wave;
 
     auto load_row = [&](int r, bf8_t (&raw)[MAXCH]) __attribute__((always_inline)) {
         const u16* src = p.src + (size_t)(r < rows ? r : rows - 1) * p.ld_src + p.col0;
@@ -260,6 +259,26 @@ __global__ __launch_bounds__(64 * QK_WAVES) void qk_norm_rope_persistent_kernel(
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) cur[i] = nxt[i];
     }
+}
+
+template <int MAXCH>
+__global__ __launch_bounds__(64 * QK_WAVES) void qk_norm_rope_persistent_kernel(QkPostArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    qk_norm_rope_persistent_body<MAXCH>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// q AND k post-processing of one layer in ONE persistent launch: blocks [0, q_blocks) stream the q rows, the rest the k rows
+// (two independent HBM-bound passes over the same GEMM output; one launch fills the chip once instead of twice - each launch
+// spends its first and last few microseconds with the memory system half empty)
+struct QkPost2Args {
+    QkPostArgs q, k;
+    int q_blocks;
+};
+template <int MAXCH>
+__global__ __launch_bounds__(64 * QK_WAVES) void qk_norm_rope_pair_kernel(QkPost2Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < p.q_blocks) qk_norm_rope_persistent_body<MAXCH>(p.q, blockIdx.x, p.q_blocks, smem);
+    else qk_norm_rope_persistent_body<MAXCH>(p.k, blockIdx.x - p.q_blocks, gridDim.x - p.q_blocks, smem);
 }
 
 // one block per (64-key tile, kv head, batch): V rows -> LDS (transposed, permuted) -> 128-byte rows
@@ -357,6 +376,39 @@ int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
         case 5: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<5>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
         case 6: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<6>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
         default: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<8>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+    }
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_qk_norm_rope_pair(const QkPostArgs& q, const QkPostArgs& k, hipStream_t stream) {
+    const int wq = q.heads * q.hd, wk = k.heads * k.hd;
+    LT_REQUIRE(q.hd % 8 == 0 && q.hd == k.hd && wk <= wq && wq <= 64 * 8 * 8, "qk_norm_rope_pair: widths %d / %d unsupported", wq, wk);
+    LT_REQUIRE(q.ld_src % 8 == 0 && q.col0 % 8 == 0 && k.ld_src % 8 == 0 && k.col0 % 8 == 0, "qk_norm_rope_pair: ld_src/col0 must be multiples of 8");
+    LT_REQUIRE((q.rope_mode == 0 || q.cs != nullptr) && (k.rope_mode == 0 || k.cs != nullptr), "qk_norm_rope_pair: rotary table missing");
+    LT_REQUIRE((q.ln_w == nullptr) == (q.ln_b == nullptr) && (k.ln_w == nullptr) == (k.ln_b == nullptr), "qk_norm_rope_pair: LayerNorm weight and bias must come together");
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    // ~2 workgroups per CU in total, split by the bytes of the two streams (GQA: the k stream is a quarter of the q stream)
+    const int rows = q.B * q.N;
+    const int total = std::min((2 * rows + QK_WAVES - 1) / QK_WAVES, 2 * cus);
+    int qb = (int)((long long)total * wq / (wq + wk));
+    qb = std::max(1, std::min(qb, total - 1));
+    QkPost2Args a{q, k, qb};
+    const dim3 grid(total);
+    const size_t smem = (size_t)wq * 4 + (size_t)QK_WAVES * (q.hd >> 1) * 8;
+    switch (((wq >> 3) + 63) / 64) {
+        case 1: hipLaunchKernelGGL(qk_norm_rope_pair_kernel<1>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 2: hipLaunchKernelGGL(qk_norm_rope_pair_kernel<2>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 3: hipLaunchKernelGGL(qk_norm_rope_pair_kernel<3>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 4: hipLaunchKernelGGL(qk_norm_rope_pair_kernel<4>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 5: hipLaunchKernelGGL(qk_norm_rope_pair_kernel<5>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        case 6: hipLaunchKernelGGL(qk_norm_rope_pair_kernel<6>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
+        default: hipLaunchKernelGGL(qk_norm_rope_pair_kernel<8>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
     }
     LT_CHECK_HIP(hipGetLastError());
     return 0;

@@ -1,0 +1,14 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r2/call8
+mkdir -p $OUT
+cd $R
+timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "switches or graph" > $OUT/pytest.log 2>&1; echo "pytest exit $?"; tail -5 $OUT/pytest.log
+for i in 1 2; do for g in 1 0; do
+python bench.py --no-cpu-baseline --opt qk_post_pair=$g 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('qk_post_pair=$g', {k:round(d[k],2) for k in ('value','ms_per_step')}, {k:(round(v,2) if isinstance(v,float) else v) for k,v in d['kernel_time_ms_per_step'].items() if k!='note'})
+"
+done; done

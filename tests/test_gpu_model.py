@@ -422,3 +422,31 @@ def test_hip_graph_replay_is_bit_identical_to_eager_launches(golden_dir):
     assert replays >= 8, replays  # 5 + 1 + 1 + 6 evaluations on the main key, minus warm-up and capture
     for a, b in zip(with_graph, eager):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("opt", ["qk_post_pair", "qkv_vt_epilogue", "gemm_w4q", "norm_specialize"])
+def test_engine_path_switches_do_not_change_results(opt):
+    """the launch-structure options of the engine (q / k post-processing in one launch, V projection with the V^T epilogue,
+    persistent 16x16x32 GEMM, specialised row kernels) on a model wide and long enough to take those paths (d 1152, 4096 tokens,
+    M = 8192 rows): each switch off vs on.  Row / layout kernels must be bit-identical; the GEMM switch changes the fp32 summation order
+    inside a 32-deep slab, so there the outputs agree to bf16 rounding."""
+    from gpu_util import set_option
+    cfg = synth.NextDiTConfig(dim=1152, n_layers=2, n_heads=16, cap_feat_dim=256)
+    sd = synth.synth_state_dict(cfg, seed=71)
+    z, t, cap, mask = synth.synth_inputs(cfg, latent_hw=(128, 128), text_len=64, uncond_len=8, seed=72)
+    model = models.NextDiT(**cfg.ctor_kwargs())
+    model.load_state_dict(sd, strict=True)
+    model = model.eval().to("cuda", torch.bfloat16)
+    zb, capb = z.to("cuda", torch.bfloat16), cap.to("cuda", torch.bfloat16)
+    outs = {}
+    on, default = 1, 1
+    try:
+        for v in (on, 0):
+            set_option(opt, v)
+            outs[1 if v else 0] = model.forward_with_cfg(zb, t.cuda(), capb, mask.cuda(), 4.0, base_seqlen=4096, proportional_attn=True)
+    finally:
+        set_option(opt, default)
+    if opt == "gemm_w4q":
+        assert rel_l2(outs[1], outs[0]) < 1e-2, rel_l2(outs[1], outs[0])
+    else:
+        assert torch.equal(outs[1], outs[0]), rel_l2(outs[1], outs[0])
