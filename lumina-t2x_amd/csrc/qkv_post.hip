@@ -17,12 +17,15 @@
 
 namespace {
 
-// QK_ROWS consecutive token rows per workgroup (8 waves x 2 rows).  Per workgroup the LayerNorm weight / bias and the
+// QK_ROWS consecutive token rows per workgroup (4 waves x 2 rows).  Per workgroup the LayerNorm weight / bias and the
 // rotary factors of its rows are staged in LDS once: read per row from L1 they were 2 x the row's own bytes (weights) plus
 // one 8-byte table load per bf16 pair, which made the kernel TA-bound (2.7 TB/s) instead of HBM-bound.
 // In the head-major destination one head's 8+ consecutive rows are whole 128-byte lines (16 * hd bytes, hd % 8 == 0), so no
 // line is shared between workgroups (= between XCD L2s).
-constexpr int QK_ROWS = 16, QK_WAVES = 8, QK_RPW = QK_ROWS / QK_WAVES;
+// (4 waves per workgroup: the persistent kernels hold the current and the next row in registers - ~150 VGPRs, 3 waves per SIMD - so
+//  three 4-wave workgroups fit a CU where only one 8-wave workgroup did: 12 instead of 8 streaming waves per CU)
+constexpr int QK_ROWS = 8, QK_WAVES = 4, QK_RPW = QK_ROWS / QK_WAVES;
+constexpr int QK_WG_PER_CU = 3;
 
 // LDS image: ln_w | ln_b (bf16, `width` each) | (cos, sin)[row][complex slot] fp32
 template <int MAXCH>
@@ -366,7 +369,7 @@ int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
         cus = cached;
     }
     const int max_blocks = (rows + QK_WAVES - 1) / QK_WAVES;
-    const dim3 grid(std::min(max_blocks, 2 * cus));
+    const dim3 grid(std::min(max_blocks, QK_WG_PER_CU * cus));
     const size_t smem = (size_t)width * 4 + (size_t)QK_WAVES * (a.hd >> 1) * 8;
     switch (((width >> 3) + 63) / 64) {
         case 1: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<1>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;
@@ -393,9 +396,9 @@ int launch_qk_norm_rope_pair(const QkPostArgs& q, const QkPostArgs& k, hipStream
         hipDeviceProp_t prop;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    // ~2 workgroups per CU in total, split by the bytes of the two streams (GQA: the k stream is a quarter of the q stream)
+    // QK_WG_PER_CU workgroups per CU in total, split by the bytes of the two streams (GQA: the k stream is a quarter of the q stream)
     const int rows = q.B * q.N;
-    const int total = std::min((2 * rows + QK_WAVES - 1) / QK_WAVES, 2 * cus);
+    const int total = std::min((2 * rows + QK_WAVES - 1) / QK_WAVES, QK_WG_PER_CU * cus);
     int qb = (int)((long long)total * wq / (wq + wk));
     qb = std::max(1, std::min(qb, total - 1));
     QkPost2Args a{q, k, qb};
