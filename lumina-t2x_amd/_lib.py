@@ -12,7 +12,8 @@ import re
 from typing import Dict, List
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblumina_dit.so")
+# LUMINA_DIT_LIB: an alternate build of the same C ABI (A/B measurements of two kernel versions on one box); still no fallback
+LIB_PATH = os.environ.get("LUMINA_DIT_LIB") or os.path.join(_HERE, "lib", "liblumina_dit.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lumina_dit.h")
 
 LT_F32, LT_BF16, LT_F16 = 0, 1, 2

@@ -1309,6 +1309,10 @@ extern "C" int lt_op_gemm_trace(const void* A, const void* W, void* C, int32_t M
     GemmArgs g;
     g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
     g.lda = K; g.ldw = K; g.ldc = N; g.bias_dtype = -1; g.trace = (unsigned long long*)trace_dev;
+    if (variant >= 100) {  // 100 + v: the SwiGLU form of variant v (W = w1 / w3 interleaved, C is [M, N / 2])
+        g.ldc = N / 2;
+        return launch_gemm_bf16(g, 1, variant - 100, (hipStream_t)stream);
+    }
     return launch_gemm_bf16(g, 0, variant, (hipStream_t)stream);
 }
 

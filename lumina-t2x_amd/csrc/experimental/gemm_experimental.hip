@@ -455,7 +455,15 @@ int launch_gemm_experimental(const GemmArgs& a, int epilogue, int variant, hipSt
     const int t256 = ((a.M + 255) / 256) * ((a.N + 255) / 256), t288 = ((a.M + 255) / 256) * ((a.N + 287) / 288);
     constexpr int S1 = 4 * 512 * 64, S2 = 4 * 544 * 64;
     if (a.trace) {
+        if (variant == 15 && epilogue == 1)
+            return launch_plain(gemm_bf16_w4q<1, 8, true>, 4 * 512 * 64, dim3(std::min(t256, exp_num_cus())), dim3(256), a, stream, nullptr, nullptr);
         LT_REQUIRE(epilogue == 0, "gemm trace: plain epilogue");
+        if (variant == 15 || variant == 16) {  // persistent 16x16x32 kernel: one record per workgroup
+            const int nt = variant == 16 ? t288 : t256;
+            const dim3 grid(std::min(nt, exp_num_cus()));
+            return variant == 16 ? launch_plain(gemm_bf16_w4q<0, 9, true>, 4 * 544 * 64, grid, dim3(256), a, stream, nullptr, nullptr)
+                                 : launch_plain(gemm_bf16_w4q<0, 8, true>, 4 * 512 * 64, grid, dim3(256), a, stream, nullptr, nullptr);
+        }
         if (variant == 12) return launch_plain(gemm_bf16_w4s<0, true>, 2 * 512 * 64, dim3(t256), dim3(256), a, stream, nullptr, nullptr);
         if (variant == 10) return launch_plain(gemm_bf16_pp<2, 2, 4, 4, 0, true, 0, 2, 2>, S1, dim3(t256), dim3(256), a, stream, nullptr, nullptr);
         if (variant == 5) return launch_plain(gemm_bf16_pp<2, 4, 4, 2, 0, true, 0, 1>, S1, dim3(t256), dim3(512), a, stream, nullptr, nullptr);

@@ -166,6 +166,7 @@ int g_gemm_w4q = 1;  // 1 (default): large dense GEMMs (>= one tile per CU) run 
 GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     const bool w4p_ok = !a.tile_expert && !a.trace && a.bias_dtype < 0 && a.K % 64 == 0 && a.K >= 128 &&
                         255LL * a.ldc * 2 + (long long)a.N * 2 < 0x7fffffffLL && epilogue != 2;
+    if (a.trace) return GK_EXPERIMENTAL;
     if (variant == 15 || variant == 16) {
         if (!w4p_ok || (epilogue == 1 && variant == 16)) return GK_NONE;
         return epilogue == 1 ? GK_W4Q256_SWIGLU : (variant == 15 ? GK_W4Q256 : GK_W4Q288);

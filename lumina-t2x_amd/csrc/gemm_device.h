@@ -1058,14 +1058,16 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmArgs p) {
 //    equal to fp32 rounding, not bit-identical to variant 1.
 // EPI 1 (SwiGLU) needs NT % 4 == 0 (w1 / w3 interleaved in 32-row groups = pairs of 16-column tiles).  K % 64 == 0, K >= 128, no bias.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-template <int EPI, int NW16>
+// TRACE (experimental build, lt_op_gemm_trace variants 15 / 16): per workgroup 8 x u64 = s_memrealtime (100 MHz) at entry | prologue
+// done | last main loop done | last epilogue issued | exit (stores acknowledged), shader clocks of the first tile's main loop,
+// HW_ID, tiles walked.
+template <int EPI, int NW16, bool TRACE = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     constexpr int MT = 8, NT = NW16, NW = 4, BM = 256, BN = 2 * NW16 * 16;
     constexpr int PA = BM / 16, PW = BN / 16, NP = PA + PW;   // 1-KiB staging pieces (16 rows x 64 B) per slab
     constexpr int IP = (NP + NW - 1) / NW;                    // pieces per wave and slab (a surplus slot re-loads the wave's last piece)
     constexpr int SLAB = (BM + BN) * 64, W_OFF = BM * 64;
     constexpr int NM = MT * NT, RD = MT + NT, EVERY = NM / IP;
-    constexpr bool SPLIT_ACC = NM * 4 > 256;  // more accumulator registers than AGPRs
     constexpr int NST = EPI == 0 ? MT * (NT / 2) + (NT % 2 ? MT : 0) : MT * (NT / 4);  // store instructions per wave and tile
     static_assert(NM % IP == 0 && RD <= NM, "one LDS-DMA per EVERY MFMAs, one fragment read per MFMA in the first RD");
     static_assert(EPI == 0 || NT % 4 == 0, "SwiGLU pairs 32-column groups");
@@ -1079,6 +1081,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
     const int ntiles = TM * TN;
     const int ns = p.K / 32;
+    unsigned long long tr_entry = 0, tr_pro = 0, tr_loop = 0, tr_epi = 0, tr_clk = 0;
+    if constexpr (TRACE) tr_entry = __builtin_amdgcn_s_memrealtime();
 
     // staging: wave w copies pieces w + 4 i; piece q < PA = A rows 16 q .., else W rows 16 (q - PA) ..; lane -> row lane >> 2, 16-byte
     // position lane & 3, fetched from source chunk pos ^ (3 * ((row >> 3) & 1))
@@ -1152,54 +1156,68 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     wait_vmcnt<IP>();
     pp_barrier();
 
-    int g = 0;               // global slab index of the stream
     bool after_epilogue = false;
-    // one slab: MFMAs of slab g from (wc, ac) | fragment reads of slab g+1 into (wn_, an) | LDS-DMA of the slab three ahead
-    auto body = [&](int s3, bf16x8 (&wc)[NT], bf16x8 (&ac)[MT], bf16x8 (&wn_)[NT], bf16x8 (&an)[MT]) __attribute__((always_inline)) {
-        const bool own = s3 < ns;  // past the tile's end: slab s3 - ns of the next tile
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(own ? cur.a : nxt.a), 0, own ? cur.a_bytes : nxt.a_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(own ? cur.w : nxt.w), 0, own ? cur.w_bytes : nxt.w_bytes, 0x00020000);
-        const char* sb = smem + ((g + 1) & 3) * SLAB;
-        char* db = smem + ((g + 3) & 3) * SLAB;
-        const int soff = (own ? s3 : s3 - ns) * 64;
+    if constexpr (TRACE) { tr_pro = __builtin_amdgcn_s_memrealtime(); tr_clk = __builtin_amdgcn_s_memtime(); }
+    // scalar state of the two streams, carried from body to body.  Each body computes the NEXT body's values inside its own MFMA
+    // stream (the fences below pin them there): between the barrier and the first MFMA of a slab there is nothing but one address
+    // add.  (Round 2's first form rebuilt descriptors, slot offsets and the tile selects at the top of every body: ~25 dependent
+    // scalar instructions per slab in front of an idle matrix pipe - profiles/r02/gemm_trace_w4q.log, 80-87 % main-loop duty.)
+    int rd_off = SLAB;       // LDS offset of slab g + 1 (fragment reads of this body)
+    int wr_off = 3 * SLAB;   // LDS offset of slab g + 3 (LDS-DMA destination of this body)
+    int d_soff = 3 * 64;     // byte offset along K of the slab the DMA stream fetches next ...
+    __amdgpu_buffer_rsrc_t dA = __builtin_amdgcn_make_buffer_rsrc((void*)cur.a, 0, cur.a_bytes, 0x00020000);   // ... in this tile
+    __amdgpu_buffer_rsrc_t dW = __builtin_amdgcn_make_buffer_rsrc((void*)cur.w, 0, cur.w_bytes, 0x00020000);
+    const int kbytes = ns * 64;
+    // one slab: MFMAs of slab g from (wc, ac) | fragment reads of slab g+1 into (wn_, an) | LDS-DMA of the slab three ahead.
+    // FIRST (a tile's slab 0): C = 0 forms, no accumulator clears.  Accumulator tiles 0..63 live in AGPRs, the rest (NT = 9: 8 tiles)
+    // in arch VGPRs; inline assembly gives each ONE home (the builtin bounced tiles through spare AGPRs: 272 us instead of 216 us on
+    // the QKV GEMM) and, with a scheduling fence per MFMA, pins the written interleave.
+    auto body = [&](auto first_tag, bf16x8 (&wc)[NT], bf16x8 (&ac)[MT], bf16x8 (&wn_)[NT], bf16x8 (&an)[MT]) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const char* sb = smem + rd_off;
+        char* db = smem + wr_off;
+        int n_rd = rd_off, n_wr = wr_off, n_soff = d_soff;
+        __amdgpu_buffer_rsrc_t nA = dA, nW = dW;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             const int mt = i / NT, nt = i % NT;
-            if constexpr (SPLIT_ACC) {
-                // 288 accumulator registers do not fit the 256 AGPRs: tiles 0..63 live there, the last 8 in arch VGPRs (the VGPR
-                // form of the instruction).  Written as inline assembly so that each accumulator has ONE home - with the builtin
-                // the compiler bounced the overflow tiles through a[80:83] around every MFMA (100 v_accvgpr_read + 96 _write per
-                // slab pair: 272 us instead of 216 us on the QKV GEMM); the written order is pinned by scheduling fences
+            if constexpr (FIRST) {
+                if (i < 64) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
+            } else {
                 if (i < 64) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
                 else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
-            } else {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], ac[mt], acc[mt][nt], 0, 0, 0);
             }
             if (i < NT) wn_[i] = *(const bf16x8*)(sb + w_row_off + i * 1024);
             else if (i < RD) an[i - NT] = *(const bf16x8*)(sb + a_row_off + (i - NT) * 1024);
-            if (i % EVERY == EVERY - 1)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(i / EVERY < PA / NW ? rA : rW, LDS_PTR(db + ldsoff[i / EVERY]), 16, voff[i / EVERY], soff, 0, 0);
-            if constexpr (SPLIT_ACC) __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (!SPLIT_ACC) {
-#pragma unroll
-            for (int i = 0; i < NM; ++i) {  // pin the written interleave
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                if (i < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (i % EVERY == EVERY - 1) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+            if (i % EVERY == EVERY / 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(i / EVERY < PA / NW ? dA : dW, LDS_PTR(db + ldsoff[i / EVERY]), 16, voff[i / EVERY], d_soff, 0, 0);
+            // the next body's scalar state, a few instructions under each of the last MFMAs
+            if (i == NM - 4) { n_rd = rd_off + SLAB; n_rd = n_rd == 4 * SLAB ? 0 : n_rd; }
+            if (i == NM - 3) { n_wr = wr_off + SLAB; n_wr = n_wr == 4 * SLAB ? 0 : n_wr; n_soff = d_soff + 64; }
+            if (i == NM - 2) {
+                if (n_soff == kbytes) {  // the DMA stream moves on to the next tile (its last three slabs ride in this tile's bodies)
+                    n_soff = 0;
+                    nA = __builtin_amdgcn_make_buffer_rsrc((void*)nxt.a, 0, nxt.a_bytes, 0x00020000);
+                    nW = __builtin_amdgcn_make_buffer_rsrc((void*)nxt.w, 0, nxt.w_bytes, 0x00020000);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        rd_off = n_rd; wr_off = n_wr; d_soff = n_soff; dA = nA; dW = nW;
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): slab g+1's fragments are in registers
         // slab g+2 landed; still allowed in flight: this body's IP DMAs and, right after a tile boundary, the NST stores issued
         // between slab g+2's DMAs and them (loads and stores retire in issue order, one counter)
-        if (after_epilogue) wait_vmcnt<IP + NST>();
-        else wait_vmcnt<IP>();
-        after_epilogue = false;
+        if constexpr (FIRST) {
+            if (after_epilogue) wait_vmcnt<IP + NST>();
+            else wait_vmcnt<IP>();
+            after_epilogue = false;
+        } else {
+            wait_vmcnt<IP>();
+        }
         pp_barrier();
-        ++g;
     };
     // epilogue through the tile's C descriptor (rows past M fall outside num_records, columns past N get an out-of-range offset):
     // every wave issues exactly NST store instructions per tile.  Lane holds, per 16x16 accumulator tile, C row l15 and columns
@@ -1264,19 +1282,28 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         }
     };
     for (int t = 0; t < my_tiles; ++t) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < ns; s += 2) {  // slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
-            body(s + 3, wf, af, wf2, af2);
-            body(s + 4, wf2, af2, wf, af);
+        body(std::true_type{}, wf, af, wf2, af2);  // slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
+        body(std::false_type{}, wf2, af2, wf, af);
+        for (int s = 2; s < ns; s += 2) {
+            body(std::false_type{}, wf, af, wf2, af2);
+            body(std::false_type{}, wf2, af2, wf, af);
         }
+        if constexpr (TRACE) { tr_loop = __builtin_amdgcn_s_memrealtime(); if (t == 0) tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
         store_out(cur);
+        if constexpr (TRACE) tr_epi = __builtin_amdgcn_s_memrealtime();
         after_epilogue = true;
         advance();
     }
     wait_vmcnt<0>();  // no LDS-DMA (the null ones of the last bodies included) may outlive the workgroup's LDS allocation
+    if constexpr (TRACE) {
+        if (p.trace && tid == 0) {
+            unsigned long long* o = p.trace + (size_t)blockIdx.x * 8;
+            o[0] = tr_entry; o[1] = tr_pro; o[2] = tr_loop; o[3] = tr_epi; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = tr_clk;
+            o[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |       // HW_ID
+                   ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);  // XCC_ID[3:0]
+            o[7] = (unsigned long long)my_tiles;
+        }
+    }
 }
 
 }  // namespace lt_gemm
