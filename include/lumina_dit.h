@@ -93,7 +93,8 @@ const char* lt_last_error(void);
 const char* lt_version(void);
 
 /* process-wide kernel selection knobs (A/B measurements, tests; defaults are the measured-best settings):
- *   "attention_variant" 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (default; hd 72)
+ *   "attention_variant" 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (hd 72 / 96) | 4 one wave per SIMD x 64 query rows,
+ *                       asm-owned AGPRs (hd 72 with whole 64-key tiles; variant 3 otherwise)
  *   "gemm_variant"      0 auto tile shape (default) | 1 256x256 | 2 256x288
  *   "gemm_swiglu_w4p"   1 (default): dense multi-round SwiGLU GEMMs run on the persistent 4-wave kernel | 0: 8-wave ping-pong
  *   "gemm_stagger"      0 (default) .. 64: 4-wave GEMM kernels (explicit variants 10, 13, 14) spread the start of the workgroups
@@ -258,7 +259,7 @@ int lt_op_attention(const void* q_dev, const void* k_dev, const void* vt_dev, co
                     void* out_dev, const void* gate_dev, int32_t accumulate, int32_t B, int32_t H,
                     int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t hd, float scale,
                     int32_t k_prescaled, void* stream);
-/* self-attention + zero-init gated text cross-attention in ONE launch (hd 72, attention_variant 3; model.py:392-434):
+/* self-attention + zero-init gated text cross-attention in ONE launch (hd 72 / 96, attention_variant 3 or 4; model.py:392-434):
  *   out = bf16(softmax(q k^T) v) + bf16(bf16(softmax(q tk^T + tbias) tv) * tanh(tgate[h]))
  * k and tk must already carry their softmax scale * log2(e) (lt_op_qk_norm_rope out_scale); layouts as lt_op_attention,
  * tk [B,Hkv,Tk,hd], tvt [B,Hkv,hd,Tkpad], tbias float [B,Tkpad] (0 / -inf, -inf in the padding), tgate bf16 [H]. */

@@ -964,7 +964,7 @@ static int g_attn_variant = 3;  // 3: ping-pong kernel where it applies (hd 72 s
 void lt_set_attention_variant(int v) { g_attn_variant = v; }
 
 // true when launch_attention() can take the text keys along with the image keys (one kernel instead of two)
-bool attention_fuses_text(int hd) { return g_attn_variant == 3 && (hd == 72 || hd == 96); }
+bool attention_fuses_text(int hd) { return g_attn_variant >= 3 && (hd == 72 || hd == 96); }
 
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.H % a.Hkv == 0, "attention: H=%d not a multiple of Hkv=%d", a.H, a.Hkv);
@@ -980,7 +980,10 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
         LT_REQUIRE(a.k_prescaled && a.tvt && a.tbias && a.tgate && a.Tk > 0 && a.Tkpad % 64 == 0 && a.Tkpad >= a.Tk,
                    "attention: incomplete fused text arguments");
     }
-    if (g_attn_variant == 3 && (a.hd == 72 || a.hd == 96) && a.bias == nullptr && !a.accumulate) {
+    // variant 4: one wave per SIMD, 64 query rows per wave (attention_v4.hip); whole 64-key tiles only, else the ping-pong kernel
+    if (g_attn_variant == 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.trace && !a.nk_batch && a.Nk % 64 == 0)
+        return launch_attention_v4(a, stream);
+    if (g_attn_variant >= 3 && (a.hd == 72 || a.hd == 96) && a.bias == nullptr && !a.accumulate) {
         constexpr int SMEM72 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16, SMEM96 = 4 * (96 * 128) + 4 * (64 * 96 * 2) + 16;
         static bool attr_done = false;
         if (!attr_done) {

@@ -1245,7 +1245,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     LT_REQUIRE(name, "lt_set_option: null name");
     ++g_option_gen;  // captured graphs bake the kernel selection: every option change starts new graph keys
     if (strcmp(name, "graph") == 0) { g_graph = value != 0; return 0; }
-    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 3, "attention_variant must be 1, 2 or 3"); lt_set_attention_variant(value); return 0; }
+    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 4, "attention_variant must be 1 .. 4"); lt_set_attention_variant(value); return 0; }
     if (strcmp(name, "qkv_post_fused") == 0) { g_qkv_post_fused = value != 0; return 0; }
     if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
     if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
@@ -1383,7 +1383,7 @@ extern "C" int lt_op_attention_fused(const void* q, const void* k, const void* v
                                      const float* tbias, const void* tgate, void* out, int32_t B, int32_t H, int32_t Hkv, int32_t N,
                                      int32_t Nk, int32_t Nkpad, int32_t Tk, int32_t Tkpad, int32_t hd, void* stream) {
     LT_REQUIRE(q && k && vt && tk && tvt && tbias && tgate && out, "lt_op_attention_fused: null pointer");
-    LT_REQUIRE(attention_fuses_text(hd), "lt_op_attention_fused: needs head_dim 72 or 96 and attention_variant 3");
+    LT_REQUIRE(attention_fuses_text(hd), "lt_op_attention_fused: needs head_dim 72 or 96 and attention_variant 3 or 4");
     AttnArgs a;
     a.q = (const u16*)q; a.k = (const u16*)k; a.vt = (const u16*)vt; a.bias = nullptr; a.out = (u16*)out; a.gate = nullptr;
     a.accumulate = 0; a.B = B; a.H = H; a.Hkv = Hkv; a.N = N; a.Nk = Nk; a.Nkpad = Nkpad; a.hd = hd; a.scale = 1.f; a.k_prescaled = 1;

@@ -121,6 +121,7 @@ struct AttnArgs {
 int launch_region_text_combine(u16* out, const u16* txt, const u16* gate, int Y, int N, int H, int hd, int Hp, int Wp,
                                int h_split, int w_split, hipStream_t stream);
 int launch_attention(const AttnArgs& a, hipStream_t stream);
+int launch_attention_v4(const AttnArgs& a, hipStream_t stream);  // hd 72, 4 waves x 64 query rows (attention_v4.hip)
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288

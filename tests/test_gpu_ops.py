@@ -435,7 +435,7 @@ def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None, fold_scale=False)
     return out.view(B, N, H, hd).permute(0, 2, 1, 3)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])  # 4: one wave per SIMD x 64 query rows (hd 72, whole tiles; else it runs variant 3)
 @pytest.mark.parametrize("B,H,Hkv,N,hd", [(1, 8, 8, 128, 72), (2, 8, 2, 320, 72), (2, 4, 4, 200, 72), (1, 3, 3, 64, 72),
                                           (2, 32, 32, 4096, 72), (1, 8, 8, 256, 48), (1, 8, 8, 192, 96),
                                           (1, 8, 8, 1000, 72), (1, 2, 2, 40, 72),
@@ -457,7 +457,7 @@ def test_attention_self(variant, B, H, Hkv, N, hd, fold):
 
 
 @pytest.mark.parametrize("hd", [72, 96])
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_attention_softmax_outlier_keys(variant, hd):
     """forces large running-max jumps mid-sequence, above and below the deferred-rescale threshold (guide 5.4
     rule 26); v1 (rescale every tile), v2 (threshold 8 in log2 units) and v3 (same threshold; hd 72: max folded into the
@@ -501,10 +501,11 @@ def test_attention_text_accumulate(variant, T, valid1, fold):
 
 @pytest.mark.parametrize("hd", [72, 96])
 @pytest.mark.parametrize("B,H,Hkv,N,T,valid1", [(2, 8, 8, 320, 128, 8), (2, 8, 2, 200, 77, 30), (1, 4, 4, 4096, 256, 256),
-                                                  (2, 4, 4, 96, 300, 130)])
-def test_attention_fused_text(B, H, Hkv, N, T, valid1, hd):
+                                                  (2, 4, 4, 96, 300, 130), (2, 4, 2, 512, 128, 100)])
+@pytest.mark.parametrize("variant", [3, 4])
+def test_attention_fused_text(B, H, Hkv, N, T, valid1, hd, variant):
     """one launch = self-attention + gated text cross-attention (model.py:392-434), both K pre-scaled (engine path)"""
-    set_option("attention_variant", 3)
+    set_option("attention_variant", variant)
     g = torch.Generator().manual_seed(N + T)
     q = bf(torch.randn(B, H, N, hd, generator=g))
     k = bf(torch.randn(B, Hkv, N, hd, generator=g))
@@ -538,6 +539,33 @@ def test_attention_fused_text(B, H, Hkv, N, T, valid1, hd):
     ref = r16(o_self + r16(o_txt * gt))
     assert not torch.isnan(got.float()).any()
     assert rel_l2(got, ref) < 6e-3, rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("B,H,Hkv,N,outliers", [(2, 32, 32, 4096, False), (1, 8, 2, 1024, True), (1, 4, 4, 64, False), (1, 2, 2, 200 * 64, True)])
+def test_attention_v4_is_bit_identical_to_v3(B, H, Hkv, N, outliers):
+    """attn_fwd_kernel_v4 (4 waves x 64 query rows, asm-owned AGPRs) runs the same arithmetic in the same order as the ping-pong
+    kernel: per query row the two are the same sequence of MFMAs, exp2 and max-moves (a wave-wide `any` only decides WHEN the rare
+    branch runs, its per-row effect is the identity for rows that do not raise) -> outputs must be equal bit for bit, with max
+    moves late in the sequence included"""
+    hd = 72
+    g = torch.Generator().manual_seed(N + H)
+    q = bf(torch.randn(B, H, N, hd, generator=g))
+    k = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    v = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    if outliers:
+        rep = H // Hkv
+        k[:, :, N // 2 + 3] = q[:, ::rep, 7] * 4.0
+        k[:, :, 5] = q[:, ::rep, N - 9] * 2.0
+        k[:, :, N - 64:] += q[:, ::rep, 40:41] * 1.5   # last tile above everything before it for row 40
+        k[:, :, :64] -= q[:, ::rep, 50:51] * 3.0
+    scale = math.sqrt(math.log(N, 64) / hd) if N > 64 else 1 / math.sqrt(hd)
+    outs = []
+    for variant in (3, 4):
+        set_option("attention_variant", variant)
+        outs.append(_run_attn(q, k, v, scale, fold_scale=True).clone())
+    assert torch.equal(outs[0], outs[1]), rel_l2(outs[1], outs[0])
+    ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), scale)
+    assert rel_l2(outs[1], ref) < 6e-3
 
 
 @pytest.mark.parametrize("M,N,K,act", [(2, 1000, 256, 0), (2, 9216, 1024, 1), (1, 37, 128, 1), (8, 64, 2048, 0)])
