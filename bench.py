@@ -205,7 +205,7 @@ def main():
                          "default), 2 attention, 4 other.  Every bracketed launch costs two event packets (all classes: +4 %% "
                          "wall), so the attention / other breakdown is taken in a short untimed pass after the timed region")
     ap.add_argument("--gqa", action="store_true", help="shorthand for --workload cfg2-gqa")
-    ap.add_argument("--attn-variant", type=int, default=None, help="A/B knob: 1 baseline, 2 VALU-diet, 3 ping-pong (default)")
+    ap.add_argument("--attn-variant", type=int, default=None, help="A/B knob: 1 baseline, 2 VALU-diet, 3 ping-pong, 4 one wave per SIMD (default)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B knob: 0 auto (default), 1 256x256, 2 256x288")
     args = ap.parse_args()
     maybe_self_launch(args, sys.argv[1:])
@@ -341,7 +341,7 @@ def main():
             },
             "kernel_time_ms_per_step": dict(breakdown, note=f"untimed pass of {nb} NFE with events around every launch"),
             "attention_tflops_per_s": attn_fl_b / (attn_ms_b * 1e-3) / 1e12 if attn_ms_b > 0 else 0.0,
-            "kernel_variants": {"attention": args.attn_variant or 3, "gemm": args.gemm_variant or 0},
+            "kernel_variants": {"attention": args.attn_variant or 4, "gemm": args.gemm_variant or 0},
             "hip_graph_replays": eng.graph_replays(),
             "ode_stepping_parity": "unpinned (torchdiffeq is neither vendored, pinned nor installed; fixed-grid solvers restated "
                                    "from its published algorithm, DESIGN.md 6)",

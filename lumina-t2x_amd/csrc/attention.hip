@@ -960,7 +960,7 @@ template __global__ void attn_fwd_kernel_v3<96, false>(AttnArgs);
 
 using lt_attn::attn_fwd_kernel_v3;
 
-static int g_attn_variant = 3;  // 3: ping-pong kernel where it applies (hd 72 self-attention), v2 elsewhere
+static int g_attn_variant = 4;  // 4: one wave per SIMD x 64 query rows where it applies (hd 72, whole tiles), else 3: ping-pong kernel (hd 72 / 96), v2 elsewhere
 void lt_set_attention_variant(int v) { g_attn_variant = v; }
 
 // true when launch_attention() can take the text keys along with the image keys (one kernel instead of two)
@@ -980,8 +980,8 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
         LT_REQUIRE(a.k_prescaled && a.tvt && a.tbias && a.tgate && a.Tk > 0 && a.Tkpad % 64 == 0 && a.Tkpad >= a.Tk,
                    "attention: incomplete fused text arguments");
     }
-    // variant 4: one wave per SIMD, 64 query rows per wave (attention_v4.hip); key counts that are multiples of 256, else the ping-pong kernel
-    if (g_attn_variant == 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 256 == 0)
+    // variant 4: one wave per SIMD, 64 query rows per wave (attention_v4.hip); whole 64-key tiles and <= 256 text keys, else the ping-pong kernel
+    if (g_attn_variant == 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && (!a.tk || a.Tkpad <= 256))
         return launch_attention_v4(a, stream);
     if (g_attn_variant >= 3 && (a.hd == 72 || a.hd == 96) && a.bias == nullptr && !a.accumulate) {
         constexpr int SMEM72 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16, SMEM96 = 4 * (96 * 128) + 4 * (64 * 96 * 2) + 16;

@@ -186,7 +186,7 @@ def bench_attn(rounds, variants, shape=(2, 32, 4096, 72)):
         err = rel_l2(outs[v].view(B, N, H, hd)[0, :, 0], ref)
         print(f"attn B{B} H{H} N{N} hd{hd} variant {v}: median {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s (best {fl/mn/1e9:7.1f})"
               f"  rel-L2 head0 vs fp32 {err:.2e}", flush=True)
-    set_option("attention_variant", 3)
+    set_option("attention_variant", 4)
 
 
 def bench_attn_vendor(rounds):

@@ -424,6 +424,29 @@ def test_hip_graph_replay_is_bit_identical_to_eager_launches(golden_dir):
         assert torch.equal(a, b)
 
 
+@pytest.mark.gpu
+def test_attention_variants_3_and_4_agree_in_the_model():
+    """the default attention kernel (variant 4: one wave per SIMD, text phase through the same tile pipeline) and the ping-pong
+    kernel (variant 3) run the same arithmetic in the same order: a whole forward_with_cfg - self-attention at 4096 tokens + fused
+    text cross-attention with a padded caption - must not change by a bit"""
+    from gpu_util import set_option
+    cfg = synth.NextDiTConfig(dim=1152, n_layers=2, n_heads=16, cap_feat_dim=256)
+    sd = synth.synth_state_dict(cfg, seed=73)
+    z, t, cap, mask = synth.synth_inputs(cfg, latent_hw=(128, 128), text_len=100, uncond_len=8, seed=74)
+    model = models.NextDiT(**cfg.ctor_kwargs())
+    model.load_state_dict(sd, strict=True)
+    model = model.eval().to("cuda", torch.bfloat16)
+    zb, capb = z.to("cuda", torch.bfloat16), cap.to("cuda", torch.bfloat16)
+    outs = {}
+    try:
+        for v in (4, 3):
+            set_option("attention_variant", v)
+            outs[v] = model.forward_with_cfg(zb, t.cuda(), capb, mask.cuda(), 4.0, base_seqlen=4096, proportional_attn=True)
+    finally:
+        set_option("attention_variant", 4)
+    assert torch.equal(outs[4], outs[3]), rel_l2(outs[4], outs[3])
+
+
 @pytest.mark.parametrize("opt", ["qk_post_pair", "qkv_vt_epilogue", "gemm_w4q", "norm_specialize"])
 def test_engine_path_switches_do_not_change_results(opt):
     """the launch-structure options of the engine (q / k post-processing in one launch, V projection with the V^T epilogue,

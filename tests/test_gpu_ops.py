@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _default_kernel_variants():
     yield
-    set_option("attention_variant", 3)
+    set_option("attention_variant", 4)
     set_option("gemm_variant", 0)
 
 
@@ -541,7 +541,9 @@ def test_attention_fused_text(B, H, Hkv, N, T, valid1, hd, variant):
     assert rel_l2(got, ref) < 6e-3, rel_l2(got, ref)
 
 
-@pytest.mark.parametrize("B,H,Hkv,N,outliers", [(2, 32, 32, 4096, False), (1, 8, 2, 1024, True), (1, 4, 4, 64, False), (1, 2, 2, 200 * 64, True)])
+@pytest.mark.parametrize("B,H,Hkv,N,outliers", [(2, 32, 32, 4096, False), (1, 8, 2, 1024, True), (1, 4, 4, 64, False), (1, 2, 2, 200 * 64, True),
+                                                 # tile counts 2, 3, 5, 6, 7 (mod 4 remainders of the ring-depth unrolled loop), ragged last q-block
+                                                 (1, 4, 4, 128, False), (1, 4, 2, 192, True), (1, 4, 4, 320, True), (2, 2, 2, 384, False), (1, 2, 1, 448, True)])
 def test_attention_v4_is_bit_identical_to_v3(B, H, Hkv, N, outliers):
     """attn_fwd_kernel_v4 (4 waves x 64 query rows, asm-owned AGPRs) runs the same arithmetic in the same order as the ping-pong
     kernel: per query row the two are the same sequence of MFMAs, exp2 and max-moves (a wave-wide `any` only decides WHEN the rare
@@ -566,6 +568,44 @@ def test_attention_v4_is_bit_identical_to_v3(B, H, Hkv, N, outliers):
     assert torch.equal(outs[0], outs[1]), rel_l2(outs[1], outs[0])
     ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), scale)
     assert rel_l2(outs[1], ref) < 6e-3
+
+
+@pytest.mark.parametrize("B,H,Hkv,N,T,valid1", [(2, 8, 8, 320, 128, 8), (2, 8, 2, 192, 77, 30), (1, 4, 4, 4096, 256, 256), (2, 4, 2, 512, 40, 33),
+                                                  (2, 4, 4, 64, 200, 130)])
+def test_attention_v4_fused_text_is_bit_identical_to_v3(B, H, Hkv, N, T, valid1):
+    """the text phase of variant 4 runs the text keys through the SAME tile pipeline as the image keys (the additive mask rides in
+    a pad slot of the QK^T MFMA: 1.0 x {0, -inf} per key) - same values as the ping-pong kernel's `scores + mask`, bit for bit"""
+    hd = 72
+    g = torch.Generator().manual_seed(N + T + 1)
+    q = bf(torch.randn(B, H, N, hd, generator=g))
+    k = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    v = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    tk = bf(torch.randn(B, Hkv, T, hd, generator=g))
+    tv = bf(torch.randn(B, Hkv, T, hd, generator=g))
+    gate = bf(torch.randn(H, generator=g))
+    mask = torch.ones(B, T)
+    mask[B - 1, valid1:] = 0
+    bias = torch.where(mask > 0, 0.0, float("-inf"))
+    L2E = 1.4426950408889634
+    kf = (k.float() * (L2E / math.sqrt(hd))).to(torch.bfloat16)
+    tkf = (tk.float() * (L2E / math.sqrt(hd))).to(torch.bfloat16)
+    Npad, Tpad = (N + 63) // 64 * 64, (T + 63) // 64 * 64
+    vt = torch.empty(B, Hkv, hd, Npad, device="cuda", dtype=torch.bfloat16)
+    tvt = torch.empty(B, Hkv, hd, Tpad, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_v_transpose(P(v.permute(0, 2, 1, 3).reshape(B * N, Hkv * hd).contiguous()), Hkv * hd, 0, P(vt), B, N, Npad, Hkv, hd, stream()))
+    ok(lib().lt_op_v_transpose(P(tv.permute(0, 2, 1, 3).reshape(B * T, Hkv * hd).contiguous()), Hkv * hd, 0, P(tvt), B, T, Tpad, Hkv, hd, stream()))
+    bias_dev = torch.full((B, Tpad), float("-inf"), device="cuda", dtype=torch.float32)
+    bias_dev[:, :T] = bias.cuda()
+    outs = []
+    for variant in (3, 4):
+        set_option("attention_variant", variant)
+        out = torch.full((B, N, H * hd), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ok(lib().lt_op_attention_fused(P(q), P(kf), P(vt), P(tkf), P(tvt), P(bias_dev), P(gate), P(out), B, H, Hkv, N, N, Npad, T, Tpad,
+                                       hd, stream()), "attention_fused")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert not torch.isnan(outs[1].float()).any()
+    assert torch.equal(outs[0], outs[1]), rel_l2(outs[1], outs[0])
 
 
 @pytest.mark.parametrize("M,N,K,act", [(2, 1000, 256, 0), (2, 9216, 1024, 1), (1, 37, 128, 1), (8, 64, 2048, 0)])
