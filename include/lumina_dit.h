@@ -94,7 +94,7 @@ const char* lt_version(void);
 
 /* process-wide kernel selection knobs (A/B measurements, tests; defaults are the measured-best settings):
  *   "attention_variant" 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (hd 72 / 96) | 4 one wave per SIMD x 64 query rows,
- *                       asm-owned AGPRs (hd 72 with whole 64-key tiles; variant 3 otherwise)
+ *                       asm-owned AGPRs (hd 72 with whole 64-key tiles; variant 3 otherwise) | 5 the same with PV on 16x16x32 MFMAs
  *   "gemm_variant"      0 auto tile shape (default) | 1 256x256 | 2 256x288
  *   "gemm_swiglu_w4p"   1 (default): dense multi-round SwiGLU GEMMs run on the persistent 4-wave kernel | 0: 8-wave ping-pong
  *   "gemm_stagger"      0 (default) .. 64: 4-wave GEMM kernels (explicit variants 10, 13, 14) spread the start of the workgroups

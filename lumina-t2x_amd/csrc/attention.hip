@@ -981,7 +981,11 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
                    "attention: incomplete fused text arguments");
     }
     // variant 4: one wave per SIMD, 64 query rows per wave (attention_v4.hip); whole 64-key tiles and <= 256 text keys, else the ping-pong kernel
-    if (g_attn_variant == 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && (!a.tk || a.Tkpad <= 256))
+#ifdef LT_EXPERIMENTAL
+    if (g_attn_variant == 5 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && (!a.tk || a.Tkpad <= 256))
+        return launch_attention_v5(a, stream);  // PV on 16x16x32 MFMAs (csrc/experimental/attention_v5.hip)
+#endif
+    if (g_attn_variant >= 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && (!a.tk || a.Tkpad <= 256))
         return launch_attention_v4(a, stream);
     if (g_attn_variant >= 3 && (a.hd == 72 || a.hd == 96) && a.bias == nullptr && !a.accumulate) {
         constexpr int SMEM72 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16, SMEM96 = 4 * (96 * 128) + 4 * (64 * 96 * 2) + 16;

@@ -1245,7 +1245,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     LT_REQUIRE(name, "lt_set_option: null name");
     ++g_option_gen;  // captured graphs bake the kernel selection: every option change starts new graph keys
     if (strcmp(name, "graph") == 0) { g_graph = value != 0; return 0; }
-    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 4, "attention_variant must be 1 .. 4"); lt_set_attention_variant(value); return 0; }
+    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 5, "attention_variant must be 1 .. 5"); lt_set_attention_variant(value); return 0; }
     if (strcmp(name, "qkv_post_fused") == 0) { g_qkv_post_fused = value != 0; return 0; }
     if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
     if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }

@@ -1,0 +1,502 @@
+// Self-attention for head_dim 72 (Next-DiT 2B): attn_fwd_kernel_v4's structure (attention_v4.hip: 4 waves per workgroup, one wave per
+// SIMD x 64 query rows, one software-pipelined instruction stream per tile, asm-owned AGPRs, text phase through the same pipeline)
+// with the PV product on v_mfma_f32_16x16x32_bf16.
+//
+// Why: both kernels are power-bound (the shader clock settles at ~1.55 GHz under them), so time follows the energy per tile, and the
+// 32x32x16 PV product of v3 / v4 pads O^T from 72 to 96 head-dim rows - a quarter of its MFMA work multiplies rows nobody reads.
+// With 16-row tiles O^T is 80 rows (72 + the row of ones that yields the softmax denominator + 7 idle): PV drops from 24 x 32 to
+// 40 x 16 matrix-pipe cycles per tile and block pair, the whole tile from 1408 to 1280.  What changes against v4:
+//  * P leaves the softmax as the B operand of a 32x32 MFMA (lane = query row of 32, 16 keys); the 16x16x32 B operand wants lane =
+//    query row of 16, 8 of 32 keys.  One v_permlane16_swap per pair of packed registers turns the two 16-key halves of a 32-key
+//    sub-tile into the fragments of the two 16-row query halves (8 swaps per block and tile);
+//  * the V^T image in memory stays as it is: the key order a swapped P fragment ends up with is the stored order with the middle two
+//    8-key blocks of every 32 exchanged - an address permutation on the fragment read (lane row j reads block {0, 2, 1, 3}[j]);
+//  * O^T is 2 x 5 x 2 four-register tiles per wave (80 AGPRs), V^T fragments are 10 per tile (one per 32 keys x 16 head-dim rows);
+//  * the four segments of a tile are 320 matrix-pipe cycles each (10 QK^T MFMAs of 32 cycles / 20 PV MFMAs of 16), and a PV "gap"
+//    is two MFMAs (the two query halves of one fragment) followed by the fillers.
+// PV sums 32 keys per MFMA instead of 16, so results equal v3 / v4 to fp32 rounding, not bit for bit.
+//
+// RESULT (profiles/r02/attn_v5_pv16x16_vs_v4_trace.log, ubench_mfma_filler_budget.log): parity green, but 2019 shader clocks per tile
+// against v4's 1719 - at 1.85 instead of 1.59 GHz, i.e. the same time.  An MFMA blocks its wave's issue for ~12 cycles whatever its
+// shape: a 32-cycle 32x32x16 leaves ~20 cycles (five fillers) for the softmax, a 16-cycle 16x16x32 leaves none, and the kernel is
+// issue-bound.  Kept as the record of that measurement; EXPERIMENTAL=1 builds only (attention_variant 5).
+// Requires whole 64-key tiles, no per-sample key counts and at most 256 text keys (launch_attention falls back to v3 otherwise).
+#include "../common.h"
+#include "../kernels.h"
+#include <type_traits>
+
+namespace lt_attn {
+
+#include "attention_v5_asm.inc"
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v5(AttnArgs p) {
+    static_assert(HD == 72, "v4 is built for hd 72 (max / row sum folded into the MFMAs through the pad slots)");
+    constexpr int KS = 5, DT = 5, NB = 2;  // QK^T k-steps of 16; O^T row tiles of 16 (72 head-dim rows + the row of ones + 7 idle)
+    constexpr int KTILE = 64 * HD * 2;        // 9216
+    constexpr int VTILE = HD * 128 + 128;     // incl. the row of ones
+    // LDS: K ring (4 slots) | V^T ring (4 slots) | the pad chunks, laid out at the K ring's (slot, sub-tile) strides so that every
+    // fragment read is `lane address + immediate`, whatever the ring slot (the tile loop is unrolled by the ring depth)
+    constexpr int K_BASE = 0, V_BASE = 4 * KTILE, CONST_OFF = V_BASE + 4 * VTILE;
+    constexpr int NKP = 9, NVP = 9, NPIECE = NKP + NVP, IP = 5;  // 1-KiB staging pieces per (K, V^T) tile pair; per wave and tile
+    constexpr float THR = 8.0f;
+    // the softmax denominator = O^T row HD: tile HD / 16, lane row (HD % 16) / 4, register HD % 4
+    constexpr int L_DT = HD / 16, L_J = (HD % 16) / 4, L_REG = HD % 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    unsigned long long tr_entry = 0, tr_loop0 = 0, tr_loop1 = 0, tr_clk = 0;  // diagnostics (lt_op_attention_trace): phase stamps
+    if (p.trace) tr_entry = __builtin_amdgcn_s_memrealtime();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int nqb = (p.N + 255) / 256;
+    const int BH = p.B * p.H;
+    int bh, qb;
+    if ((BH & 7) == 0) {  // XCD-aware: head bh lives on XCD bh % 8, its q-blocks run back to back (K/V stay in that L2)
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bh = xcd + 8 * (idx / nqb);
+        qb = idx % nqb;
+    } else {
+        bh = blockIdx.x / nqb;
+        qb = blockIdx.x % nqb;
+    }
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int bhk = b * p.Hkv + h / (p.H / p.Hkv);
+
+    // constants in LDS: ones rows behind each V^T slot, and the K-side pad chunks - one per key, at the K ring's (slot, sub-tile,
+    // key) strides / 9: (1, 1, b, 0, 0, 0, 0, 0) with b = 0 for image keys and the key's additive mask (0 / -inf) for text keys
+    if (tid < 128) *(unsigned*)(smem + V_BASE + (tid >> 5) * VTILE + HD * 128 + (tid & 31) * 4) = 0x3F803F80u;
+    auto pad_chunk = [&](int slot, int kt2, int key) __attribute__((always_inline)) {
+        return (u32x4*)(smem + CONST_OFF + slot * KTILE + kt2 * (32 * HD * 2) + key * 16);
+    };
+    *pad_chunk(tid >> 6, (tid >> 5) & 1, tid & 31) = u32x4{0x3F803F80u, 0u, 0u, 0u};
+
+    // ---- staging: 18 one-KiB pieces per (K, V^T) tile pair, five per wave (two duplicates), branch-free ----------------------
+    // piece q = wave + 4 i (q >= 18: q - 4 again, same bytes to the same place); q < 9: bytes [1024 q, +1024) of the K tile's LDS
+    // image; else V^T rows 8 (q - 9) .. +7 (128-byte rows, chunk-swizzled on the source address)
+    int st_lds[IP], st_voff[IP];
+    const bool s2_is_k = (wave == 0);  // slots 0, 1 are K pieces and 3, 4 V^T pieces for every wave; slot 2 is K piece 8 for wave 0
+    auto v_voff = [&](int j, int v_ld) __attribute__((always_inline)) {
+        const int d = 8 * j + (lane >> 3);
+        return d * v_ld * 2 + (((lane & 7) ^ ((d >> 1) & 7)) << 4);
+    };
+    __amdgpu_buffer_rsrc_t rK, rV, rS2;
+    auto make_src = [&](const u16* k_head, int k_rows, const u16* v_head, int v_ld) __attribute__((always_inline)) {
+        const int kbytes = (int)((size_t)k_rows * HD * 2), vbytes = (int)((size_t)HD * v_ld * 2);
+        rK = __builtin_amdgcn_make_buffer_rsrc((void*)k_head, 0, kbytes, 0x00020000);
+        rV = __builtin_amdgcn_make_buffer_rsrc((void*)v_head, 0, vbytes, 0x00020000);
+        rS2 = __builtin_amdgcn_make_buffer_rsrc((void*)(s2_is_k ? k_head : v_head), 0, s2_is_k ? kbytes : vbytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < IP; ++i) {
+            int q = wave + 4 * i;
+            if (q >= NPIECE) q -= 4;
+            const bool isk = q < NKP;
+            const int j = isk ? q : q - NKP;
+            st_lds[i] = (isk ? K_BASE : V_BASE) + j * 1024;
+            st_voff[i] = isk ? j * 1024 + lane * 16 : v_voff(j, v_ld);
+        }
+    };
+    // piece i of the batch {K(tk), V^T(tv)} into ring slots ks / vs (compile-time constants in the tile loop)
+    auto dma = [&](int i, int tk, int tv, int ks, int vs) __attribute__((always_inline)) {
+        const bool isk = i < 2 || (i == 2 && s2_is_k);
+        const int dst = st_lds[i] + (isk ? ks * KTILE : vs * VTILE);
+        const int soff = isk ? tk * KTILE : tv * 128;
+        if (i < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, LDS_PTR(smem + dst), 16, st_voff[i], soff, 0, 0);
+        else if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rS2, LDS_PTR(smem + dst), 16, st_voff[i], soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(smem + dst), 16, st_voff[i], soff, 0, 0);
+    };
+    // ---- per-lane LDS read addresses (absolute LDS byte addresses: the fragment reads are inline assembly) -------------------------
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    const int ka = (int)lds0 + K_BASE + l31 * (HD * 2) + hi * 16;  // + slot * KTILE + kt2 * 32 * HD * 2 + 32 s  (immediates)
+    // last k-step: the hi half reads its key's pad chunk (1, 1, mask, 0, ..), the lo half hd 64..71 of its key row
+    const int kp = hi ? (int)lds0 + CONST_OFF + l31 * 16 : ka + (KS - 1) * 32;
+    // V^T fragment (kh, dt): A operand of a 16x16x32 MFMA = rows d = 16 dt + (lane & 15), 8 keys per lane row j = lane >> 4.  After
+    // the permlane16 exchange a P fragment's lane row j holds, in stored key order, the 8-key block {0, 2, 1, 3}[j] of the 32-key half
+    // kh: chunk 4 kh + {0, 2, 1, 3}[j] of the V^T row, at LDS position chunk ^ ((d >> 1) & 7).  dt 0..3: immediate 2048 dt on va[kh];
+    // dt 4 (rows 64.., clamped to the row of ones) has its own addresses
+    int va[2], va4[2];
+    {
+        const int m = lane & 15, j = lane >> 4;
+        const int blk8 = ((j & 1) << 1) | (j >> 1);  // {0, 2, 1, 3}[j]
+        const int d4 = (64 + m > HD) ? HD : 64 + m;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            va[kh] = (int)lds0 + V_BASE + m * 128 + (((4 * kh + blk8) ^ ((m >> 1) & 7)) << 4);
+            va4[kh] = (int)lds0 + V_BASE + d4 * 128 + (((4 * kh + blk8) ^ ((d4 >> 1) & 7)) << 4);
+        }
+    }
+
+    f32x16 sc[NB][2];     // scores of the current tile, two 32-key sub-tiles per block; exp2 in place
+    u32x4 pa[NB][4];      // P of the current tile as bf16 pairs, index 2 kh + half: after the permlane16 exchange of a 32-key half kh's two
+                          // entries, entry 2 kh + qh is the PV operand of query half qh
+    float m_run[NB] = {0.f, 0.f}, mxv[NB] = {0.f, 0.f};
+    v5_o_zero(0);
+    v5_o_zero(1);
+    v5_kc_init(hi ? 0x3F803F80u : 0u);
+
+    auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+    auto bar = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // fragment reads: asm on both ends (the compiler neither copies the AGPR fragments nor knows about their latency: the consumers
+    // wait with s_waitcnt lgkmcnt, see iter())
+    auto read_k = [&](int n, int slot) __attribute__((always_inline)) { v5_read_k(n, slot, ka, kp); };
+    auto read_v = [&](int n, int slot) __attribute__((always_inline)) { v5_read_v(n, slot, va[n / 5], va4[n / 5]); };  // n = 5 kh + dt
+    auto mfma_qk = [&](int blk, int n) __attribute__((always_inline)) { v5_mfma_qk(blk, n, sc[blk][n & 1]); };
+    // one PV gap: fragment n = 5 kh + dt against both query halves
+    auto mfma_pv = [&](int blk, int n) __attribute__((always_inline)) {
+        v5_mfma_pv(blk, n, 0, pa[blk][2 * (n / 5)]);
+        v5_mfma_pv(blk, n, 1, pa[blk][2 * (n / 5) + 1]);
+    };
+    auto lgkm0 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+    // ---- softmax of one block's tile, cut into the 19 filler groups of its window ------------------------------------------------
+    // Window gap w (0..21: the two segments a block's softmax hides under, + 2).  Nothing in gaps 0, 1 (the scores' last MFMAs are still
+    // in flight); the rest is packed by measured issue cost
+    // (scripts/ubench/valu_rate.hip: v_exp_f32 8 cycles, v_max3 / v_cvt_pk 4.5) to <= 25 cycles per gap beside the gap's one fragment
+    // read or DMA piece and the MFMA's own issue slot (32 cycles per MFMA):
+    //   2-5: 4 max3 | 6: fold, exchange with the row's other half | 7: move the folded maximum if the tile exceeds it by 2^THR (rare
+    //   wave-uniform branch) | 8-22: per 16-key group 8 exp2 in place + 4 cvt_pk into the PV operand, three exp2 (or the equivalent) per gap
+    // Every step is an inline-asm statement: the written order is the issue order.  (The hazard recognizer puts a wait state between
+    // two dependent inline-asm statements with no compiler-visible instruction between them: the order below keeps such pairs rare.)
+    // hot = true (tiles >= 1 of the self-attention loop): the rare branch touches the scores, O^T and Q only through inline assembly
+    // (v5_score_shift: the move is one extra MFMA per sub-tile against the constant K fragment) - the hot path then has no register
+    // copies at the join.  hot = false (tile 0, text tiles): plain VALU form, with the forced move of a first tile.
+#define S_(g, i) sc[blk][(g) >> 1][8 * ((g) & 1) + (i)]
+    // one asm statement per instruction: with several elements of a score tuple as operands of ONE statement the register allocator
+    // stops treating them as sub-registers of the MFMA's tuple and copies 20 registers per block and tile
+    auto exp1 = [&](int blk, int g, int i) __attribute__((always_inline)) {
+        float x = S_(g, i);
+        asm volatile("v_exp_f32 %0, %0" : "+v"(x));
+        S_(g, i) = x;
+    };
+    auto cvt1 = [&](int blk, int g, int j) __attribute__((always_inline)) {
+        const float x = S_(g, 2 * j), y = S_(g, 2 * j + 1);
+        unsigned wd;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(wd) : "v"(x), "v"(y));
+        pa[blk][g][j] = wd;
+    };
+    auto exps = [&](int blk, int g, int i, int n) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < n; ++e) exp1(blk, g, i + e);
+    };
+    auto cvts = [&](int blk, int g, int j, int n) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < n; ++e) cvt1(blk, g, j + e);
+    };
+    auto exp2_cvt2 = [&](int blk, int ge, int i, int gc, int j, bool cvt_first) __attribute__((always_inline)) {
+        if (cvt_first) { cvts(blk, gc, j, 2); exps(blk, ge, i, 2); }
+        else { exps(blk, ge, i, 2); cvts(blk, gc, j, 2); }
+    };
+    // P of a 32-key half kh: entries 2 kh (keys 0-3, 8-11 | 4-7, 12-15 of the half, by lane half) and 2 kh + 1 (keys 16.. likewise) ->
+    // the fragments of the two 16-row query halves: v_permlane16_swap exchanges lane rows 1 <-> 0 and 3 <-> 2 of the two registers
+    // (two wait states between a VALU write and the permlane's read of it: the schedule puts other steps in between)
+    auto swaps = [&](int blk, int kh, int i, int n) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < n; ++e) {
+            unsigned x = pa[blk][2 * kh][i + e], y = pa[blk][2 * kh + 1][i + e];
+            asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+            pa[blk][2 * kh][i + e] = x;
+            pa[blk][2 * kh + 1][i + e] = y;
+        }
+    };
+    // running tile max over score indices k0 .. k0 + 3 of both sub-tiles: four independent accumulators (a dependent pair of asm
+    // statements costs a wait state; this way it is one per gap), folded and exchanged with the row's other half in gap 6
+    float mx4[NB][4];
+    auto max4 = [&](int blk, int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = sc[blk][0][k0 + e], b = sc[blk][1][k0 + e];
+            if (k0 == 0) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mx4[blk][e]) : "v"(a), "v"(b));
+            else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx4[blk][e]) : "v"(a), "v"(b));
+        }
+    };
+    auto max_fold = [&](int blk) __attribute__((always_inline)) {
+        float a, b;
+        asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(a) : "v"(mx4[blk][0]), "v"(mx4[blk][1]), "v"(mx4[blk][2]), "v"(mx4[blk][3]));
+        b = a;
+        // the other 16 keys of the row's 32-key sub-tiles live on lane ^ 32: v_permlane32_swap puts (own, partner) halves side by side
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+        mxv[blk] = a;
+    };
+    auto decide = [&](int blk, int t, bool hot) __attribute__((always_inline)) {
+        const float mx = mxv[blk];
+        const bool first = !hot && (t == 0);
+        const bool raise = first || (mx > THR);
+        if (__builtin_expect(__any(raise), 0)) {
+            // new running max = m_run + mx (scores are relative to m_run already), rounded to the bf16 pair (hi + lo) the MFMA
+            // will actually subtract from now on; delta is the step between the two REPRESENTED values
+            const float nm = -(m_run[blk] + (raise ? mx : 0.f));
+            const float nm_hi = bfr(nm);
+            const float nm_lo = bfr(nm - nm_hi);
+            const float m_new = -(nm_hi + nm_lo);
+            const float delta = m_new - m_run[blk];
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            if (hot) {
+                // the pair Q carries now (it represents -m_run exactly, so it can be recomputed)
+                const float p_hi = bfr(-m_run[blk]);
+                const float p_lo = bfr(-m_run[blk] - p_hi);
+                v5_score_shift(hi ? pack2bf(nm_hi, nm_lo) : 0u, hi ? pack2bf(-p_hi, -p_lo) : 0u, sc[blk][0], sc[blk][1]);
+            } else {
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[blk][kt2][r] -= delta;
+            }
+            m_run[blk] = m_new;
+            // O^T tiles hold query row 16 qh + (lane & 15): that row's factor lives on lane 16 qh + (lane & 15) of this layout
+            v5_o_scale(blk, 0, __shfl(alpha, lane & 15, 64));
+            v5_o_scale(blk, 1, __shfl(alpha, 16 + (lane & 15), 64));
+            if (hi) v5_q_pad_write(blk, pack2bf(nm_hi, nm_lo));  // pad slots 0 and 1 of the last k-step live on the hi half
+        }
+    };
+    // w = 0 .. 24: gaps 0-9 = the other block's PV segment, 10-19 = its QK^T segment, 20-24 = the first five gaps of the block's own
+    // PV segment (its first five gaps multiply the 32-key half 0 only, so half 1's P may still be under way)
+    auto sm_fill = [&](int blk, int w, int t, bool hot) __attribute__((always_inline)) {
+        switch (w) {
+            case 2: case 3: case 4: case 5: max4(blk, 4 * (w - 2)); break;
+            case 6: max_fold(blk); break;
+            case 7: decide(blk, t, hot); exps(blk, 0, 0, 1); break;
+            case 8: exps(blk, 0, 1, 2); break;
+            case 9: exps(blk, 0, 3, 2); break;
+            case 10: exps(blk, 0, 5, 3); break;
+            case 11: cvts(blk, 0, 0, 4); break;
+            case 12: exps(blk, 1, 0, 3); break;
+            case 13: exps(blk, 1, 3, 3); break;
+            case 14: exps(blk, 1, 6, 2); cvts(blk, 1, 0, 2); break;
+            case 15: cvts(blk, 1, 2, 2); swaps(blk, 0, 0, 2); break;
+            case 16: swaps(blk, 0, 2, 2); exps(blk, 2, 0, 2); break;
+            case 17: exps(blk, 2, 2, 3); break;
+            case 18: exps(blk, 2, 5, 3); break;
+            case 19: cvts(blk, 2, 0, 4); exps(blk, 3, 0, 1); break;
+            case 20: exps(blk, 3, 1, 3); break;
+            case 21: exps(blk, 3, 4, 2); break;
+            case 22: exps(blk, 3, 6, 2); break;
+            case 23: cvts(blk, 3, 0, 4); break;
+            case 24: swaps(blk, 1, 0, 4); break;
+            default: break;
+        }
+    };
+
+    // one tile; J = t & 3 (ring slot of K(t) and V^T(t)) is a compile-time constant: the loop below is unrolled by the ring depth, so
+    // every LDS offset is an immediate and the scalar work per tile is the DMA's m0 writes and two running offsets.
+    // HAS_PREV = false: tile 0 (no softmax_B / PV_B of a previous tile).  Every segment is ten gaps of 32 matrix-pipe cycles.
+    auto iter = [&](int t, auto has_prev_c, auto slot_c) __attribute__((always_inline)) {
+        constexpr bool HAS_PREV = decltype(has_prev_c)::value;
+        constexpr int J = decltype(slot_c)::value, J1 = (J + 1) & 3, J2 = (J + 2) & 3, J3 = (J + 3) & 3;
+        // seg 1: QK^T_A(t) | softmax_B(t-1) second half | the five DMA pieces (one per odd gap)
+        lgkm0();  // K(t) fragments (read during seg 3 / 4 of the previous tile, or the prologue)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            mfma_qk(0, i);
+            if (i & 1) dma(i >> 1, t + 3, t + 2, J3, J2);
+            if constexpr (HAS_PREV) sm_fill(1, 10 + i, t - 1, true);  // (second half: no max move in it)
+            fence();
+        }
+        // seg 2: PV_B(t-1) | softmax_A(t) first half | V^T(t) fragment n two gaps after PV_B's MFMAs n released its register
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            if constexpr (HAS_PREV) mfma_pv(1, i);
+            else if (i == 0) { asm volatile("s_nop 15"); asm volatile("s_nop 15"); }  // the scores' MFMAs complete uncovered
+            if (i >= 2) read_v(i - 2, J);
+            if constexpr (HAS_PREV) { if (i < 5) sm_fill(1, 20 + i, t - 1, true); }
+            sm_fill(0, i, t, HAS_PREV);
+            fence();
+        }
+        // seg 3: QK^T_B(t) | softmax_A(t) second half | last two V^T(t) fragments, then K(t+1) fragment n two gaps after its MFMA
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            mfma_qk(1, i);
+            if (i < 2) read_v(8 + i, J);
+            else read_k(i - 2, J1);
+            sm_fill(0, 10 + i, t, HAS_PREV);
+            fence();
+        }
+        // seg 4: PV_A(t) | softmax_B(t) first half | last two K(t+1) fragments
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // V^T(t) fragments (the eight K reads behind them may stay in flight)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            mfma_pv(0, i);
+            if (i < 2) read_k(8 + i, J1);
+            if (i < 5) sm_fill(0, 20 + i, t, HAS_PREV);
+            sm_fill(1, i, t, HAS_PREV);
+            fence();
+        }
+        // K(t+2), V(t+1) (issued one tile ago) have landed; this tile's five pieces may stay in flight
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        bar();
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    using C3 = std::integral_constant<int, 3>;
+    using T_ = std::true_type;
+
+    // ---- two phases through the same tile pipeline: the image keys (self-attention), then - fused zero-init gated text
+    //      cross-attention (model.py:420-434) - the text keys of the same Q rows (post-RoPE, :427) with fresh O^T / maximum -----------
+    u32x2 res[NB][DT][2];  // result, bf16 (flash-attn output dtype, model.py:392-405): [block][head-dim tile][query half]
+    int qrow[NB];
+    bool q_ok[NB];
+    const int nph = p.tk ? 2 : 1;
+    // the text keys' mask values (0 / -inf: scale free), one per thread = per text key, fetched now and written into the pad chunks
+    // when the text phase is set up
+    float text_bias = -INFINITY;
+    if (p.tk && tid < p.Tkpad) text_bias = p.tbias[(size_t)b * p.Tkpad + tid];
+    // sources of a phase + its first batches: {K(0)}, {K(1), V(0)}, {K(2), V(1)}  (what iterations -3, -2, -1 would have issued).
+    // Phase 1 is started right after the last barrier of phase 0's tile loop - the ring and the pad chunks are idle from there on -
+    // so that its tiles fly under phase 0's drain and epilogue.
+    auto start_phase = [&](int ph) __attribute__((always_inline)) {
+        if (ph == 0) {
+            make_src(p.k + (size_t)bhk * p.Nk * HD, p.Nk, p.vt + (size_t)bhk * HD * p.Nkpad, p.Nkpad);
+        } else {
+            make_src(p.tk + (size_t)bhk * p.Tk * HD, p.Tk, p.tvt + (size_t)bhk * HD * p.Tkpad, p.Tkpad);
+            // thread -> text key tid (tile tid >> 6, at most four tiles: launcher): (1, 1, mask, 0, ..)
+            *pad_chunk(tid >> 6, (tid >> 5) & 1, tid & 31) = u32x4{0x3F803F80u, (unsigned)f2bf(text_bias), 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < IP; ++i) {
+            const bool isk = i < 2 || (i == 2 && s2_is_k);
+            if (isk) dma(i, 0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IP; ++i) dma(i, 1, 0, 1, 0);
+#pragma unroll
+        for (int i = 0; i < IP; ++i) dma(i, 2, 1, 2, 1);
+    };
+    start_phase(0);
+    for (int ph = 0; ph < nph; ++ph) {
+        const int nt = ph == 0 ? p.Nk / 64 : (p.Tk + 63) / 64;
+        if (ph == 1) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                v5_o_zero(blk);
+                m_run[blk] = 0.f;
+                if (hi) v5_q_pad_write(blk, 0u);
+            }
+        }
+        if (ph == 0) {
+        // (after the first tiles' DMA is in flight: the Q rows' global loads and their conversion overlap it)
+        // ---- Q fragments of both blocks, pre-scaled to the log2 domain unless K carries the scale --------------------------------
+        const float sl2 = p.k_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            qrow[blk] = qb * 256 + wave * 64 + blk * 32 + l31;
+            q_ok[blk] = qrow[blk] < p.N;
+            if (!q_ok[blk]) qrow[blk] = p.N - 1;
+            const u16* qptr = p.q + ((size_t)bh * p.N + qrow[blk]) * HD;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int d0 = 16 * s + 8 * hi;
+                // pad half of the last k-step (d0 >= HD): slots 0, 1 become (-m_hi, -m_lo); slot 2 = 1.0 multiplies the key's mask value
+                unsigned w[4] = {0u, d0 < HD ? 0u : 0x00003F80u, 0u, 0u};
+                if (d0 < HD) {
+                    const bf8_t raw = *(const bf8_t*)(qptr + d0);
+                    float f[8];
+                    unpack8(raw, f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = pack2bf(f[2 * e] * sl2, f[2 * e + 1] * sl2);
+                }
+                v5_q_write(blk, s, w[0], w[1], w[2], w[3]);
+            }
+        }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // DMA landed, constant rows / pad chunks written
+        bar();
+#pragma unroll
+        for (int n = 0; n < 2 * KS; ++n) read_k(n, 0);
+
+        if (p.trace && ph == 0) { tr_loop0 = __builtin_amdgcn_s_memrealtime(); tr_clk = __builtin_amdgcn_s_memtime(); }
+        iter(0, std::false_type{}, C0{});
+        if (nt > 1) iter(1, T_{}, C1{});
+        if (nt > 2) iter(2, T_{}, C2{});
+        if (nt > 3) iter(3, T_{}, C3{});
+        int t = 4;
+        for (; t + 3 < nt; t += 4) {
+            iter(t, T_{}, C0{});
+            iter(t + 1, T_{}, C1{});
+            iter(t + 2, T_{}, C2{});
+            iter(t + 3, T_{}, C3{});
+        }
+        if (t < nt) iter(t, T_{}, C0{});
+        if (t + 1 < nt) iter(t + 1, T_{}, C1{});
+        if (t + 2 < nt) iter(t + 2, T_{}, C2{});
+        if (p.trace && ph == 0) { tr_loop1 = __builtin_amdgcn_s_memrealtime(); tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
+        if (ph + 1 < nph) start_phase(ph + 1);
+        // drain: softmax_B(last) second half, PV_B(last)
+#pragma unroll
+        for (int w = 10; w < 25; ++w) { sm_fill(1, w, nt - 1, nt > 1); fence(); }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { mfma_pv(1, i); fence(); }
+        fence();
+
+        // O^T tile (blk, dt, qh): lane = (query row 16 qh + (lane & 15), head-dim rows 16 dt + 4 (lane >> 4) .. + 3).  The softmax
+        // denominator is O^T row HD: register L_REG of tile L_DT on lane row L_J
+        const float gate = ph == 0 ? 0.f : bfr(tanhf(bf2f(p.tgate[h])));
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                f32x4 ot[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) ot[dt] = v5_o_read(blk, dt, qh);
+                const float inv = 1.0f / __shfl(ot[L_DT][L_REG], 16 * L_J + (lane & 15), 64);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    if (ph == 0) {
+                        res[blk][dt][qh][0] = pack2bf_pk(ot[dt][0] * inv, ot[dt][1] * inv);
+                        res[blk][dt][qh][1] = pack2bf_pk(ot[dt][2] * inv, ot[dt][3] * inv);
+                    } else {
+                        // output + bf16(output_y * tanh(gate))  (model.py:433-434, bf16 rounding points)
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = bfr(bfr(ot[dt][j] * inv) * gate);
+                        res[blk][dt][qh][0] = pack2bf(bf_lo(res[blk][dt][qh][0]) + v[0], bf_hi(res[blk][dt][qh][0]) + v[1]);
+                        res[blk][dt][qh][1] = pack2bf(bf_lo(res[blk][dt][qh][1]) + v[2], bf_hi(res[blk][dt][qh][1]) + v[3]);
+                    }
+                }
+            }
+    }
+
+    // a lane holds query row 16 qh + (lane & 15) of its block: four consecutive head-dim values per tile = 8-byte stores
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+            const int row = qb * 256 + wave * 64 + blk * 32 + 16 * qh + (lane & 15);
+            if (row < p.N) {
+                u16* orow = p.out + ((size_t)b * p.N + row) * ((size_t)p.H * HD) + (size_t)h * HD;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int d0 = 16 * dt + 4 * (lane >> 4);
+                    if (d0 < HD) *(u32x2*)(orow + d0) = res[blk][dt][qh];
+                }
+            }
+        }
+    if (p.trace && tid == 0) {  // per workgroup: s_memrealtime (100 MHz) at entry | loop start | loop end | exit, shader clocks of the loop
+        unsigned long long* o = p.trace + (size_t)blockIdx.x * 8;
+        o[0] = tr_entry; o[1] = tr_loop0; o[2] = tr_loop1; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = tr_clk; o[5] = (unsigned long long)(p.Nk / 64);
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // XCC_ID
+        o[7] = 0;
+    }
+}
+
+template __global__ void attn_fwd_kernel_v5<72>(AttnArgs);
+
+}  // namespace lt_attn
+
+int launch_attention_v5(const AttnArgs& a, hipStream_t stream) {
+    constexpr int SMEM72 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 3 * (64 * 72 * 2) + 32 * 72 * 2 + 16;  // rings + the strided constant chunks
+    static bool attr_done = false;
+    if (!attr_done) {
+        LT_CHECK_HIP(hipFuncSetAttribute((const void*)lt_attn::attn_fwd_kernel_v5<72>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM72));
+        attr_done = true;
+    }
+    const int nqb = (a.N + 255) / 256;
+    hipLaunchKernelGGL(lt_attn::attn_fwd_kernel_v5<72>, dim3(a.B * a.H * nqb), dim3(256), SMEM72, stream, a);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 from gpu_util import P, lib, ok, set_option, stream  # noqa: E402
 
 L = lib()
-set_option("attention_variant", 4)
+VARIANT = int(os.environ.get("LT_ATTN_VARIANT", "4"))  # 4, or 5 (PV on 16x16x32 MFMAs: 1280 matrix-pipe cycles per tile)
+set_option("attention_variant", VARIANT)
 B, H, N, hd = 2, 32, 4096, 72
 q = torch.randn(B, H, N, hd, device="cuda").to(torch.bfloat16)
 k = torch.randn(B, H, N, hd, device="cuda").to(torch.bfloat16)
@@ -39,7 +40,7 @@ us = lambda c: c / 100.0
 pct = lambda x: " ".join(f"{np.percentile(x, p):8.2f}" for p in (0, 10, 50, 90, 100))
 ntile = t[:, 5]
 loop = us(t[:, 2] - t[:, 1])
-print(f"attention v4 B{B} H{H} N{N} hd{hd}: {nwg} items on {len(t)} persistent workgroups, event duration {wall:.1f} us, first entry -> last exit {us(t[:, 3].max() - t0):.1f} us")
+print(f"attention variant {VARIANT} B{B} H{H} N{N} hd{hd}: {nwg} items on {len(t)} persistent workgroups, event duration {wall:.1f} us, first entry -> last exit {us(t[:, 3].max() - t0):.1f} us")
 print("   percentiles over workgroups          min      p10      p50      p90      max")
 print(f"   entry after first entry       us: {pct(us(t[:, 0] - t0))}")
 print(f"   prologue (entry -> loop)      us: {pct(us(t[:, 1] - t[:, 0]))}")

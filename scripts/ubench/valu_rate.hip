@@ -22,10 +22,32 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, float* sink
         if (KIND == 7) asm volatile(REP64("v_exp_f16 %0, %0\n\tv_exp_f16 %1, %1\n\tv_exp_f16 %2, %2\n\tv_exp_f16 %3, %3\n\t") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
         if (KIND == 8) asm volatile(REP64("v_exp_f32 %0, %0\n\ts_nop 0\n\tv_exp_f32 %1, %1\n\ts_nop 0\n\t") : "+v"(a0), "+v"(a1));
         if (KIND == 9) asm volatile(REP64("v_exp_f32 %0, %0\n\tv_mfma_f32_32x32x16_bf16 a[0:15], v[200:203], v[204:207], a[0:15]\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\t") : "+v"(a0), "+v"(a1), "+v"(a2) :: "a0","a15","v200","v207");
+        if (KIND >= 10 && KIND < 20) {  // one 32x32x16 MFMA + (KIND - 10) + 3 v_mul per group
+            constexpr int NM = KIND - 10 + 3;
+            for (int r = 0; r < 64; ++r) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], v[200:203], v[204:207], a[0:15]" ::: "a0", "a15", "v200", "v207");
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {  // independent fillers (eight registers in rotation)
+                    float& x = (m & 7) == 0 ? a0 : (m & 7) == 1 ? a1 : (m & 7) == 2 ? a2 : (m & 7) == 3 ? a3 : (m & 7) == 4 ? a4 : (m & 7) == 5 ? a5 : (m & 7) == 6 ? a6 : a7;
+                    asm volatile("v_mul_f32 %0, %0, %0" : "+v"(x));
+                }
+            }
+        }
+        if (KIND >= 20 && KIND < 30) {  // two 16x16x32 MFMAs + (KIND - 20) + 2 v_mul per group
+            constexpr int NM = KIND - 20 + 2;
+            for (int r = 0; r < 64; ++r) {
+                asm volatile("v_mfma_f32_16x16x32_bf16 a[0:3], v[200:203], v[204:207], a[0:3]\n\tv_mfma_f32_16x16x32_bf16 a[4:7], v[200:203], v[208:211], a[4:7]" ::: "a0", "a7", "v200", "v211");
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    float& x = (m & 7) == 0 ? a0 : (m & 7) == 1 ? a1 : (m & 7) == 2 ? a2 : (m & 7) == 3 ? a3 : (m & 7) == 4 ? a4 : (m & 7) == 5 ? a5 : (m & 7) == 6 ? a6 : a7;
+                    asm volatile("v_mul_f32 %0, %0, %0" : "+v"(x));
+                }
+            }
+        }
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-    sink[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3;
+    sink[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 template <int KIND>
 void run(const char* name, int per_iter) {
@@ -50,5 +72,17 @@ int main() {
     run<7>("v_exp_f16", 4);
     run<8>("v_exp_f32 + s_nop 0 (pairs)", 4);
     run<9>("1 MFMA 32x32x16 + 3 v_exp_f32 (per 4)", 4);
+    // ticks per GROUP = 4 x the printed value when per_iter is set to 4: print per group instead
+    run<10>("[per group/4] MFMA32 + 3 v_mul", 4);
+    run<12>("[per group/4] MFMA32 + 5 v_mul", 4);
+    run<13>("[per group/4] MFMA32 + 6 v_mul", 4);
+    run<14>("[per group/4] MFMA32 + 7 v_mul", 4);
+    run<15>("[per group/4] MFMA32 + 8 v_mul", 4);
+    run<17>("[per group/4] MFMA32 + 10 v_mul", 4);
+    run<20>("[per group/4] 2 MFMA16 + 2 v_mul", 4);
+    run<22>("[per group/4] 2 MFMA16 + 4 v_mul", 4);
+    run<23>("[per group/4] 2 MFMA16 + 5 v_mul", 4);
+    run<24>("[per group/4] 2 MFMA16 + 6 v_mul", 4);
+    run<26>("[per group/4] 2 MFMA16 + 8 v_mul", 4);
     return 0;
 }

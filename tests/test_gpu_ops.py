@@ -435,7 +435,8 @@ def _run_attn(q, k, v, scale, bias=None, gate=None, prev=None, fold_scale=False)
     return out.view(B, N, H, hd).permute(0, 2, 1, 3)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])  # 4: one wave per SIMD x 64 query rows (hd 72, whole tiles; else it runs variant 3)
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])  # 4 / 5: one wave per SIMD x 64 query rows (hd 72, whole tiles; else variant 3); 5 (EXPERIMENTAL=1 builds,
+                                                    # else it runs 4): PV on 16x16x32 MFMAs
 @pytest.mark.parametrize("B,H,Hkv,N,hd", [(1, 8, 8, 128, 72), (2, 8, 2, 320, 72), (2, 4, 4, 200, 72), (1, 3, 3, 64, 72),
                                           (2, 32, 32, 4096, 72), (1, 8, 8, 256, 48), (1, 8, 8, 192, 96),
                                           (1, 8, 8, 1000, 72), (1, 2, 2, 40, 72),
@@ -457,7 +458,7 @@ def test_attention_self(variant, B, H, Hkv, N, hd, fold):
 
 
 @pytest.mark.parametrize("hd", [72, 96])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_attention_softmax_outlier_keys(variant, hd):
     """forces large running-max jumps mid-sequence, above and below the deferred-rescale threshold (guide 5.4
     rule 26); v1 (rescale every tile), v2 (threshold 8 in log2 units) and v3 (same threshold; hd 72: max folded into the
@@ -502,7 +503,7 @@ def test_attention_text_accumulate(variant, T, valid1, fold):
 @pytest.mark.parametrize("hd", [72, 96])
 @pytest.mark.parametrize("B,H,Hkv,N,T,valid1", [(2, 8, 8, 320, 128, 8), (2, 8, 2, 200, 77, 30), (1, 4, 4, 4096, 256, 256),
                                                   (2, 4, 4, 96, 300, 130), (2, 4, 2, 512, 128, 100)])
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 5])
 def test_attention_fused_text(B, H, Hkv, N, T, valid1, hd, variant):
     """one launch = self-attention + gated text cross-attention (model.py:392-434), both K pre-scaled (engine path)"""
     set_option("attention_variant", variant)
@@ -562,12 +563,15 @@ def test_attention_v4_is_bit_identical_to_v3(B, H, Hkv, N, outliers):
         k[:, :, :64] -= q[:, ::rep, 50:51] * 3.0
     scale = math.sqrt(math.log(N, 64) / hd) if N > 64 else 1 / math.sqrt(hd)
     outs = []
-    for variant in (3, 4):
+    for variant in (3, 4, 5):
         set_option("attention_variant", variant)
         outs.append(_run_attn(q, k, v, scale, fold_scale=True).clone())
     assert torch.equal(outs[0], outs[1]), rel_l2(outs[1], outs[0])
+    # variant 5 sums 32 keys per PV MFMA instead of 16: equal to fp32 rounding of the accumulation, i.e. a few bf16 ulps of the output
+    assert rel_l2(outs[2], outs[0]) < 1.5e-3, rel_l2(outs[2], outs[0])
     ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), scale)
     assert rel_l2(outs[1], ref) < 6e-3
+    assert rel_l2(outs[2], ref) < 6e-3
 
 
 @pytest.mark.parametrize("B,H,Hkv,N,T,valid1", [(2, 8, 8, 320, 128, 8), (2, 8, 2, 192, 77, 30), (1, 4, 4, 4096, 256, 256), (2, 4, 2, 512, 40, 33),
