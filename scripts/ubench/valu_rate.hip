@@ -7,6 +7,9 @@
 #define REP64(x) REP8(REP8(x))
 template <int KIND>
 __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, float* sink, float seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sink, 0, 256 * 256 * 4, 0x00020000);
+    const int voff = (threadIdx.x & 63) * 16;
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     unsigned long long t0, t1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier");
@@ -44,7 +47,20 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, float* sink
                 }
             }
         }
+        if (KIND >= 30 && KIND < 40) {  // MFMAs of one kind (+ one LDS-DMA piece per group for the even kinds): what a buffer_load ... lds costs the stream
+            for (int r = 0; r < 64; ++r) {
+                if (KIND < 32) asm volatile("v_mfma_f32_16x16x32_bf16 a[0:3], v[200:203], v[204:207], a[0:3]\n\tv_mfma_f32_16x16x32_bf16 a[4:7], v[200:203], v[208:211], a[4:7]\n\t"
+                                            "v_mfma_f32_16x16x32_bf16 a[8:11], v[200:203], v[204:207], a[8:11]\n\tv_mfma_f32_16x16x32_bf16 a[12:15], v[200:203], v[208:211], a[12:15]\n\t"
+                                            "v_mfma_f32_16x16x32_bf16 a[16:19], v[200:203], v[204:207], a[16:19]\n\tv_mfma_f32_16x16x32_bf16 a[20:23], v[200:203], v[208:211], a[20:23]\n\t"
+                                            "v_mfma_f32_16x16x32_bf16 a[24:27], v[200:203], v[204:207], a[24:27]\n\tv_mfma_f32_16x16x32_bf16 a[28:31], v[200:203], v[208:211], a[28:31]" ::: "a0", "a31", "v200", "v211");
+                else asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], v[200:203], v[204:207], a[0:15]\n\tv_mfma_f32_32x32x16_bf16 a[16:31], v[200:203], v[208:211], a[16:31]\n\t"
+                                  "v_mfma_f32_32x32x16_bf16 a[32:47], v[200:203], v[204:207], a[32:47]\n\tv_mfma_f32_32x32x16_bf16 a[48:63], v[200:203], v[208:211], a[48:63]" ::: "a0", "a63", "v200", "v211");
+                if ((KIND & 1) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (r & 7) * 1024), 16, voff, (r & 15) * 1024, 0, 0);
+                if ((r & 7) == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
     sink[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -53,8 +69,8 @@ template <int KIND>
 void run(const char* name, int per_iter) {
     unsigned long long* d; float* s;
     hipMalloc(&d, 256 * 8); hipMalloc(&s, 256 * 256 * 4);
-    hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(256), 0, 0, d, s, 0.001f);
-    hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(256), 0, 0, d, s, 0.001f);
+    hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(256), 8192, 0, d, s, 0.001f);
+    hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(256), 8192, 0, d, s, 0.001f);
     hipDeviceSynchronize();
     unsigned long long h[256]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     double n = 16.0 * 64 * per_iter;
@@ -84,5 +100,10 @@ int main() {
     run<23>("[per group/4] 2 MFMA16 + 5 v_mul", 4);
     run<24>("[per group/4] 2 MFMA16 + 6 v_mul", 4);
     run<26>("[per group/4] 2 MFMA16 + 8 v_mul", 4);
+    // groups of 128 matrix-pipe cycles: ticks per group = 4 x the printed value
+    run<31>("[per group/4] 8 MFMA16", 4);
+    run<30>("[per group/4] 8 MFMA16 + 1 buffer_load lds", 4);
+    run<33>("[per group/4] 4 MFMA32", 4);
+    run<32>("[per group/4] 4 MFMA32 + 1 buffer_load lds", 4);
     return 0;
 }
