@@ -93,6 +93,7 @@ const char* lt_last_error(void);
 const char* lt_version(void);
 
 /* process-wide kernel selection knobs (A/B measurements, tests; defaults are the measured-best settings):
+ *   "qkv_fused_gemm" 1 (default): Q | K | V projection in one launch where the shapes are whole 256 x 288 tiles
  *   "attention_variant" 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (hd 72 / 96) | 4 one wave per SIMD x 64 query rows,
  *                       asm-owned AGPRs (hd 72 with whole 64-key tiles; variant 3 otherwise) | 5 the same with PV on 16x16x32 MFMAs
  *   "gemm_variant"      0 auto tile shape (default) | 1 256x256 | 2 256x288
@@ -198,6 +199,11 @@ int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, 
  * M = B * tokens, tokens % 64 == 0, N = kv_heads * hd; variant 0 auto | 1 256x256 | 2 256x288. */
 int lt_op_gemm_vt(const void* A_dev, const void* W_dev, void* vt_dev, int32_t M, int32_t N, int32_t K, int32_t tokens,
                   int32_t hd, int32_t variant, void* stream);
+/* fused QKV projection (the engine's form at large M): C[M, N] gets columns [0, split) as a plain GEMM (row stride N; columns >= split
+ * are left untouched), vt gets the V columns [split, N) as the transposed image of lt_op_gemm_vt.  One launch of the persistent
+ * 256 x 288 kernel: split and N - split multiples of 288, tokens % 256 == 0, M % tokens == 0, K % 64 == 0, M / 256 * N / 288 >= #CUs. */
+int lt_op_gemm_qkv(const void* A_dev, const void* W_dev, void* C_dev, void* vt_dev, int32_t M, int32_t N, int32_t K, int32_t split,
+                   int32_t tokens, int32_t hd, void* stream);
 /* name of the kernel lt_op_gemm_bf16(..., variant) would launch for a dense problem (bench.py labels its roofline line with it) */
 int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap);
 /* grouped (mixture-of-experts) form of lt_op_gemm_bf16 - replaces the per-expert Python loop `for i, expert in

@@ -41,6 +41,7 @@ int g_qkv_post_fused = 0;
 // lt_set_option("qkv_vt_epilogue"): 1 = the V projection is its own GEMM launch whose epilogue writes the attention kernels' V^T
 // image (no v_transpose pass: 15.6 us per layer at cfg 2, and the 37.7 MB V slice is never written row-major / re-read)
 int g_qkv_vt_epilogue = 1;
+int g_qkv_fused_gemm = 1;  // lt_set_option("qkv_fused_gemm"): Q | K | V in one launch of the persistent kernel where the shapes allow it
 // lt_set_option("graph"): 1 = a model evaluation (~250 launches) is captured into a HIP graph per (arguments, shapes) and replayed.
 // Every lt_set_option bumps g_option_gen, which is part of the graph key (kernel selection is baked into a captured graph).
 int g_qk_post_pair = 1;  // lt_set_option("qk_post_pair"): 1 = q and k post-processing share one persistent launch (large problems)
@@ -537,7 +538,15 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         // only (a second launch of a latency-bound 512-row GEMM costs more than the transpose), whole 64-key tiles per sample
         // (no key padding to zero), and not for packed batches (their padded rows must read as zero keys)
         const bool vt_epi = g_qkv_vt_epilogue && !pk && N % 64 == 0 && (long long)((M + 255) / 256) * ((dkv + 255) / 256) >= 128;
-        if (vt_epi) {
+        // ... and ONE launch for all three when the shapes are whole tiles of the persistent 256 x 288 kernel (lt_set_option
+        // "qkv_fused_gemm"): Q | K tiles with the plain epilogue, V tiles with swapped MFMA operands and the V^T epilogue
+        GemmArgs gq;
+        gq.A = e->h; gq.W = w.wqkv; gq.C = e->qkv; gq.bias = nullptr; gq.bias_dtype = -1; gq.M = M; gq.N = d + 2 * dkv; gq.K = d;
+        gq.lda = d; gq.ldw = d; gq.ldc = e->qkvn; gq.VT = e->vt; gq.vt_split = d + dkv; gq.vt_tokens = N; gq.vt_hd = hd; gq.vt_npad = Npad;
+        if (vt_epi && g_qkv_fused_gemm && gemm_qkv_fusable(gq)) {
+            ProfScope ps(e, 0, 2.0 * M * (double)(d + 2 * dkv) * d, s, true);
+            if (launch_gemm_bf16(gq, 3, 0, s, ps.ev0(), ps.ev1())) return 1;
+        } else if (vt_epi) {
             if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, d + dkv, d, nullptr, 0, s)) return 1;
             GemmArgs g;
             g.A = e->h; g.W = w.wqkv + (size_t)(d + dkv) * d; g.C = e->vt; g.bias = nullptr; g.bias_dtype = -1;
@@ -1248,6 +1257,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 5, "attention_variant must be 1 .. 5"); lt_set_attention_variant(value); return 0; }
     if (strcmp(name, "qkv_post_fused") == 0) { g_qkv_post_fused = value != 0; return 0; }
     if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
+    if (strcmp(name, "qkv_fused_gemm") == 0) { g_qkv_fused_gemm = value != 0; return 0; }
     if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_swiglu_w4p") == 0) { lt_set_gemm_swiglu_w4p(value != 0); return 0; }
@@ -1281,6 +1291,15 @@ extern "C" int lt_op_gemm_vt(const void* A, const void* W, void* vt, int32_t M, 
     g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)vt; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
     g.lda = K; g.ldw = K; g.ldc = 0; g.bias_dtype = -1; g.vt_tokens = tokens; g.vt_hd = hd; g.vt_npad = tokens;
     return launch_gemm_bf16(g, 2, variant, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_gemm_qkv(const void* A, const void* W, void* C, void* vt, int32_t M, int32_t N, int32_t K, int32_t split,
+                              int32_t tokens, int32_t hd, void* stream) {
+    LT_REQUIRE(A && W && C && vt, "lt_op_gemm_qkv: null pointer");
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.bias_dtype = -1; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = N; g.VT = (u16*)vt; g.vt_split = split; g.vt_tokens = tokens; g.vt_hd = hd; g.vt_npad = tokens;
+    return launch_gemm_bf16(g, 3, 0, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap) {

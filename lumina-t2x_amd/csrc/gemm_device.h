@@ -1068,9 +1068,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     constexpr int IP = (NP + NW - 1) / NW;                    // pieces per wave and slab (a surplus slot re-loads the wave's last piece)
     constexpr int SLAB = (BM + BN) * 64, W_OFF = BM * 64;
     constexpr int NM = MT * NT, RD = MT + NT, EVERY = NM / IP;
-    constexpr int NST = EPI == 0 ? MT * (NT / 2) + (NT % 2 ? MT : 0) : MT * (NT / 4);  // store instructions per wave and tile
+    constexpr int NST = EPI != 1 ? MT * (NT / 2) + (NT % 2 ? MT : 0) : MT * (NT / 4);  // store instructions per wave and tile
+    constexpr int NST_V = (MT / 2) * NT;  // ... of a V^T tile (EPI 3)
     static_assert(NM % IP == 0 && RD <= NM, "one LDS-DMA per EVERY MFMAs, one fragment read per MFMA in the first RD");
-    static_assert(EPI == 0 || NT % 4 == 0, "SwiGLU pairs 32-column groups");
+    static_assert(EPI != 1 || NT % 4 == 0, "SwiGLU pairs 32-column groups");
     static_assert(PA % NW == 0, "A pieces first: slot i < PA / NW is an A piece for every wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1098,8 +1099,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + sswz;
         ldsoff[i] = q * 1024;
     }
-    const int ncols_out = EPI == 0 ? p.N : p.N / 2;
-    struct Tile { const u16* a; const u16* w; u16* c; int a_bytes, w_bytes, c_bytes, n0; };
+    const int ncols_out = EPI == 1 ? p.N / 2 : p.N;
+    struct Tile { const u16* a; const u16* w; u16* c; int a_bytes, w_bytes, c_bytes, n0, m0; };
     auto setup = [&](int v) __attribute__((always_inline)) {
         int tm, tn;
         tile_coords(v, ntiles, TM, TN, tm, tn, p.group_rows > 0 ? p.group_rows : 4);
@@ -1113,9 +1114,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         t.w_bytes = (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left);
         t.c_bytes = (int)(c_left > 0x7fffffffLL ? 0x7fffffffLL : c_left);
         t.n0 = n0_;
+        t.m0 = m0;
         return t;
     };
-    const Tile t_null = {p.A, p.W, p.C, 0, 0, 0, 0};  // no next tile: the last bodies' DMAs read nothing (all lanes out of range)
+    const Tile t_null = {p.A, p.W, p.C, 0, 0, 0, 0, 0};  // no next tile: the last bodies' DMAs read nothing (all lanes out of range)
 
     // fragment reads: lane -> row l15 of the 16-row tile, chunk q4 (swizzled)
     const int csw = (q4 ^ (((l15 >> 3) & 1) * 3)) << 4;
@@ -1156,7 +1158,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     wait_vmcnt<IP>();
     pp_barrier();
 
-    bool after_epilogue = false;
+    int after_epilogue = 0;  // stores of the previous tile's epilogue still in the queue: 0 none, 1 NST, 2 NST_V (EPI 3: a V^T tile)
     if constexpr (TRACE) { tr_pro = __builtin_amdgcn_s_memrealtime(); tr_clk = __builtin_amdgcn_s_memtime(); }
     // scalar state of the two streams, carried from body to body.  Each body computes the NEXT body's values inside its own MFMA
     // stream (the fences below pin them there): between the barrier and the first MFMA of a slab there is nothing but one address
@@ -1172,8 +1174,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     // FIRST (a tile's slab 0): C = 0 forms, no accumulator clears.  Accumulator tiles 0..63 live in AGPRs, the rest (NT = 9: 8 tiles)
     // in arch VGPRs; inline assembly gives each ONE home (the builtin bounced tiles through spare AGPRs: 272 us instead of 216 us on
     // the QKV GEMM) and, with a scheduling fence per MFMA, pins the written interleave.
-    auto body = [&](auto first_tag, bf16x8 (&wc)[NT], bf16x8 (&ac)[MT], bf16x8 (&wn_)[NT], bf16x8 (&an)[MT]) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_tag)::value;
+    // SWAP (EPI 3, the V columns of a fused QKV projection): D = A_frag x W_frag instead of W_frag x A_frag - the same products,
+    // but a lane then holds 4 consecutive ROWS (tokens) of one column, which is what the transposed V image wants.
+    auto body = [&](auto first_tag, auto swap_tag, bf16x8 (&wc)[NT], bf16x8 (&ac)[MT], bf16x8 (&wn_)[NT], bf16x8 (&an)[MT]) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value, SWAP = decltype(swap_tag)::value;
         const char* sb = smem + rd_off;
         char* db = smem + wr_off;
         int n_rd = rd_off, n_wr = wr_off, n_soff = d_soff;
@@ -1182,12 +1186,18 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             const int mt = i / NT, nt = i % NT;
-            if constexpr (FIRST) {
+            if constexpr (FIRST && !SWAP) {
                 if (i < 64) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
                 else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
-            } else {
+            } else if constexpr (!FIRST && !SWAP) {
                 if (i < 64) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
                 else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
+            } else if constexpr (FIRST) {
+                if (i < 64) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[mt][nt]) : "v"(ac[mt]), "v"(wc[nt]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[mt][nt]) : "v"(ac[mt]), "v"(wc[nt]));
+            } else {
+                if (i < 64) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(ac[mt]), "v"(wc[nt]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(ac[mt]), "v"(wc[nt]));
             }
             if (i < NT) wn_[i] = *(const bf16x8*)(sb + w_row_off + i * 1024);
             else if (i < RD) an[i - NT] = *(const bf16x8*)(sb + a_row_off + (i - NT) * 1024);
@@ -1211,9 +1221,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         // slab g+2 landed; still allowed in flight: this body's IP DMAs and, right after a tile boundary, the NST stores issued
         // between slab g+2's DMAs and them (loads and stores retire in issue order, one counter)
         if constexpr (FIRST) {
-            if (after_epilogue) wait_vmcnt<IP + NST>();
+            if (after_epilogue == 1) wait_vmcnt<IP + NST>();
+            else if (EPI == 3 && after_epilogue == 2) wait_vmcnt<IP + NST_V>();
             else wait_vmcnt<IP>();
-            after_epilogue = false;
+            after_epilogue = 0;
         } else {
             wait_vmcnt<IP>();
         }
@@ -1228,7 +1239,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int row_off = (wm * (MT * 16) + mt * 16 + l15) * p.ldc * 2;  // bytes from the tile's first C row (< 2^31: launcher)
-            if constexpr (EPI == 0) {
+            if constexpr (EPI != 1) {
 #pragma unroll
                 for (int np = 0; np < NT / 2; ++np) {
                     const f32x4 a = acc[mt][2 * np], b = acc[mt][2 * np + 1];
@@ -1273,6 +1284,34 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             }
         }
     };
+    // EPI 3, a V tile (column block at or past p.vt_split): the transposed, key-permuted V image vt[b][kv head][d][token'] of the
+    // attention kernels (AttnArgs::vt; positions inside every group of 16 tokens: 0-3, 8-11, 4-7, 12-15).  After the swapped MFMAs a
+    // lane holds, per 16x16 accumulator tile, column l15 and rows 4 q4 + r = one quad of the group.  v_permlane32_swap of two row
+    // tiles' packed registers puts quads (0, 2) resp. (1, 3) of ONE tile side by side: 8 consecutive positions = one 16-byte store.
+    // A 256-row tile lies inside one sample (tokens per sample % 256 == 0, launcher).
+    auto store_vt = [&](const Tile& t) __attribute__((always_inline)) {
+        const int hd = p.vt_hd, kvh = (p.N - p.vt_split) / hd;
+        const int b = t.m0 / p.vt_tokens, tok0 = t.m0 - b * p.vt_tokens + wm * (MT * 16);
+        const long long vt_all = (long long)(p.M / p.vt_tokens) * kvh * hd * p.vt_npad * 2;
+        const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)p.VT, 0, (int)(vt_all > 0x7fffffffLL ? 0x7fffffffLL : vt_all), 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = t.n0 - p.vt_split + wn * (NT * 16) + nt * 16 + l15;
+            const int head = c / hd, d = c - head * hd;
+            const int row_off = (((b * kvh + head) * hd + d) * p.vt_npad + tok0 + (q4 >> 1) * 16 + (q4 & 1) * 8) * 2;  // bytes (< 2^31: launcher)
+#pragma unroll
+            for (int mp = 0; mp < MT / 2; ++mp) {
+                const f32x4 a = acc[2 * mp][nt], bb = acc[2 * mp + 1][nt];
+                const unsigned a0 = pack2bf_pk(a[0], a[1]), a1 = pack2bf_pk(a[2], a[3]);
+                const unsigned b0 = pack2bf_pk(bb[0], bb[1]), b1 = pack2bf_pk(bb[2], bb[3]);
+                auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                // lane rows 0 / 1: row tile 2 mp, positions 0-7 / 8-15; lane rows 2 / 3: row tile 2 mp + 1
+                const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(o, rV, row_off + mp * 64, 0, 0);
+            }
+        }
+    };
     auto advance = [&]() __attribute__((always_inline)) {
         if (has_next) {
             cur = nxt;
@@ -1281,17 +1320,28 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             nxt = has_next ? setup(v + gridDim.x) : t_null;
         }
     };
-    for (int t = 0; t < my_tiles; ++t) {
-        body(std::true_type{}, wf, af, wf2, af2);  // slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
-        body(std::false_type{}, wf2, af2, wf, af);
+    // one tile: slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
+    auto run_tile = [&](auto swap_tag) __attribute__((always_inline)) {
+        body(std::true_type{}, swap_tag, wf, af, wf2, af2);
+        body(std::false_type{}, swap_tag, wf2, af2, wf, af);
         for (int s = 2; s < ns; s += 2) {
-            body(std::false_type{}, wf, af, wf2, af2);
-            body(std::false_type{}, wf2, af2, wf, af);
+            body(std::false_type{}, swap_tag, wf, af, wf2, af2);
+            body(std::false_type{}, swap_tag, wf2, af2, wf, af);
         }
-        if constexpr (TRACE) { tr_loop = __builtin_amdgcn_s_memrealtime(); if (t == 0) tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
-        store_out(cur);
+    };
+    for (int t = 0; t < my_tiles; ++t) {
+        if (EPI == 3 && cur.n0 >= p.vt_split) {
+            run_tile(std::true_type{});
+            if constexpr (TRACE) { tr_loop = __builtin_amdgcn_s_memrealtime(); if (t == 0) tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
+            if constexpr (EPI == 3) store_vt(cur);
+            after_epilogue = 2;
+        } else {
+            run_tile(std::false_type{});
+            if constexpr (TRACE) { tr_loop = __builtin_amdgcn_s_memrealtime(); if (t == 0) tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
+            store_out(cur);
+            after_epilogue = 1;
+        }
         if constexpr (TRACE) tr_epi = __builtin_amdgcn_s_memrealtime();
-        after_epilogue = true;
         advance();
     }
     wait_vmcnt<0>();  // no LDS-DMA (the null ones of the last bodies included) may outlive the workgroup's LDS allocation

@@ -20,12 +20,18 @@ struct GemmArgs {
     // epilogue 2 (V^T): C is the attention kernels' transposed, key-permuted V image [M / vt_tokens][N / vt_hd][vt_hd][vt_npad]
     // (AttnArgs::vt) instead of a row-major matrix: the V projection lands in the layout the PV MFMA reads, no transpose pass
     int vt_tokens = 0, vt_hd = 0, vt_npad = 0;
+    // epilogue 3 (fused QKV projection, persistent 16x16x32 kernel): columns < vt_split go to C as a plain GEMM, columns >= vt_split are
+    // the V projection and land in VT as the transposed image (same layout as epilogue 2).  vt_split and N - vt_split are multiples of
+    // the 288-column tile, vt_tokens of the 256-row tile.
+    u16* VT = nullptr;
+    int vt_split = 0;
     int group_rows = 0;  // experiment knob (lt_set_option "gemm_group"): tile rows per group of the XCD-aware tile order (0 = 4)
     int stagger = 0;  // experiment knob of the 4-wave kernels (lt_set_option "gemm_stagger"), filled by the launcher
 };
 // ev0 / ev1: optional start / stop events carried by the dispatch packet itself (profiling without extra queue packets)
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0 = nullptr,
                      hipEvent_t ev1 = nullptr);
+bool gemm_qkv_fusable(const GemmArgs& a);  // epilogue 3 can take this problem (else: one plain launch for Q | K + one V^T launch)
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream);
 
 // ---- norm / residual kernels (norm.hip) --------------------------------------------------------

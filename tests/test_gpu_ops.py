@@ -224,6 +224,28 @@ def test_gemm_vt_epilogue_matches_gemm_plus_transpose(tokens, B, kvh, hd, K, var
     assert torch.all(buf[:guard] == 7.0) and torch.all(buf[-guard:] == 7.0), "stray store outside the V^T image"
 
 
+@pytest.mark.parametrize("tokens,B,H,Hkv,hd,K", [(4096, 2, 32, 32, 72, 2304), (4096, 2, 32, 8, 72, 2304), (1024, 8, 16, 16, 72, 1152), (16384, 1, 32, 8, 72, 256)])
+def test_gemm_fused_qkv_matches_separate_launches(tokens, B, H, Hkv, hd, K):
+    """one launch of the persistent 256 x 288 kernel for the whole QKV projection (lt_op_gemm_qkv: plain tiles for the Q | K columns,
+    swapped-operand V^T tiles for the V columns) against the same kernel run as a plain GEMM + lt_op_v_transpose: identical MFMA
+    sequences per output element -> bit-identical; MHA and GQA splits, several tiles per CU, short K"""
+    d, dkv = H * hd, Hkv * hd
+    M, N, split = B * tokens, H * hd + 2 * Hkv * hd, H * hd + Hkv * hd
+    g = torch.Generator().manual_seed(tokens + Hkv)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    plain = _gemm(A, W, variant=16)
+    vt_ref = torch.empty(B, Hkv, hd, tokens, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_v_transpose(P(plain), N, split, P(vt_ref), B, tokens, tokens, Hkv, hd, stream()))
+    C = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    vt = torch.full((B, Hkv, hd, tokens), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_gemm_qkv(P(A), P(W), P(C), P(vt), M, N, K, split, tokens, hd, stream()), "gemm_qkv")
+    torch.cuda.synchronize()
+    assert torch.equal(C[:, :split], plain[:, :split])
+    assert torch.isnan(C[:, split:].float()).all()   # the V columns of C are not written
+    assert torch.equal(vt, vt_ref), rel_l2(vt, vt_ref)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 3, 7])
 @pytest.mark.parametrize("epilogue", [0, 1])
 def test_gemm_grouped_expert_segments(variant, epilogue):
