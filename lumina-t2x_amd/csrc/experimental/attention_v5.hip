@@ -188,10 +188,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v5(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < n; ++e) cvt1(blk, g, j + e);
     };
-    auto exp2_cvt2 = [&](int blk, int ge, int i, int gc, int j, bool cvt_first) __attribute__((always_inline)) {
-        if (cvt_first) { cvts(blk, gc, j, 2); exps(blk, ge, i, 2); }
-        else { exps(blk, ge, i, 2); cvts(blk, gc, j, 2); }
-    };
     // P of a 32-key half kh: entries 2 kh (keys 0-3, 8-11 | 4-7, 12-15 of the half, by lane half) and 2 kh + 1 (keys 16.. likewise) ->
     // the fragments of the two 16-row query halves: v_permlane16_swap exchanges lane rows 1 <-> 0 and 3 <-> 2 of the two registers
     // (two wait states between a VALU write and the permlane's read of it: the schedule puts other steps in between)
