@@ -175,16 +175,20 @@ def cpu_baseline(latent, n_tokens, n_sample_layers=2):
     return out
 
 
-def gemm_kernel_label(lib, M, d, F, dkv):
-    """names of the kernels the engine's dispatcher runs for this workload's GEMM shapes (lt_op_gemm_describe)"""
+def gemm_kernel_label(lib, M, d, F, dkv, tokens, hd):
+    """names of the kernels the engine's dispatcher runs for this workload's GEMM shapes (lt_op_gemm_describe), and the number of
+    GEMM launches per layer (4 when the QKV projection is one launch, else 5)"""
     import ctypes as C
-    shapes = [("QK", M, d + dkv, d, 0), ("V", M, dkv, d, 2), ("O", M, d, d, 0), ("W1|W3+SwiGLU", M, 2 * F, d, 1), ("W2", M, d, F, 0)]
-    parts = []
+    fused = bool(lib.lt_op_gemm_qkv_fusable(M, d + 2 * dkv, d, d + dkv, tokens, hd))
+    shapes = [("O", M, d, d, 0), ("W1|W3+SwiGLU", M, 2 * F, d, 1), ("W2", M, d, F, 0)]
+    if not fused:
+        shapes = [("QK", M, d + dkv, d, 0), ("V", M, dkv, d, 2)] + shapes
+    parts = ["QKV: gemm_bf16_w4q<3,9> (persistent 4 waves, 16x16x32 MFMA, 256x288, fused QKV: plain Q|K tiles + V^T tiles)"] if fused else []
     for nm, m, n, k, epi in shapes:
         buf = C.create_string_buffer(160)
         lib.lt_op_gemm_describe(m, n, k, epi, 0, buf, 160)
         parts.append(f"{nm}: {buf.value.decode()}")
-    return "; ".join(parts)
+    return "; ".join(parts), (4 if fused else 5)
 
 
 def main():
@@ -271,7 +275,9 @@ def main():
     eng.profile_enable(args.profile_classes)
     # HIP start/stop events on the GEMM dispatches of the first --event-steps NFE of the timed region (every NFE has the
     # same launch mix; timing all of them costs ~2.5 ms per NFE of queue idle time, which would be charged to `value`)
-    gemm_launches_per_nfe = 5 * model.n_layers + 2
+    hd0 = model.dim // model.n_heads
+    gemm_label, gemm_per_layer = gemm_kernel_label(_lib.load(), 2 * n_tokens, model.dim, model.ffn_hidden, model.n_kv_heads * hd0, n_tokens, hd0)
+    gemm_launches_per_nfe = gemm_per_layer * model.n_layers + 2
     event_launches = -1 if args.event_steps <= 0 else max(1, int(round(args.event_steps * gemm_launches_per_nfe)))
     # ... taken from the middle of the region (the first launches after the barrier meet an idle chip in another power state)
     skip = gemm_launches_per_nfe * (args.steps // 2) if event_launches > 0 else 0
@@ -325,8 +331,7 @@ def main():
             "mfma_roofline_frac_whole_step": nfe_flops * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "roofline": {
                 "bound": "mfma",
-                "kernel": "all bf16 GEMM launches of the timed region - " + gemm_kernel_label(
-                    _lib.load(), 2 * n_tokens, model.dim, model.ffn_hidden, model.n_kv_heads * hd),
+                "kernel": "all bf16 GEMM launches of the timed region - " + gemm_label,
                 "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
                 "traffic_source": traffic_src,

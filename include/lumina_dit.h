@@ -204,6 +204,8 @@ int lt_op_gemm_vt(const void* A_dev, const void* W_dev, void* vt_dev, int32_t M,
  * 256 x 288 kernel: split and N - split multiples of 288, tokens % 256 == 0, M % tokens == 0, K % 64 == 0, M / 256 * N / 288 >= #CUs. */
 int lt_op_gemm_qkv(const void* A_dev, const void* W_dev, void* C_dev, void* vt_dev, int32_t M, int32_t N, int32_t K, int32_t split,
                    int32_t tokens, int32_t hd, void* stream);
+/* 1 if the engine runs this QKV projection as ONE launch (lt_op_gemm_qkv's conditions and the options allow it), else 0 */
+int lt_op_gemm_qkv_fusable(int32_t M, int32_t N, int32_t K, int32_t split, int32_t tokens, int32_t hd);
 /* name of the kernel lt_op_gemm_bf16(..., variant) would launch for a dense problem (bench.py labels its roofline line with it) */
 int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap);
 /* grouped (mixture-of-experts) form of lt_op_gemm_bf16 - replaces the per-expert Python loop `for i, expert in

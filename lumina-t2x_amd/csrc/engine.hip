@@ -1302,6 +1302,13 @@ extern "C" int lt_op_gemm_qkv(const void* A, const void* W, void* C, void* vt, i
     return launch_gemm_bf16(g, 3, 0, (hipStream_t)stream);
 }
 
+extern "C" int lt_op_gemm_qkv_fusable(int32_t M, int32_t N, int32_t K, int32_t split, int32_t tokens, int32_t hd) {
+    GemmArgs g;
+    g.A = nullptr; g.W = nullptr; g.C = nullptr; g.bias = nullptr; g.bias_dtype = -1; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = N; g.VT = (u16*)1; g.vt_split = split; g.vt_tokens = tokens; g.vt_hd = hd; g.vt_npad = tokens;
+    return g_qkv_fused_gemm && g_qkv_vt_epilogue && gemm_qkv_fusable(g) ? 1 : 0;
+}
+
 extern "C" int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap) {
     LT_REQUIRE(out && cap > 0, "lt_op_gemm_describe: null buffer");
     GemmArgs g;
