@@ -476,3 +476,23 @@ def test_bench_self_launch_command_and_flop_count():
         assert mine == O.flops_per_nfe(cfg, n, t, 2)
         assert ffn_hidden(cfg.dim) == cfg.ffn_hidden
     assert 32.5e12 < flops_per_nfe(dim=2304, n_layers=24, n_heads=32, cap_feat_dim=2048, n_tokens=4096, text_len=128) < 34.0e12
+
+
+def test_generated_attention_accessors_are_in_sync_with_their_generator(tmp_path, monkeypatch):
+    """lumina-t2x_amd/csrc/attention_v4_asm.inc (and the experimental variant's) are generated files that are committed: the
+    generator must reproduce them byte for byte"""
+    import importlib.util
+    import shutil
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for gen, rel in (("gen_attn_v4_asm.py", ("lumina-t2x_amd", "csrc", "attention_v4_asm.inc")),
+                     ("gen_attn_v5_asm.py", ("lumina-t2x_amd", "csrc", "experimental", "attention_v5_asm.inc"))):
+        committed = open(os.path.join(REPO, *rel)).read()
+        # run the generator against a scratch copy of the tree layout (it writes next to its own location)
+        root = tmp_path / gen.replace(".py", "")
+        (root / "scripts").mkdir(parents=True)
+        (root.joinpath(*rel[:-1])).mkdir(parents=True)
+        shutil.copy(os.path.join(REPO, "scripts", gen), root / "scripts" / gen)
+        spec = importlib.util.spec_from_file_location("gen_mod_" + gen[:-3], str(root / "scripts" / gen))
+        spec.loader.exec_module(importlib.util.module_from_spec(spec))
+        assert open(root.joinpath(*rel)).read() == committed, f"{'/'.join(rel)} is stale: run python scripts/{gen}"
+
