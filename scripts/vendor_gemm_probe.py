@@ -24,7 +24,9 @@ for name, M, N, K in shapes:
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     for _ in range(6):
         torch.nn.functional.linear(A, W)
-    for variant in (1, 3, 10, 12):  # classic 256x256, ping-pong 256x256, 4-wave LDS-DMA, 4-wave VGPR-staged
+    # classic 256x256 (8 waves), ping-pong 256x256 (8 waves), persistent 4 waves x (128 x 128) on 32x32x16 MFMAs, persistent 4 waves on
+    # 16x16x32 MFMAs (the engine's kernel) - all in the product library (round 1 probed the experimental variants 10 / 12 here)
+    for variant in (1, 3, 14, 15):
         for _ in range(6):
             ok(L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(out), M, N, K, 0, variant, stream()))
     torch.cuda.synchronize()
