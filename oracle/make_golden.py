@@ -312,9 +312,67 @@ def mini_ode_kats():
     print("mini_ode.npz:", {k: v.shape for k, v in d.items() if v.ndim > 0})
 
 
+def solver_kats():
+    """The reference's own in-tree ODE step, ``midpoint_solver`` (visual_anagrams/generate.py:212-219), driven exactly as its
+    caller does (generate.py:385-414: ``timesteps.tolist()`` floats, ``noisy_img = noisy_img - (-midpoint_solver(...))``) over
+    seeded grids with a closed-form drift and the unmodified tiny NextDiT's ``forward_with_cfg`` as drift.  Every call the
+    solver makes to ``func`` is logged: the second call's state argument is ``y0 + f0 * dt/2`` = one explicit Euler step of
+    size dt/2 written by the reference itself.  tests/test_oracle_golden.py holds oracle/odeint_oracle.py (euler, midpoint) to
+    these; tests/test_gpu_model.py holds lt_sample_ode to odeint_oracle bit for bit and to the tiny-model trajectory here."""
+    midpoint_solver = R.load_anagrams_solvers()
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
+        del sys.modules[m]
+    sys.path = [q for q in sys.path if not q.startswith(R.REFERENCE_ROOT)]
+    _, T = R.load_reference("lumina_next_t2i")
+    integ = importlib.import_module("transport.integrators")
+    cfg = synth.TINY
+    model = R.build_reference_model(cfg, synth.synth_state_dict(cfg, seed=31))
+    z, _, cap, mask = synth.synth_inputs(cfg, latent_hw=(16, 16), text_len=16, uncond_len=8, seed=32)
+    model_kw = dict(cap_feats=cap, cap_mask=mask, cfg_scale=4.0, proportional_attn=True, base_seqlen=16, scale_factor=1.0,
+                    scale_watershed=1.0)
+
+    def closed(y, t):  # smooth, time dependent, state dependent (nonlinear)
+        return -y * (0.5 + t.view(-1, 1, 1, 1)) + 0.1 * torch.cos(3.0 * y)
+
+    from functools import partial
+    drifts = {"closed": closed, "tiny": partial(model.forward_with_cfg, **model_kw)}  # generate.py:400: partial(model.forward_with_cfg, **model_kwargs)
+    grids = {"uniform5": integ.ode(drift=None, t0=0, t1=1, sampler_type="midpoint", num_steps=5, atol=1e-6, rtol=1e-3).t,
+             "shift4_6": integ.ode(drift=None, t0=0, t1=1, sampler_type="midpoint", num_steps=6, atol=1e-6, rtol=1e-3,
+                                   time_shifting_factor=4).t}
+    y0 = {"closed": torch.linspace(-1.0, 1.0, 2 * 3 * 4 * 4).view(2, 3, 4, 4).clone(), "tiny": z}
+    d = {"config": np.array(json.dumps(cfg.to_dict())), "seed_w": 31, "seed_x": 32, "cap": _np(cap), "mask": _np(mask),
+         "model_kw": np.array(json.dumps({k: v for k, v in model_kw.items() if not torch.is_tensor(v)}))}
+    for gname, grid in grids.items():
+        d[f"grid_{gname}"] = _np(grid)
+        timesteps = grid.tolist()  # generate.py:385
+        for dname, func in drifts.items():
+            log_y, log_t = [], []
+
+            def logged(y, t, _f=func):
+                log_y.append(_np(y).copy())
+                log_t.append(_np(t).copy())
+                return _f(y, t)
+
+            y = y0[dname].clone()
+            traj, incs = [_np(y).copy()], []
+            with torch.no_grad():
+                for i in range(len(timesteps) - 1):
+                    noise = -midpoint_solver(logged, timesteps[i], timesteps[i + 1], y)  # generate.py:402-404
+                    incs.append(_np(-noise).copy())
+                    y = y - noise                                                         # generate.py:414
+                    traj.append(_np(y).copy())
+            tag = f"{gname}_{dname}"
+            d[f"traj_{tag}"], d[f"inc_{tag}"] = np.stack(traj), np.stack(incs)
+            d[f"calls_y_{tag}"], d[f"calls_t_{tag}"] = np.stack(log_y), np.stack(log_t)
+    np.savez_compressed(os.path.join(OUT, "solver_kat.npz"), **d)
+    print("solver_kat.npz:", {k: v.shape for k, v in d.items() if hasattr(v, "shape") and v.ndim > 1})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
+    if sys.argv[1:] == ["solver"]:  # python -m oracle.make_golden solver: only tests/golden/solver_kat.npz
+        return solver_kats()
     models_mod, transport_mod = R.load_reference()
     kats(models_mod, transport_mod)
     model_case("nextdit_tiny", synth.TINY, "lumina_next_t2i", (16, 16), 16, 8, 0, 1)
@@ -330,6 +388,7 @@ def main():
     packed_case("nextdit_tiny_packed", synth.TINY, [(16, 16), (12, 20), (8, 24), (16, 16)], 16, 13, 14)
     compositional_case("compositional_tiny", synth.TINY, (16, 24), (2, 2), 16, 15, 16)
     compositional_case("compositional_tiny_1x3", synth.TINY, (12, 24), (1, 3), 13, 17, 18)
+    solver_kats()
 
 
 if __name__ == "__main__":

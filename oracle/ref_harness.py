@@ -45,3 +45,32 @@ def build_reference_model(cfg, state_dict):
     missing = model.load_state_dict(state_dict, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return model
+
+
+
+def load_anagrams_solvers():
+    """The reference's only in-tree statement of an ODE step: ``midpoint_solver`` (``visual_anagrams/generate.py:212-219``), what
+    torchdiffeq's fixed-grid ``midpoint`` does per interval (its first half is the Euler slope).  generate.py is a script - importing
+    it parses ``sys.argv`` and loads checkpoints at module level (generate.py:268-270) - so the function definitions are compiled
+    VERBATIM from the file's syntax tree (no source text is copied or edited) into a namespace that holds ``torch``.
+    ``.to("cuda")`` (generate.py:215,218) is made a no-op on the CPU harness exactly as ``.cuda()`` is for model.py:952."""
+    import ast
+    if not available():
+        raise RuntimeError(f"reference checkout not found under {REFERENCE_ROOT}")
+    path = os.path.join(REFERENCE_ROOT, "visual_anagrams", "generate.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    wanted = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("midpoint_solver",)]
+    assert len(wanted) == 1 and wanted[0].lineno == 212, [(n.name, n.lineno) for n in wanted]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), path, "exec"), ns)
+    if not torch.cuda.is_available() and not getattr(torch.Tensor.to, "_lt_cpu_harness", False):
+        _to = torch.Tensor.to
+
+        def to(self, *a, **k):
+            a = tuple(x for x in a if not (isinstance(x, str) and x.startswith("cuda")))
+            if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+                k.pop("device")
+            return _to(self, *a, **k) if (a or k) else self
+        to._lt_cpu_harness = True
+        torch.Tensor.to = to
+    return ns["midpoint_solver"]

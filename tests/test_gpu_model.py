@@ -191,6 +191,35 @@ def test_engine_trajectory_vs_reference_golden(golden_dir, method):
     assert err < max(5e-2, 1.5 * floor), (err, floor)
 
 
+@pytest.mark.parametrize("grid,num_steps,shift", [("uniform5", 5, None), ("shift4_6", 6, 4)])
+def test_engine_midpoint_trajectory_vs_reference_midpoint_solver(golden_dir, grid, num_steps, shift):
+    """lt_sample_ode `midpoint` against the trajectory the reference's OWN in-tree midpoint step produced with the unmodified tiny
+    NextDiT as drift (visual_anagrams/generate.py:212-219 driven as :385-414; tests/golden/solver_kat.npz).  The CPU suite holds
+    odeint_oracle to the same fixture and test_engine_ode_loop_equals_stepwise_torch holds lt_sample_ode to odeint_oracle bit for
+    bit; this closes the chain end to end (bf16 engine vs fp32 reference: the trajectory gate of SURVEY 8d)."""
+    g, cfg = _golden(golden_dir, "solver_kat")
+    model = _model(cfg, int(g["seed_w"]))
+    kw = json.loads(str(g["model_kw"]))
+    cap = torch.from_numpy(g["cap"]).to("cuda", torch.bfloat16)
+    mask = torch.from_numpy(g["mask"]).cuda()
+    ref = torch.from_numpy(g[f"traj_{grid}_tiny"])
+    z = ref[0].to("cuda", torch.bfloat16)
+    fn = Sampler(create_transport()).sample_ode(sampling_method="midpoint", num_steps=num_steps, time_shifting_factor=shift)
+    traj = fn(z, model.forward_with_cfg, cap_feats=cap, cap_mask=mask, **kw)
+    assert traj.shape == ref.shape and model._engine.last_nfe() == 2 * (num_steps - 1)
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    floor_traj = OD.odeint(lambda t, y: O.forward_with_cfg(sd, cfg, y, torch.ones(2) * t.float(), bf16=True, cap_feats=cap.float().cpu(),
+                                                           cap_mask=mask.cpu(), **kw).to(torch.bfloat16),
+                           ref[0].to(torch.bfloat16), torch.from_numpy(g[f"grid_{grid}"]), method="midpoint")
+    floor = rel_l2(floor_traj[-1], ref[-1])
+    err = rel_l2(traj[-1], ref[-1])
+    assert err < max(5e-2, 1.5 * floor), (err, floor)
+    # fp32 state: the engine's arithmetic on the state is then the reference's (fp32 y, fp32 dt); only the drift is bf16
+    z32 = ref[0].cuda()
+    traj32 = fn(z32, model.forward_with_cfg, cap_feats=cap, cap_mask=mask, **kw)
+    assert traj32.dtype == torch.float32 and rel_l2(traj32[-1], ref[-1]) < max(5e-2, 1.5 * floor)
+
+
 def test_full_width_two_layers_vs_oracle():
     """Next-DiT 2B widths (d 2304, hd 72, F 6144), 1024^2 latent (N = 4096, M = 8192 rows), 2 layers: exercises
     every kernel at the BASELINE cfg-2 shapes against the CPU oracle."""

@@ -264,3 +264,66 @@ def test_fulldepth_weight_draw_is_reproducible(golden_dir):
     wsum = np.array([float(sd[k].double().abs().sum()) for k in keys[:3]])
     np.testing.assert_allclose(wsum, g["wsum"], rtol=1e-12)
     np.testing.assert_array_equal(sd[keys[3]].flatten()[:8].double().numpy(), g["wprobe"])
+
+
+# ---- the ODE stepping, pinned to the reference's only in-tree statement of it (visual_anagrams/generate.py:212-219) ----------------
+def _solver_drifts(g):
+    cfg = _cfg(g)
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    kw = json.loads(str(g["model_kw"]))
+    cap, mask = torch.from_numpy(g["cap"]), torch.from_numpy(g["mask"])
+
+    def closed(y, t):
+        return -y * (0.5 + t.view(-1, 1, 1, 1)) + 0.1 * torch.cos(3.0 * y)
+
+    def tiny(y, t):
+        return O.forward_with_cfg(sd, cfg, y, t, cap_feats=cap, cap_mask=mask, **kw)
+
+    return {"closed": closed, "tiny": tiny}
+
+
+def _as_odeint_func(func, batch):
+    # torchdiffeq hands the user function a 0-dim t; integrators.py:108 expands it to [B] the same way
+    return lambda t, y: func(y, torch.ones(batch) * t)
+
+
+@pytest.mark.parametrize("drift", ["closed", "tiny"])
+@pytest.mark.parametrize("grid", ["uniform5", "shift4_6"])
+def test_midpoint_restatement_equals_reference_midpoint_solver(golden_dir, grid, drift):
+    """oracle/odeint_oracle.py `midpoint` (restated from torchdiffeq, which is absent everywhere) against trajectories produced by
+    the reference's own `midpoint_solver` driven as generate.py:385-414 drives it.  On the dyadic grid every time value is exact
+    in both formulations -> bit-equal for the closed-form drift; the shifted grid differs by how t0 + dt/2 is rounded (Python
+    doubles in generate.py, fp32 tensors in torchdiffeq): <= 1 ulp of t, so the tolerance is 2e-6 absolute (fp32 data of O(1))."""
+    g = _load(golden_dir, "solver_kat")
+    func = _solver_drifts(g)[drift]
+    ref = g[f"traj_{grid}_{drift}"]
+    t = torch.from_numpy(g[f"grid_{grid}"])
+    y0 = torch.from_numpy(ref[0])
+    mine = OD.odeint(_as_odeint_func(func, y0.size(0)), y0, t, method="midpoint").numpy()
+    if grid == "uniform5" and drift == "closed":
+        np.testing.assert_array_equal(mine, ref)
+    else:  # the oracle model's fp32 summation order differs from the reference module's by ~1e-6 (test_oracle_matches_reference_model)
+        np.testing.assert_allclose(mine, ref, rtol=0, atol=2e-6 if drift == "closed" else 5e-5)
+    # the product's host mirror of the same stepping (used by dopri5 / SDE-free host loops and as the bit-exact model of lt_sample_ode)
+    from lumina_t2x_amd.transport.integrators import fixed_grid_odeint
+    prod = fixed_grid_odeint(_as_odeint_func(func, y0.size(0)), y0, t, method="midpoint").numpy()
+    np.testing.assert_array_equal(prod, mine)
+
+
+@pytest.mark.parametrize("drift", ["closed", "tiny"])
+@pytest.mark.parametrize("grid", ["uniform5", "shift4_6"])
+def test_euler_restatement_equals_first_half_of_reference_midpoint_solver(golden_dir, grid, drift):
+    """`midpoint_solver`'s first half IS an explicit Euler step of size dt/2 (generate.py:216-217: y_mid = y0 + f0 * half_dt); the
+    state it hands to its second `func` call was logged.  odeint_oracle `euler` over [t0, t0 + dt/2] from the same y0 must land
+    on it."""
+    g = _load(golden_dir, "solver_kat")
+    func = _solver_drifts(g)[drift]
+    calls_y, calls_t = g[f"calls_y_{grid}_{drift}"], g[f"calls_t_{grid}_{drift}"]
+    for j in range(0, len(calls_y), 2):
+        y0, y_mid = torch.from_numpy(calls_y[j]), calls_y[j + 1]
+        tt = torch.tensor([calls_t[j][0], calls_t[j + 1][0]])
+        mine = OD.odeint(_as_odeint_func(func, y0.size(0)), y0, tt, method="euler")[-1].numpy()
+        if drift == "closed":
+            np.testing.assert_allclose(mine, y_mid, rtol=0, atol=1.2e-7)  # dt/2 = fl32(t_mid) - t0 vs 0.5 * (t1 - t0): <= 1 ulp
+        else:
+            np.testing.assert_allclose(mine, y_mid, rtol=0, atol=5e-5)
