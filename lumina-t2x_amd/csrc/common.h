@@ -83,6 +83,8 @@ __device__ __forceinline__ f32x2 bfr2(f32x2 v) { return unpk_bf(pk_bf(v)); }  //
 
 // host-side error plumbing shared by the launchers
 void lt_set_error(const char* fmt, ...);
+// compute units of the CURRENT device (cached per device id; defined in gemm_bf16.hip)
+int num_cus();
 #define LT_CHECK_HIP(expr)                                                              \
     do {                                                                                \
         hipError_t _e = (expr);                                                         \

@@ -720,8 +720,15 @@ int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* ou
         ge->key = key;
     }
     if (ge->failed || ge->uses++ == 0) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+    // a caller that is capturing ITS stream (torch.cuda.graph around the sampler) cannot launch a graph or start a second capture
+    // from inside: hand it plain launches, which its own capture records
+    hipStreamCaptureStatus caller_cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &caller_cap) != hipSuccess) { (void)hipGetLastError(); caller_cap = hipStreamCaptureStatusNone; }
+    if (caller_cap != hipStreamCaptureStatusNone) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+    // the RoPE table is ONE shared buffer outside every graph (it is rebuilt only when scale / ntk change): a replay of key A after
+    // key B changed the table must rebuild it first - before every replay, not only before the capture
+    if (ensure_rope(e, a, s)) return 1;
     if (!ge->exec) {
-        if (ensure_rope(e, a, s)) return 1;  // the table build must not be part of the graph (it runs only when its arguments change)
         if (!e->cap_stream) LT_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
         hipGraph_t graph = nullptr;
         bool ok = hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -1030,6 +1037,10 @@ extern "C" int lt_prepare_prompt_regional(lt_engine* e, const void* cap_feats_de
     if (prepare_caption_kv(e, Y, T, Tpad, s)) return 1;
     const size_t need = (size_t)Y * c.max_tokens * e->d;
     if (e->reg_txt_elems < need) {
+        // captured graphs bake this pointer into their kernels: none may outlive the buffer
+        LT_CHECK_HIP(hipStreamSynchronize(s));
+        for (auto& ge : e->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+        e->graphs.clear();
         if (e->reg_txt) LT_CHECK_HIP(hipFree(e->reg_txt));
         LT_CHECK_HIP(hipMalloc((void**)&e->reg_txt, need * 2));
         e->reg_txt_elems = need;

@@ -45,9 +45,19 @@ template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1, false, 0, 1, 4>(GemmArgs); 
 template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0, false, 0, 1, 4>(GemmArgs);  //  64 x 128
 }  // namespace lt_gemm
 
-namespace {
-int num_cus();
-}  // namespace
+int num_cus() {
+    static int per_dev[64] = {0};  // one entry per device id: a process may drive several devices
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    if (per_dev[dev] == 0) {
+        hipDeviceProp_t prop;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        per_dev[dev] = n > 0 ? n : 256;
+    }
+    return per_dev[dev];
+}
+
 
 // the fused QKV projection (epilogue 3) runs on the 256 x 288 persistent kernel only: whole tiles on both sides of the split, a
 // 256-row tile inside one sample, at least one tile per CU, offsets that fit the buffer instructions' 32-bit arithmetic
@@ -109,16 +119,6 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     return 0;
 }
 
-int num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
 
 template <int EPI, bool OVL>
 int launch_w4p(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {

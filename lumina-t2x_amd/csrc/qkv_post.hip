@@ -347,27 +347,23 @@ __global__ __launch_bounds__(64 * QK_WAVES) void qkv_post_kernel(QkvPostArgs p) 
 
 }  // namespace
 
-int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
+// argument checks shared by the single and the pair launcher
+static int validate_qk_post(const QkPostArgs& a, const char* who) {
     const int width = a.heads * a.hd;
-    LT_REQUIRE(a.hd % 8 == 0 && width <= 64 * 8 * 8, "qk_norm_rope: hd %% 8 == 0 and heads*hd <= 4096 required (got %d x %d)", a.heads, a.hd);
-    LT_REQUIRE(a.ld_src % 8 == 0 && a.col0 % 8 == 0, "qk_norm_rope: ld_src/col0 must be multiples of 8");
-    LT_REQUIRE(a.rope_mode == 0 || a.cs != nullptr, "qk_norm_rope: rotary table missing");
-    LT_REQUIRE(a.rope_mode != 1 || (a.hd % 4 == 0 && a.grid_w > 0), "qk_norm_rope: 2-D rope needs hd %% 4 == 0");
-    LT_REQUIRE((a.ln_w == nullptr) == (a.ln_b == nullptr), "qk_norm_rope: LayerNorm weight and bias must come together");
+    LT_REQUIRE(a.hd % 8 == 0 && width <= 64 * 8 * 8, "%s: hd %% 8 == 0 and heads*hd <= 4096 required (got %d x %d)", who, a.heads, a.hd);
+    LT_REQUIRE(a.ld_src % 8 == 0 && a.col0 % 8 == 0, "%s: ld_src/col0 must be multiples of 8", who);
+    LT_REQUIRE(a.rope_mode == 0 || a.cs != nullptr, "%s: rotary table missing", who);
+    LT_REQUIRE(a.rope_mode != 1 || (a.hd % 4 == 0 && a.grid_w > 0), "%s: 2-D rope needs hd %% 4 == 0 and grid_w > 0 (got hd %d, grid_w %d)", who, a.hd, a.grid_w);
+    LT_REQUIRE((a.ln_w == nullptr) == (a.ln_b == nullptr), "%s: LayerNorm weight and bias must come together", who);
+    return 0;
+}
+
+int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
+    if (int rc = validate_qk_post(a, "qk_norm_rope")) return rc;
+    const int width = a.heads * a.hd;
     const int rows = a.B * a.N;
     // persistent grid: ~2 workgroups (16 waves) per CU, never more workgroups than rows / 8
-    int cus = 256;
-    {
-        static int cached = 0;
-        if (!cached) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                cached = prop.multiProcessorCount;
-            else cached = 256;
-        }
-        cus = cached;
-    }
+    const int cus = num_cus();
     const int max_blocks = (rows + QK_WAVES - 1) / QK_WAVES;
     const dim3 grid(std::min(max_blocks, QK_WG_PER_CU * cus));
     const size_t smem = (size_t)width * 4 + (size_t)QK_WAVES * (a.hd >> 1) * 8;
@@ -385,17 +381,11 @@ int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
 }
 
 int launch_qk_norm_rope_pair(const QkPostArgs& q, const QkPostArgs& k, hipStream_t stream) {
+    if (int rc = validate_qk_post(q, "qk_norm_rope_pair (q)")) return rc;
+    if (int rc = validate_qk_post(k, "qk_norm_rope_pair (k)")) return rc;
     const int wq = q.heads * q.hd, wk = k.heads * k.hd;
-    LT_REQUIRE(q.hd % 8 == 0 && q.hd == k.hd && wk <= wq && wq <= 64 * 8 * 8, "qk_norm_rope_pair: widths %d / %d unsupported", wq, wk);
-    LT_REQUIRE(q.ld_src % 8 == 0 && q.col0 % 8 == 0 && k.ld_src % 8 == 0 && k.col0 % 8 == 0, "qk_norm_rope_pair: ld_src/col0 must be multiples of 8");
-    LT_REQUIRE((q.rope_mode == 0 || q.cs != nullptr) && (k.rope_mode == 0 || k.cs != nullptr), "qk_norm_rope_pair: rotary table missing");
-    LT_REQUIRE((q.ln_w == nullptr) == (q.ln_b == nullptr) && (k.ln_w == nullptr) == (k.ln_b == nullptr), "qk_norm_rope_pair: LayerNorm weight and bias must come together");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    LT_REQUIRE(q.hd == k.hd && wk <= wq, "qk_norm_rope_pair: widths %d / %d unsupported", wq, wk);
+    const int cus = num_cus();
     // QK_WG_PER_CU workgroups per CU in total, split by the bytes of the two streams (GQA: the k stream is a quarter of the q stream)
     const int rows = q.B * q.N;
     const int total = std::min((2 * rows + QK_WAVES - 1) / QK_WAVES, QK_WG_PER_CU * cus);

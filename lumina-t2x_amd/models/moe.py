@@ -164,4 +164,17 @@ def DiT_Llama_600M_patch2_Both(**kwargs):
 
 
 def DiT_Llama_600M_GQA_patch2(**kwargs):
+    """reference models.py:1021-1024: like its siblings above, the name resolves to the file the un-suffixed builders come from
+    (models.py = time-routed experts).  The reference defines the same name in models1.py / models2.py for the other two routings;
+    those are spelled out below."""
+    return DiT_Llama_TimeMoE(patch_size=2, dim=1536, n_layers=16, n_heads=32, n_kv_heads=8, **kwargs)
+
+
+def DiT_Llama_600M_GQA_patch2_Spatial(**kwargs):
+    """reference models1.py:1021-1024 (there: DiT_Llama_600M_GQA_patch2)"""
+    return DiT_Llama_SpaceMoE(patch_size=2, dim=1536, n_layers=16, n_heads=32, n_kv_heads=8, **kwargs)
+
+
+def DiT_Llama_600M_GQA_patch2_Both(**kwargs):
+    """reference models2.py:1069-1072 (there: DiT_Llama_600M_GQA_patch2)"""
     return DiT_Llama(patch_size=2, dim=1536, n_layers=16, n_heads=32, n_kv_heads=8, **kwargs)

@@ -453,6 +453,40 @@ def test_hip_graph_replay_is_bit_identical_to_eager_launches(golden_dir):
         assert torch.equal(a, b)
 
 
+def test_hip_graph_replay_rebuilds_the_shared_rope_table_when_keys_alternate(golden_dir):
+    """the RoPE table is one buffer outside every graph.  Key A (scale_factor 1) captured and replayed, then key B
+    (scale_factor 2) rebuilds the table, then key A again: its cached graph must not replay against B's table."""
+    from gpu_util import set_option
+    g, cfg = _golden(golden_dir, "nextdit_tiny")
+    model = _model(cfg, int(g["seed_w"]))
+    z, t, cap, mask = _inputs(g)
+    t_hi = torch.full((2,), 0.8, device="cuda")
+    kwA = dict(base_seqlen=16, proportional_attn=True, scale_factor=1.0, scale_watershed=1.0)
+    kwB = dict(base_seqlen=16, proportional_attn=True, scale_factor=2.0, scale_watershed=0.3)
+
+    def runs():
+        outs = [model.forward_with_cfg(z, t_hi, cap, mask, 4.0, **kwA) for _ in range(3)]
+        outs += [model.forward_with_cfg(z, t_hi, cap, mask, 4.0, **kwB) for _ in range(3)]
+        outs += [model.forward_with_cfg(z, t_hi, cap, mask, 4.0, **kwA) for _ in range(2)]
+        outs += [model.forward_with_cfg(z, t_hi, cap, mask, 4.0, **kwB) for _ in range(2)]
+        return outs
+
+    try:
+        set_option("graph", 1)
+        before = model._engine.graph_replays() if model._engine is not None else 0
+        with_graph = runs()
+        replays = model._engine.graph_replays() - before
+        set_option("graph", 0)
+        eager = runs()
+    finally:
+        set_option("graph", 1)
+    assert replays >= 6, replays
+    assert not torch.equal(eager[0], eager[3])  # the two keys really differ (NTK branch at t = 0.8)
+    for i, (a, b) in enumerate(zip(with_graph, eager)):
+        assert torch.equal(a, b), i
+    assert torch.equal(with_graph[6], with_graph[0]) and torch.equal(with_graph[8], with_graph[3])
+
+
 @pytest.mark.gpu
 def test_attention_variants_3_and_4_agree_in_the_model():
     """the default attention kernel (variant 4: one wave per SIMD, text phase through the same tile pipeline) and the ping-pong

@@ -496,3 +496,20 @@ def test_generated_attention_accessors_are_in_sync_with_their_generator(tmp_path
         spec.loader.exec_module(importlib.util.module_from_spec(spec))
         assert open(root.joinpath(*rel)).read() == committed, f"{'/'.join(rel)} is stale: run python scripts/{gen}"
 
+
+
+def test_moe_builder_names_resolve_to_the_reference_files_they_cite():
+    """Next-DiT-MoE defines DiT_Llama_600M_GQA_patch2 in all three model files; in this package the un-suffixed names follow
+    models.py (time-routed), the routing of models1.py / models2.py is in the suffix."""
+    from lumina_t2x_amd.models import moe
+    with torch.device("meta"):
+        a = moe.DiT_Llama_600M_GQA_patch2()
+        b = moe.DiT_Llama_600M_GQA_patch2_Spatial()
+        c = moe.DiT_Llama_600M_GQA_patch2_Both()
+        d = moe.DiT_Llama_600M_patch2()
+    assert type(a) is moe.DiT_Llama_TimeMoE and type(d) is moe.DiT_Llama_TimeMoE
+    assert type(b) is moe.DiT_Llama_SpaceMoE and type(c) is moe.DiT_Llama
+    ka, kd = set(a.state_dict()), set(d.state_dict())
+    assert ka == kd  # GQA changes shapes, not keys
+    assert a.layers[0].attention.wk.weight.shape[0] == 8 * 48 and d.layers[0].attention.wk.weight.shape[0] == 32 * 48
+    assert any("feed_forward_space" in k for k in c.state_dict()) and not any("feed_forward_space" in k for k in ka)
