@@ -18,8 +18,9 @@ time-aware RoPE scaling, one image per GPU: its BASELINE form "batch = 8 sharded
 
 ``roofline`` is measured live with HIP events around every launch of the dominant kernel class (the bf16 MFMA GEMMs,
 76 % of the algorithmic FLOPs) on the launch stream; ``cpu_baseline`` times the CPU oracle (fp32, host
-cores) on a bounded sample: a full-width forward_with_cfg with 2 of the 24 layers, scaled to 24; the one TRUE reference
-timing (unmodified reference module, authoring container) is quoted beside it from profiles/.
+cores) on ONE complete forward_with_cfg of the bench workload (all 24 layers: 30-70 s of CPU time, measured, not
+extrapolated); the TRUE reference timing (unmodified reference module, authoring container, min of 3 with the host load
+stated) is quoted beside it from profiles/.  ``power`` is the socket power sampled over the timed region.
 """
 import argparse
 import json
@@ -90,6 +91,93 @@ def random_init_(model, seed):
                 p.normal_(0.0, min(0.06, p.shape[-1] ** -0.5), generator=g)
 
 
+class PowerSampler:
+    """Socket power of one GPU sampled on a host thread while a region runs (amdsmi, else the hwmon power file).  The GEMM / attention
+    kernels of this path run under the board's power cap; this is the measurement in watts beside the clock
+    evidence: `avg_w`, `max_w`, the gfx clock seen, and joules per algorithmic TFLOP of the region."""
+
+    def __init__(self, index=0, period_s=0.005):
+        self.index, self.period, self.samples, self.clocks = index, period_s, [], []
+        self._stop = self._thread = self._read = self._clk = None
+        self.source = None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[index]
+
+            def read():
+                d = amdsmi.amdsmi_get_power_info(h)
+                for k in ("current_socket_power", "average_socket_power", "socket_power"):
+                    v = d.get(k)
+                    if isinstance(v, (int, float)) and v > 0:
+                        return float(v)
+                return None
+
+            def clk():
+                try:
+                    c = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                    v = c.get("clk", c.get("cur_clk"))
+                    return float(v) if isinstance(v, (int, float)) else None
+                except Exception:
+                    return None
+
+            if read() is not None:
+                self._read, self._clk, self.source = read, clk, "amdsmi socket power"
+        except Exception:
+            pass
+        if self._read is None:
+            import glob
+            files = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") +
+                           glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+            if files:
+                f = files[min(index, len(files) - 1)]
+
+                def read():
+                    try:
+                        with open(f) as fh:
+                            return float(fh.read().strip()) * 1e-6
+                    except Exception:
+                        return None
+
+                if read():
+                    self._read, self._clk, self.source = read, (lambda: None), f
+
+    def __enter__(self):
+        import threading
+        if self._read is None:
+            return self
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                w = self._read()
+                if w:
+                    self.samples.append(w)
+                c = self._clk()
+                if c:
+                    self.clocks.append(c)
+                self._stop.wait(self.period)
+
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+
+    def report(self, seconds, tflop):
+        if not self.samples:
+            return None
+        avg = sum(self.samples) / len(self.samples)
+        out = {"avg_w": avg, "max_w": max(self.samples), "samples": len(self.samples), "source": self.source,
+               "joule_per_tflop": avg * seconds / tflop if tflop > 0 else None}
+        if self.clocks:
+            out["gfx_clock_mhz_avg"] = sum(self.clocks) / len(self.clocks)
+        return out
+
+
 def pmc_traffic():
     """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes of this same command (scripts/gpu_prof.sh ->
     profiles/rNN/pmc_gemm.json; PMC passes are separate runs by construction).  None when no summary is committed."""
@@ -122,15 +210,18 @@ def rocprof_gemm_time_per_nfe():
 def reference_cpu_timing():
     """the one TRUE reference number: 1 NFE of the unmodified NextDiT_2B_patch2 (fp32, CPU) in the authoring container, recorded
     by oracle/make_fulldepth_golden.py (the GPU box has no /root/reference)"""
-    path = os.path.join(REPO, "profiles", "r02", "reference_cpu_timing.json")
-    if not os.path.exists(path):
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "reference_cpu_timing.json")))
+    if not files:
         return None
+    path = files[-1]
     with open(path) as f:
         return json.load(f)
 
 
-def cpu_baseline(latent, n_tokens, n_sample_layers=2):
-    """Oracle (CPU restatement of the reference forward, fp32, host cores) on a bounded sample."""
+def cpu_baseline(latent, n_tokens):
+    """Oracle (CPU restatement of the reference forward, fp32, host cores): ONE complete forward_with_cfg of the bench workload -
+    all 24 layers, full width, 4096 tokens - timed, not extrapolated."""
     import torch
     from oracle import nextdit_oracle as O
     from oracle import synth
@@ -151,28 +242,32 @@ def cpu_baseline(latent, n_tokens, n_sample_layers=2):
         if rate > best * 1.05:
             best, cores = rate, n
     torch.set_num_threads(cores)
-    cfg = synth.NextDiTConfig(n_layers=n_sample_layers)
-    sd = synth.synth_state_dict(cfg, seed=0)
+    cfg = synth.NextDiTConfig()
+    assert cfg.n_layers == 24 and cfg.dim == 2304
+    t0 = time.time()
+    sd = synth.synth_state_dict(cfg, seed=0, streams=True)
+    t_draw = time.time() - t0
     z, t, cap, mask = synth.synth_inputs(cfg, latent_hw=(latent, latent), text_len=TEXT_LEN, uncond_len=8, seed=1)
     kw = dict(cfg_scale=4.0, proportional_attn=True, base_seqlen=n_tokens)
-    t0 = time.time()
-    O.forward_with_cfg(sd, cfg, z, t, cap, mask, n_layers=0, **kw)
-    t_fixed = time.time() - t0
-    t0 = time.time()
-    O.forward_with_cfg(sd, cfg, z, t, cap, mask, **kw)
-    t_sample = time.time() - t0
-    per_layer = max(t_sample - t_fixed, 1e-9) / n_sample_layers
-    t_nfe = t_fixed + 24 * per_layer
-    out = {
+    with torch.no_grad():
+        t0 = time.time()
+        out = O.forward_with_cfg(sd, cfg, z, t, cap, mask, **kw)
+        t_nfe = time.time() - t0
+    assert torch.isfinite(out).all()
+    try:
+        load = os.getloadavg()[0]
+    except OSError:
+        load = None
+    res = {
         "value": n_tokens / t_nfe, "unit": "latent-tokens/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle fp32 forward_with_cfg at full width (d=2304, N={n_tokens}, T=128, B=2) with {n_sample_layers} of 24 "
-                   f"layers: {t_sample:.1f} s; embed/final part {t_fixed:.2f} s; extrapolated to 24 layers = {t_nfe:.1f} s per NFE"),
-        "denoising_steps_per_s": 1.0 / t_nfe,
+        "sample": (f"ONE complete oracle fp32 forward_with_cfg of the bench workload (24 of 24 layers, d=2304, N={n_tokens}, T=128, B=2): "
+                   f"{t_nfe:.1f} s measured on {cores} threads ({ncpu} logical CPUs, 1-min load {load}); weight draw {t_draw:.0f} s not counted"),
+        "denoising_steps_per_s": 1.0 / t_nfe, "seconds_per_nfe": t_nfe,
     }
     ref = reference_cpu_timing()
     if ref:
-        out["reference_module_authoring_container"] = ref
-    return out
+        res["reference_module_authoring_container"] = ref
+    return res
 
 
 def gemm_kernel_label(lib, M, d, F, dkv, tokens, hd):
@@ -285,11 +380,13 @@ def main():
     eng.profile_reset()
     parallel.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    traj = run(args.steps)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    dt = time.perf_counter() - t0
+    power = PowerSampler(local)
+    with power:
+        t0 = time.perf_counter()
+        traj = run(args.steps)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
     eng.profile_enable(False)
     assert eng.last_nfe() == args.steps
@@ -342,14 +439,17 @@ def main():
                 # kernel trace of the same command gives the pure kernel durations
                 "rocprofv3_cross_check": (None if rp_ms is None else {
                     "gemm_ms_per_step": rp_ms, "achieved": gemm_fl_per_nfe / (rp_ms * 1e-3) / 1e12,
-                    "frac": gemm_fl_per_nfe / (rp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "source": rp_src}),
+                    "frac": gemm_fl_per_nfe / (rp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "source": rp_src,
+                    "box": "builder's profiling box (a committed file), NOT this run's box"}),
             },
             "kernel_time_ms_per_step": dict(breakdown, note=f"untimed pass of {nb} NFE with events around every launch"),
             "attention_tflops_per_s": attn_fl_b / (attn_ms_b * 1e-3) / 1e12 if attn_ms_b > 0 else 0.0,
             "kernel_variants": {"attention": args.attn_variant or 4, "gemm": args.gemm_variant or 0},
             "hip_graph_replays": eng.graph_replays(),
-            "ode_stepping_parity": "unpinned (torchdiffeq is neither vendored, pinned nor installed; fixed-grid solvers restated "
-                                   "from its published algorithm, DESIGN.md 6)",
+            "power": power.report(dt, nfe_flops * args.steps / 1e12),
+            "ode_stepping_parity": "euler (this run) and midpoint pinned to the reference's in-tree midpoint_solver (visual_anagrams/"
+                                   "generate.py:212-219, tests/golden/solver_kat.npz); rk4 / dopri5 restate torchdiffeq (absent "
+                                   "everywhere) and stay unpinned, DESIGN.md 6",
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             out["cpu_baseline"] = cpu_baseline(latent, n_tokens)

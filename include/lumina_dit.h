@@ -165,6 +165,16 @@ int64_t lt_last_nfe(lt_engine* e);
 /* model evaluations served by replaying a captured HIP graph since lt_create (0 with lt_set_option("graph", 0)) */
 int64_t lt_graph_replays(lt_engine* e);
 
+/* ---- mixture-of-experts routing hooks (parity tests: hold the discrete top-2 choice equal to a reference run's) ----
+ * Tables are host int32 [n_layers][2 branches: 0 time-routed, 1 token-routed][rows][2], rows = batch * tokens of the call, expert
+ * ids in ascending order per row; branches a variant does not run are -1.  Both hooks switch HIP-graph replay off while active.
+ * record(on): every following forward stores the experts moe_route picked; read() returns the last forward's table.
+ * force(sel, rows): the following forwards of exactly `rows` rows use these experts instead of their own top-2 (the softmax
+ * weights are still computed from the call's own router logits); force(NULL, 0) ends it. */
+int lt_moe_routing_record(lt_engine* e, int32_t on);
+int lt_moe_routing_read(lt_engine* e, int32_t* host_out, int32_t rows);
+int lt_moe_routing_force(lt_engine* e, const int32_t* host_sel, int32_t rows);
+
 /* ---- profiling hooks (bench.py roofline object) ----------------------------------------------- */
 /* class 0 = MFMA GEMM kernel, 1 = attention kernel, 2 = everything else.  When enabled, every
  * launch of that class is bracketed by HIP events on the launch stream. */

@@ -75,6 +75,9 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_sample_ode": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(_f32), _i32, _i32, _i32, _i32, C.POINTER(LtStepArgs), _vp]),
     "lt_last_nfe": (_i64, [_vp]),
     "lt_graph_replays": (_i64, [_vp]),
+    "lt_moe_routing_record": (_i32, [_vp, _i32]),
+    "lt_moe_routing_read": (_i32, [_vp, C.POINTER(_i32), _i32]),
+    "lt_moe_routing_force": (_i32, [_vp, C.POINTER(_i32), _i32]),
     "lt_profile_enable": (_i32, [_vp, _i32]),
     "lt_profile_read": (_i32, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "lt_profile_reset": (_i32, [_vp]),

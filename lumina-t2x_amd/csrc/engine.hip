@@ -133,6 +133,9 @@ struct lt_engine {
     int moe_mode = 0;  // 0: time + space MoE per block (models2.py), 1: time-routed MoE only (models.py), 2: token-routed only (models1.py)
     u16 *moe_xs = nullptr, *moe_us = nullptr, *moe_ys = nullptr, *moe_logits = nullptr, *moe_wts = nullptr;
     int *moe_sel = nullptr, *moe_pos = nullptr, *moe_tile_expert = nullptr;
+    // parity hooks (lt_moe_routing_*): [L][2 branches][max rows][2] expert ids, recorded from / forced onto moe_route_kernel
+    int *moe_rec = nullptr, *moe_force = nullptr;
+    int moe_rec_on = 0, moe_force_rows = 0, moe_rec_rows = 0;
     u16 *capb = nullptr, *capn = nullptr, *kvy = nullptr;
     float* txt_bias = nullptr;
     float* rope = nullptr;
@@ -369,7 +372,7 @@ int ensure_rope(lt_engine* e, const lt_step_args* a, hipStream_t s) {
 
 // one MoE feed-forward (branch 0 = TimeMoeLayer on the timestep embedding, 1 = SpaceMoeLayer on the tokens;
 // models2.py:451-506): e->h -> e->o
-int moe_ffn(lt_engine* e, LayerW& w, int branch, int M, int N, int B, hipStream_t s) {
+int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B, hipStream_t s) {
     const int d = e->d, F = e->F, A = e->A;
     MoeArgs m;
     m.x = e->h; m.rows = M; m.rows_per_sample = N; m.d = d; m.E = e->E;
@@ -379,7 +382,7 @@ int moe_ffn(lt_engine* e, LayerW& w, int branch, int M, int N, int B, hipStream_
     const int tiles = (int)((2 * (size_t)M + (size_t)e->E * 255 + 255) / 256);
     m.sel = e->moe_sel; m.wts = e->moe_wts; m.pos = e->moe_pos; m.tile_expert = e->moe_tile_expert; m.max_tiles = tiles;
     m.xs = e->moe_xs; m.ys = e->moe_ys; m.out = e->o;
-    m.gate_w = nullptr; m.sample_logits = nullptr;
+    m.gate_w = nullptr; m.sample_logits = nullptr; m.forced = nullptr;
     {
         ProfScope ps(e, 2, 0, s);
         if (branch == 0) {  // gate(cond) with cond = t_embedder(t) (models2.py:462, :950-951)
@@ -388,7 +391,16 @@ int moe_ffn(lt_engine* e, LayerW& w, int branch, int M, int N, int B, hipStream_
         } else {
             m.gate_w = w.gate_s;
         }
+        const size_t slot = ((size_t)layer * 2 + branch) * (size_t)e->cfg.max_batch * e->cfg.max_tokens * 2;
+        if (e->moe_force_rows) {
+            LT_REQUIRE(e->moe_force_rows == M, "forced MoE routing was given for %d rows, this call has %d", e->moe_force_rows, M);
+            m.forced = e->moe_force + slot;
+        }
         if (launch_moe_route(m, s)) return 1;
+        if (e->moe_rec_on) {
+            LT_CHECK_HIP(hipMemcpyAsync(e->moe_rec + slot, e->moe_sel, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
+            e->moe_rec_rows = M;
+        }
         if (launch_moe_plan(m, s)) return 1;
         if (launch_moe_gather(m, s)) return 1;
     }
@@ -627,11 +639,11 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             last_post_w = v.post ? w.ffn_norm2 : nullptr;
             last_gate = chunk(l, v.i_gate[1]);
         } else if (e->moe_mode != 0) {  // one MoE FFN in the ImageNet block (models.py:755-758: time-routed; models1.py: per token)
-            if (moe_ffn(e, w, e->moe_mode == 1 ? 0 : 1, M, N, B, s)) return 1;
+            if (moe_ffn(e, w, l, e->moe_mode == 1 ? 0 : 1, M, N, B, s)) return 1;
             last_post_w = w.ffn_norm2;
             last_gate = chunk(l, v.i_gate[1]);
         } else {  // time MoE -> residual -> space MoE (models2.py:793-800)
-            if (moe_ffn(e, w, 0, M, N, B, s)) return 1;
+            if (moe_ffn(e, w, l, 0, M, N, B, s)) return 1;
             {
                 ProfScope ps(e, 2, 0, s);
                 GatedResArgs g;
@@ -640,7 +652,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
                 if (launch_gated_residual_norm(g, s)) return 1;
             }
-            if (moe_ffn(e, w, 1, M, N, B, s)) return 1;
+            if (moe_ffn(e, w, l, 1, M, N, B, s)) return 1;
             last_post_w = w.norm_space;
             last_gate = chunk(l, 5);
         }
@@ -697,7 +709,7 @@ bool profiling_wants_events(const lt_engine* e) {
 }
 
 int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* out, const lt_step_args* a, int use_cfg, hipStream_t s) {
-    if (!g_graph || profiling_wants_events(e)) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+    if (!g_graph || profiling_wants_events(e) || e->moe_rec_on || e->moe_force_rows) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
     const int B = a->batch;
     if (B < 1 || B > e->cfg.max_batch || a->latent_h <= 0 || a->latent_w <= 0 || (a->io_dtype != LT_BF16 && a->io_dtype != LT_F32))
         return run_forward(e, x_in, t_dev, out, a, use_cfg, s);  // let the eager path produce the error message
@@ -929,6 +941,8 @@ extern "C" void lt_destroy(lt_engine* e) {
     if (e->pk_dev) (void)hipFree(e->pk_dev);
     if (e->reg_txt) (void)hipFree(e->reg_txt);
     if (e->reg_qmap) (void)hipFree(e->reg_qmap);
+    if (e->moe_rec) (void)hipFree(e->moe_rec);
+    if (e->moe_force) (void)hipFree(e->moe_force);
     for (int k = 0; k < 3; ++k)
         for (auto& pr : e->prof[k].ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete e;
@@ -1183,6 +1197,49 @@ extern "C" int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, vo
 
 extern "C" int64_t lt_last_nfe(lt_engine* e) { return e ? e->last_nfe : -1; }
 extern "C" int64_t lt_graph_replays(lt_engine* e) { return e ? e->graph_replays : -1; }
+
+// ---- MoE routing parity hooks -------------------------------------------------------------------------
+namespace {
+size_t moe_table_ints(const lt_engine* e) { return (size_t)e->L * 2 * e->cfg.max_batch * e->cfg.max_tokens * 2; }
+}  // namespace
+
+extern "C" int lt_moe_routing_record(lt_engine* e, int32_t on) {
+    LT_REQUIRE(e && e->E > 0, "lt_moe_routing_record: not a mixture-of-experts engine");
+    if (on && !e->moe_rec) {
+        LT_CHECK_HIP(hipMalloc((void**)&e->moe_rec, moe_table_ints(e) * sizeof(int)));
+        LT_CHECK_HIP(hipMemset(e->moe_rec, 0xff, moe_table_ints(e) * sizeof(int)));
+    }
+    e->moe_rec_on = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int lt_moe_routing_read(lt_engine* e, int32_t* host_out, int32_t rows) {
+    LT_REQUIRE(e && e->E > 0 && host_out, "lt_moe_routing_read: not a mixture-of-experts engine / null buffer");
+    LT_REQUIRE(e->moe_rec && e->moe_rec_rows > 0, "lt_moe_routing_read: nothing recorded (lt_moe_routing_record, then a forward)");
+    LT_REQUIRE(rows == e->moe_rec_rows, "lt_moe_routing_read: the last recorded call had %d rows, not %d", e->moe_rec_rows, rows);
+    LT_CHECK_HIP(hipDeviceSynchronize());
+    const size_t cap = (size_t)e->cfg.max_batch * e->cfg.max_tokens * 2;
+    for (int lb = 0; lb < e->L * 2; ++lb)
+        LT_CHECK_HIP(hipMemcpy(host_out + (size_t)lb * rows * 2, e->moe_rec + (size_t)lb * cap, (size_t)rows * 2 * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lt_moe_routing_force(lt_engine* e, const int32_t* host_sel, int32_t rows) {
+    LT_REQUIRE(e && e->E > 0, "lt_moe_routing_force: not a mixture-of-experts engine");
+    if (!host_sel || rows <= 0) { e->moe_force_rows = 0; return 0; }
+    LT_REQUIRE((long long)rows <= (long long)e->cfg.max_batch * e->cfg.max_tokens, "lt_moe_routing_force: %d rows exceed the engine's capacity", rows);
+    for (size_t i = 0; i < (size_t)e->L * 2 * rows * 2; ++i) {
+        // branches the variant does not run carry -1 and are never read
+        LT_REQUIRE(host_sel[i] >= -1 && host_sel[i] < e->E, "lt_moe_routing_force: expert id %d outside 0..%d", host_sel[i], e->E - 1);
+    }
+    if (!e->moe_force) LT_CHECK_HIP(hipMalloc((void**)&e->moe_force, moe_table_ints(e) * sizeof(int)));
+    LT_CHECK_HIP(hipDeviceSynchronize());
+    const size_t cap = (size_t)e->cfg.max_batch * e->cfg.max_tokens * 2;
+    for (int lb = 0; lb < e->L * 2; ++lb)
+        LT_CHECK_HIP(hipMemcpy(e->moe_force + (size_t)lb * cap, host_sel + (size_t)lb * rows * 2, (size_t)rows * 2 * sizeof(int), hipMemcpyHostToDevice));
+    e->moe_force_rows = rows;
+    return 0;
+}
 
 // ---- profiling ------------------------------------------------------------------------------------------
 extern "C" int lt_profile_enable(lt_engine* e, int32_t on) {

@@ -144,6 +144,7 @@ struct MoeArgs {
     const u16* x;              // [rows, d] FFN input (after pre-norm + modulate)
     const u16* gate_w;         // space router weight [E, d] (per-token logits) or null
     const u16* sample_logits;  // time router logits [B, E] bf16 (every token of a sample shares them) or null
+    const int* forced;         // [rows, 2] expert ids that replace the top-2 choice (parity hook, lt_moe_routing_force) or null
     int rows, rows_per_sample, d, E;
     int* sel;                  // [rows, 2] selected experts, ascending expert id (= the reference's accumulation order)
     u16* wts;                  // [rows, 2] bf16 softmax weights aligned with sel

@@ -59,6 +59,10 @@ __global__ __launch_bounds__(256) void moe_route_kernel(MoeArgs p) {
         int i2 = i1 == 0 ? 1 : 0;
 #pragma unroll
         for (int e = 0; e < MAX_E; ++e) if (e != i1 && e != i2 && logit[e] > logit[i2]) i2 = e;
+        if (p.forced) {  // the discrete choice comes from outside (a reference run's); the weights stay this run's own arithmetic
+            i1 = p.forced[2 * row];
+            i2 = p.forced[2 * row + 1];
+        }
         // softmax over (v1, v2) in fp32, then the cast back to the activation dtype (:466-470)
         const float ex = __expf(logit[i2] - logit[i1]);
         const float w1 = 1.0f / (1.0f + ex), w2 = ex / (1.0f + ex);

@@ -265,6 +265,29 @@ class DiTEngine:
         """model evaluations served by a captured HIP graph so far"""
         return int(self.lib.lt_graph_replays(self.handle))
 
+    # ---- mixture-of-experts routing hooks (parity tests) ----------------------------------------------
+    def moe_routing_record(self, on: bool = True) -> None:
+        _lib.check(self.lib.lt_moe_routing_record(self.handle, 1 if on else 0), "lt_moe_routing_record")
+
+    def moe_routing_read(self, rows: int):
+        """experts the last forward picked: int32 array [n_layers, 2 (time, token branch), rows, 2]; -1 = branch not run"""
+        import numpy as np
+        out = np.empty((int(self.cfg.n_layers), 2, rows, 2), dtype=np.int32)
+        _lib.check(self.lib.lt_moe_routing_read(self.handle, out.ctypes.data_as(C.POINTER(C.c_int32)), rows), "lt_moe_routing_read")
+        return out
+
+    def moe_routing_force(self, sel=None) -> None:
+        """sel int32 [n_layers, 2, rows, 2] (ascending expert ids per row) replaces the top-2 choice of the following forwards;
+        None ends it"""
+        import numpy as np
+        if sel is None:
+            _lib.check(self.lib.lt_moe_routing_force(self.handle, None, 0), "lt_moe_routing_force")
+            return
+        sel = np.ascontiguousarray(sel, dtype=np.int32)
+        assert sel.ndim == 4 and sel.shape[0] == int(self.cfg.n_layers) and sel.shape[1] == 2 and sel.shape[3] == 2, sel.shape
+        _lib.check(self.lib.lt_moe_routing_force(self.handle, sel.ctypes.data_as(C.POINTER(C.c_int32)), sel.shape[2]),
+                   "lt_moe_routing_force")
+
     # ---- profiling hooks used by bench.py -----------------------------------------------------------
     def profile_enable(self, on) -> None:
         """False / 0: off; True: every kernel class; int: bit mask (1 GEMM, 2 attention, 4 other)"""

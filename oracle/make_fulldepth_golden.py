@@ -40,19 +40,25 @@ CASES = {
     "full_2b": dict(cfg=synth.NEXT_2B, pkg="lumina_next_t2i", module="models.model", cls="NextDiT", latent_hw=(128, 128), text_len=128,
                     uncond_len=8, seed_w=61, seed_x=62,
                     calls=[("cfg4", 0.5, dict(cfg_scale=4.0, base_seqlen=4096, proportional_attn=True))]),
-    # BASELINE configs[3]: Lumina-Next-SFT 2B (GQA 32/8), time-aware RoPE scaling (scale_factor 2, watershed 0.3): both branches
+    # BASELINE configs[3]: Lumina-Next-SFT 2B (GQA 32/8), time-aware RoPE scaling (scale_factor 2, watershed 0.3): both branches.
+    # The fp32 reference at the config's 16 384 tokens needs an explicit [B, H, N, N] mask (> 62 GB); 4096 tokens as a 32 x 128
+    # patch grid keeps the config's RoPE range (column positions 0..127 under NTK / linear scaling) and its 16-tile key loops
     "full_2b_gqa_ntk": dict(cfg=synth.NextDiTConfig(n_kv_heads=8), pkg="lumina_next_t2i_mini", module="models.nextdit", cls="NextDiT",
-                            latent_hw=(64, 64), text_len=64, uncond_len=8, seed_w=71, seed_x=72,
+                            latent_hw=(64, 256), text_len=128, uncond_len=8, seed_w=71, seed_x=72,
                             calls=[("ntk", 0.6, dict(cfg_scale=4.0, scale_factor=2.0, scale_watershed=0.3, base_seqlen=4096, proportional_attn=True)),
                                    ("lin", 0.1, dict(cfg_scale=4.0, scale_factor=2.0, scale_watershed=0.3, base_seqlen=4096, proportional_attn=True))]),
-    # BASELINE configs[2]: Lumina-T2I 5B (Flag-DiT, 32 layers, d 3072, hd 96), 32 rows x 33 tokens incl. eol
-    "full_flag5b": dict(cfg=synth.FLAG_5B, pkg="lumina_t2i", module="models.model", cls="DiT_Llama", latent_hw=(64, 64), text_len=128,
+    # BASELINE configs[2]: Lumina-T2I 5B (Flag-DiT, 32 layers, d 3072, hd 96) at the config's own 1024^2: 64 rows x 65 tokens incl. eol
+    "full_flag5b": dict(cfg=synth.FLAG_5B, pkg="lumina_t2i", module="models.model", cls="DiT_Llama", latent_hw=(128, 128), text_len=128,
                         uncond_len=8, seed_w=81, seed_x=82,
                         calls=[("cfg4", 0.5, dict(cfg_scale=4.0, base_seqlen=4096, proportional_attn=True))]),
     # BASELINE configs[4]: Next-DiT-MoE 600M "Both" (4 time + 4 space experts per block, 16 layers), 1024 tokens
     "full_moe600m": dict(cfg=synth.NextDiTConfig(dim=1536, n_layers=16, n_heads=32, family="moe"), pkg="Next-DiT-MoE", module="models.models2",
                          cls="DiT_Llama", latent_hw=(64, 64), text_len=0, uncond_len=0, seed_w=91, seed_x=92,
                          calls=[("cfg4", 0.5, dict(cfg_scale=4.0))]),
+    # the same model at the config's own 256^2 (latent 32 x 32 -> 256 tokens, 512 rows with the CFG pair): the small-M kernels
+    "full_moe600m_256": dict(cfg=synth.NextDiTConfig(dim=1536, n_layers=16, n_heads=32, family="moe"), pkg="Next-DiT-MoE", module="models.models2",
+                             cls="DiT_Llama", latent_hw=(32, 32), text_len=0, uncond_len=0, seed_w=91, seed_x=93,
+                             calls=[("cfg4", 0.5, dict(cfg_scale=4.0))]),
 }
 
 
@@ -65,7 +71,7 @@ def weight_checksum(sd):
     return wsum, sd[mats[-1]].flatten()[:8].double().numpy().copy(), pick + [mats[-1]]
 
 
-def oracle_call(cfg, sd, ins, kw, bf16):
+def oracle_call(cfg, sd, ins, kw, bf16, moe_hook=None):
     if cfg.family == "next_t2i":
         z, t, cap, mask = ins
         return O.forward_with_cfg(sd, cfg, z, t, cap, mask, bf16=bf16, **kw)
@@ -73,7 +79,7 @@ def oracle_call(cfg, sd, ins, kw, bf16):
         z, t, cap, mask = ins
         return V.flag_forward_with_cfg(sd, cfg, z, t, cap, mask, bf16=bf16, **kw)
     z, t, y = ins
-    return V.imagenet_forward_with_cfg(sd, cfg, z, t, y, bf16=bf16, **kw)
+    return V.imagenet_forward_with_cfg(sd, cfg, z, t, y, bf16=bf16, moe_hook=moe_hook, **kw)
 
 
 def _fresh_import(pkg, module):
@@ -162,6 +168,29 @@ def run_case(name):
             print(f"[{name}] {tag}: oracle fp32 {t1 - t0:.0f} s, bf16-choreography {time.time() - t1:.0f} s", flush=True)
             out[f"oracle_{tag}"] = want.float().numpy()
             out[f"floor_{tag}"] = floor.float().numpy()
+            if cfg.family.startswith("moe"):
+                # routing-pinned yardstick: the experts the fp32 run selects (the restatement equals the
+                # reference module bit for bit on this draw, so these ARE the reference's selections), the bf16 choreography
+                # re-run with that discrete choice held equal, and how often the free bf16 run agreed with it
+                rec32 = V.MoeRouting(cfg.n_layers)
+                again = oracle_call(cfg, sd, ins, ckw, False, rec32)
+                assert torch.equal(again, want)
+                table = rec32.table()
+                rec16 = V.MoeRouting(cfg.n_layers)
+                free16 = oracle_call(cfg, sd, ins, ckw, True, rec16)
+                assert torch.equal(free16.float(), floor.float())
+                forced = oracle_call(cfg, sd, ins, ckw, True, V.MoeRouting(cfg.n_layers, force=table))
+                t16 = rec16.table()
+                ran = table >= 0
+                agree = float((((t16 == table) | ~ran).all(axis=-1)).mean())
+                assert table.max() < 128
+                out[f"route_{tag}"] = table.astype(np.int8)
+                out[f"floor_forced_{tag}"] = forced.float().numpy()
+                out[f"floor_agree_{tag}"] = np.float64(agree)
+                r = torch.from_numpy(ref[tag]) if tag in ref else want
+                relf = float((forced.float() - r).norm() / r.norm())
+                print(f"[{name}] {tag}: bf16 choreography with the fp32 routing forced vs reference {relf:.3e}; free bf16 routing agrees "
+                      f"with fp32 on {agree * 100:.2f} % of (layer, branch, row) selections", flush=True)
             if tag in ref:
                 out[f"ref_{tag}"] = ref[tag]
                 r = torch.from_numpy(ref[tag])

@@ -80,11 +80,33 @@ def _cfg_combine(out, cfg_scale, bf16):
 
 # ---- time / space MoE (Next-DiT-MoE/models/models2.py:451-506) ---------------------------------------------------------
 
-def _moe_combine(x2d, logits, experts_fn, n_experts, top_k, bf16):
+class MoeRouting:
+    """parity instrument, not part of the reference: records the experts every MoE layer selects ([L][2 branches][rows][2],
+    ascending ids per row, -1 where a branch does not run) and / or replaces the discrete top-2 choice with a given table while
+    the softmax weights stay the run's own arithmetic (what lt_moe_routing_record / _force do in the engine)."""
+
+    def __init__(self, n_layers, force=None):
+        self.n_layers, self.force, self.rec = n_layers, force, {}
+
+    def table(self):
+        import numpy as np
+        rows = max(v.shape[0] for v in self.rec.values())
+        out = np.full((self.n_layers, 2, rows, 2), -1, dtype=np.int32)
+        for (l, b), v in self.rec.items():
+            out[l, b, : v.shape[0]] = v
+        return out
+
+
+def _moe_combine(x2d, logits, experts_fn, n_experts, top_k, bf16, hook=None, where=None):
     """shared tail of TimeMoeLayer / SpaceMoeLayer.forward (:464-477 / :493-506): top-k over the router logits, fp32
     softmax over the selected logits, cast to the activation dtype, then for expert 0, 1, ... in order
     ``results[rows] += weight * expert(rows)`` (results starts as zeros in the activation dtype)."""
     weights, selected = torch.topk(logits, top_k)
+    if hook is not None:
+        if hook.force is not None:
+            selected = torch.from_numpy(hook.force[where[0], where[1], : logits.shape[0]]).long()
+            weights = torch.gather(logits, 1, selected)
+        hook.rec[where] = torch.sort(selected, dim=1).values.to(torch.int32).numpy().copy()
     weights = _r(F.softmax(weights.float(), dim=1), bf16)
     results = torch.zeros_like(x2d)
     for e in range(n_experts):
@@ -95,29 +117,29 @@ def _moe_combine(x2d, logits, experts_fn, n_experts, top_k, bf16):
     return results
 
 
-def moe_time(sd, p, cfg, x, cond, bf16):
+def moe_time(sd, p, cfg, x, cond, bf16, hook=None, layer=0):
     """TimeMoeLayer.forward (:459-477): the router sees the TIME embedding, so every token of a sample shares experts."""
     B, N, d = x.shape
     logits = _linear(cond, sd[p + "gate.weight"], None, bf16)              # nn.Linear(min(dim,1024), E, bias=False)
     logits = logits.repeat(1, N).view(B * N, -1)
     out = _moe_combine(x.reshape(B * N, d), logits, lambda e, rows: feed_forward(sd, p + f"experts.{e}.", rows, bf16),
-                       cfg.num_experts, cfg.num_experts_per_tok, bf16)
+                       cfg.num_experts, cfg.num_experts_per_tok, bf16, hook, (layer, 0))
     return out.view(B, N, d)
 
 
-def moe_space(sd, p, cfg, x, bf16):
+def moe_space(sd, p, cfg, x, bf16, hook=None, layer=0):
     """SpaceMoeLayer.forward (:488-506): per-token router on the FFN input."""
     B, N, d = x.shape
     x2 = x.reshape(B * N, d)
     logits = _linear(x2, sd[p + "gate.weight"], None, bf16)               # nn.Linear(dim, E, bias=False)
     out = _moe_combine(x2, logits, lambda e, rows: feed_forward(sd, p + f"experts.{e}.", rows, bf16),
-                       cfg.num_experts, cfg.num_experts_per_tok, bf16)
+                       cfg.num_experts, cfg.num_experts_per_tok, bf16, hook, (layer, 1))
     return out.view(B, N, d)
 
 
 # ---- class-conditional Next-DiT (ImageNet) and its MoE sibling ----------------------------------------------------------
 
-def imagenet_block(sd, i, cfg: NextDiTConfig, x, freqs_cis, adaln_input, time_input, bf16):
+def imagenet_block(sd, i, cfg: NextDiTConfig, x, freqs_cis, adaln_input, time_input, bf16, moe_hook=None):
     """TransformerBlockSandwichNorm2.forward: Next-DiT-ImageNet/models/models.py:759-796 (4 chunks) and
     Next-DiT-MoE/models/models2.py:769-820 (6 chunks, two FFN branches, the second on the updated stream)."""
     p = f"layers.{i}."
@@ -138,19 +160,19 @@ def imagenet_block(sd, i, cfg: NextDiTConfig, x, freqs_cis, adaln_input, time_in
         f = feed_forward(sd, p + "feed_forward.", mod1(pf_rmsnorm(h, eps, bf16), ch[2]), bf16)
         return gated(h, ch[3], f, "ffn_norm.weight")
     if cfg.family == "moe_time":   # Next-DiT-MoE/models/models.py:755-758: `feed_forward` is ONE time-routed MoeLayer
-        f = moe_time(sd, p + "feed_forward.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[2]), time_input, bf16)
+        f = moe_time(sd, p + "feed_forward.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[2]), time_input, bf16, moe_hook, i)
         return gated(h, ch[3], f, "ffn_norm.weight")
     if cfg.family == "moe_space":  # Next-DiT-MoE/models/models1.py:755-758: ONE token-routed MoeLayer
-        f = moe_space(sd, p + "feed_forward.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[2]), bf16)
+        f = moe_space(sd, p + "feed_forward.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[2]), bf16, moe_hook, i)
         return gated(h, ch[3], f, "ffn_norm.weight")
-    ft = moe_time(sd, p + "feed_forward_time.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[2]), time_input, bf16)
+    ft = moe_time(sd, p + "feed_forward_time.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[2]), time_input, bf16, moe_hook, i)
     h = gated(h, ch[3], ft, "ffn_norm_time.weight")
-    fs = moe_space(sd, p + "feed_forward_space.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[4]), bf16)
+    fs = moe_space(sd, p + "feed_forward_space.", cfg, mod1(pf_rmsnorm(h, eps, bf16), ch[4]), bf16, moe_hook, i)
     return gated(h, ch[5], fs, "ffn_norm_space.weight")
 
 
 def imagenet_forward(sd_in: Dict[str, torch.Tensor], cfg: NextDiTConfig, x, t, y, *, freqs_table=None, bf16: bool = False,
-                     n_layers: Optional[int] = None, return_hidden: bool = False):
+                     n_layers: Optional[int] = None, return_hidden: bool = False, moe_hook=None):
     """DiT_Llama.forward (Next-DiT-ImageNet/models/models.py:920-944; MoE: models2.py:930-958, which hands the
     timestep embedding to every block as ``time_input``)."""
     sd = _sd(sd_in, bf16)
@@ -168,7 +190,7 @@ def imagenet_forward(sd_in: Dict[str, torch.Tensor], cfg: NextDiTConfig, x, t, y
     L = cfg.n_layers if n_layers is None else n_layers
     hidden = []
     for i in range(L):
-        h = imagenet_block(sd, i, cfg, h, freqs_cis, adaln_input, te, bf16)
+        h = imagenet_block(sd, i, cfg, h, freqs_cis, adaln_input, te, bf16, moe_hook)
         if return_hidden:
             hidden.append(h)
     o = _final_shift_scale(sd, cfg, h, adaln_input, bf16)
@@ -181,14 +203,15 @@ def imagenet_forward(sd_in: Dict[str, torch.Tensor], cfg: NextDiTConfig, x, t, y
 
 
 def imagenet_forward_with_cfg(sd, cfg: NextDiTConfig, x, t, y, cfg_scale, rope_scaling_factor=None, ntk_factor=None,
-                              bf16=False, n_layers=None):
+                              bf16=False, n_layers=None, moe_hook=None):
     """DiT_Llama.forward_with_cfg (models.py:946-974)."""
     table = None
     if rope_scaling_factor is not None or ntk_factor is not None:
         assert rope_scaling_factor is not None and ntk_factor is not None
         table = rope_table_2d_general(cfg.head_dim, 384, rope_scaling_factor=rope_scaling_factor, ntk_factor=ntk_factor)
     half = x[: len(x) // 2]
-    out = imagenet_forward(sd, cfg, torch.cat([half, half], dim=0), t, y, freqs_table=table, bf16=bf16, n_layers=n_layers)
+    out = imagenet_forward(sd, cfg, torch.cat([half, half], dim=0), t, y, freqs_table=table, bf16=bf16, n_layers=n_layers,
+                           moe_hook=moe_hook)
     return _cfg_combine(out, cfg_scale, bf16)
 
 

@@ -4,7 +4,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 export LT_NO_EVENT_PROFILE=1  # the engine's own HIP events off: rocprofv3's trace is the measurement here
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof
+OUT=${PROF_OUT:-$R/gpurun_out/prof}
 rm -rf $OUT; mkdir -p $OUT
 cd $R
 STEPS=${PROF_STEPS:-6}

@@ -233,7 +233,7 @@ def test_oracle_compositional_regional_attention_matches_reference(golden_dir, n
 
 # ---- full-depth, full-width fixtures of the BASELINE configs (oracle/make_fulldepth_golden.py) -----------------------------------
 
-FULL = ["full_2b", "full_2b_gqa_ntk", "full_flag5b", "full_moe600m"]
+FULL = ["full_2b", "full_2b_gqa_ntk", "full_flag5b", "full_moe600m", "full_moe600m_256"]
 
 
 @pytest.mark.parametrize("name", FULL)
@@ -252,6 +252,12 @@ def test_fulldepth_oracle_is_pinned_to_the_reference(golden_dir, name):
         f = float((floor - ref).norm() / ref.norm())
         assert 5e-3 < f < (0.35 if "moe" in name else 8e-2), f
         assert torch.equal(ref[0, :3], ref[1, :3])  # CFG on channels [:3]: both rows carry the guided value (model.py:908-913)
+        if "moe" in name:  # routing-pinned yardstick: with the discrete choice held equal the bf16 noise is the dense models'
+            ff = torch.from_numpy(g[f"floor_forced_{tag}"])
+            assert 5e-3 < float((ff - ref).norm() / ref.norm()) < 8e-2
+            route = g[f"route_{tag}"]
+            assert route.shape[:2] == (16, 2) and route.shape[3] == 2 and route.min() >= 0 and route.max() < 4
+            assert (route[..., 0] < route[..., 1]).all() and 0.5 < float(g[f"floor_agree_{tag}"]) < 1.0
 
 
 def test_fulldepth_weight_draw_is_reproducible(golden_dir):
