@@ -35,9 +35,11 @@ extern "C" const char* lt_version(void) { return lt_gemm_has_experimental() ? "l
 namespace {
 
 constexpr float LOG2E = 1.44269504088896340736f;
-// lt_set_option("qkv_post_fused"): 1 = one launch for q / k post-processing + V transpose, 0 = three launches.  In-situ A/B
-// with the LDS-staged row kernels (profiles/r01/bench_ab_qkv_post_fused.log): three launches 0.1-0.2 ms / NFE faster.
-int g_qkv_post_fused = 0;
+// lt_set_option("qkv_post_fused"): 1 = one launch for q / k post-processing + V transpose, 0 = three launches, 2 (default) = one
+// launch where the problem is launch-bound (fewer than 2048 rows: the three passes are 5 us each at 512 rows, i.e. pure launch
+// latency - profiles/r02/rocprofv3_kernel_stats_cfg1_r02.csv), three where it is bandwidth-bound (in-situ A/B at cfg 2 with the
+// LDS-staged row kernels, profiles/r01/bench_ab_qkv_post_fused.log: three launches 0.1-0.2 ms / NFE faster).
+int g_qkv_post_fused = 2;
 // lt_set_option("qkv_vt_epilogue"): 1 = the V projection is its own GEMM launch whose epilogue writes the attention kernels' V^T
 // image (no v_transpose pass: 15.6 us per layer at cfg 2, and the 37.7 MB V slice is never written row-major / re-read)
 int g_qkv_vt_epilogue = 1;
@@ -583,7 +585,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             pa.k = qa;
             pa.v_src = e->qkv; pa.v_dst = e->vt; pa.v_ld_src = e->qkvn; pa.v_col0 = d + dkv; pa.v_B = B; pa.v_N = N;
             pa.v_Npad = Npad; pa.v_kv_heads = Hkv; pa.v_hd = hd;
-            if (g_qkv_post_fused && !vt_epi) {
+            if (!vt_epi && (g_qkv_post_fused == 1 || (g_qkv_post_fused == 2 && M < 2048))) {
                 if (launch_qkv_post(pa, s)) return 1;  // q, k post-processing and the V transpose in one launch
             } else if (g_qk_post_pair && M >= 2048) {
                 if (launch_qk_norm_rope_pair(pa.q, pa.k, s)) return 1;  // q and k in one persistent launch
@@ -1323,12 +1325,11 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     ++g_option_gen;  // captured graphs bake the kernel selection: every option change starts new graph keys
     if (strcmp(name, "graph") == 0) { g_graph = value != 0; return 0; }
     if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 5, "attention_variant must be 1 .. 5"); lt_set_attention_variant(value); return 0; }
-    if (strcmp(name, "qkv_post_fused") == 0) { g_qkv_post_fused = value != 0; return 0; }
+    if (strcmp(name, "qkv_post_fused") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "qkv_post_fused must be 0, 1 or 2 (auto)"); g_qkv_post_fused = value; return 0; }
     if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
     if (strcmp(name, "qkv_fused_gemm") == 0) { g_qkv_fused_gemm = value != 0; return 0; }
     if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
-    if (strcmp(name, "gemm_swiglu_w4p") == 0) { lt_set_gemm_swiglu_w4p(value != 0); return 0; }
     if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }
     if (strcmp(name, "gemm_group") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_group must be 0..64"); lt_set_gemm_group(value); return 0; }
     if (strcmp(name, "gemm_stagger") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_stagger must be 0..64"); return lt_set_gemm_stagger(value); }

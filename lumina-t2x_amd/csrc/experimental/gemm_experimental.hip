@@ -2,6 +2,8 @@
 // AGPR accumulators (11), 4-wave VGPR-staged (12), 4 x (128 x 128) per-tile form (10), ping-pong tail overlap, trace builds.
 // Built only with `make EXPERIMENTAL=1` (-DLT_EXPERIMENTAL); measurements in profiles/r01/opbench_gemm_*.log and DESIGN.md 5.1.
 #include "../gemm_device.h"
+#include "gemm_w4p.h"
+#include "gemm_small_m.h"
 
 namespace lt_gemm {
 
@@ -499,6 +501,24 @@ int launch_gemm_experimental(const GemmArgs& a, int epilogue, int variant, hipSt
             LT_REQUIRE(!a.tile_expert, "gemm variant 12: dense problems only");
             return epilogue == 1 ? launch_plain(gemm_bf16_w4s<1>, 2 * 512 * 64, dim3(t256), dim3(256), a, stream, ev0, ev1)
                                  : launch_plain(gemm_bf16_w4s<0>, 2 * 512 * 64, dim3(t256), dim3(256), a, stream, ev0, ev1);
+        case 13:
+        case 14: {  // persistent 4 waves x (128 x 128) on 32x32x16 MFMAs (14: a tile's epilogue rides in the next tile's first slab)
+            LT_REQUIRE(!a.tile_expert && a.bias_dtype < 0 && a.K % 64 == 0 && a.K >= 128, "gemm variants 13 / 14: dense, no bias, K %% 64 == 0, K >= 128");
+            const dim3 grid(std::min(t256, exp_num_cus()));
+            if (variant == 14) return epilogue == 1 ? launch_plain(gemm_bf16_w4p<1, true>, S1, grid, dim3(256), a, stream, ev0, ev1)
+                                                    : launch_plain(gemm_bf16_w4p<0, true>, S1, grid, dim3(256), a, stream, ev0, ev1);
+            return epilogue == 1 ? launch_plain(gemm_bf16_w4p<1, false>, S1, grid, dim3(256), a, stream, ev0, ev1)
+                                 : launch_plain(gemm_bf16_w4p<0, false>, S1, grid, dim3(256), a, stream, ev0, ev1);
+        }
+        case 17:
+        case 18: {  // deep-ring small-M kernel (gemm_small_m.h): 128 x 128 (17, also SwiGLU) / 64 x 128 (18) tiles
+            LT_REQUIRE(a.bias_dtype < 0 && a.K % 64 == 0 && a.K >= 32 * 13, "gemm variants 17 / 18: no bias, K %% 64 == 0, K >= 416");
+            LT_REQUIRE(variant == 17 || epilogue == 0, "gemm variant 18: plain epilogue");
+            const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128), t64 = ((a.M + 63) / 64) * ((a.N + 127) / 128);
+            if (variant == 18) return launch_plain(gemm_bf16_sm<0, 2, 4, 12>, 12 * 192 * 64, dim3(std::min(t64, exp_num_cus())), dim3(256), a, stream, ev0, ev1);
+            return epilogue == 1 ? launch_plain(gemm_bf16_sm<1, 4, 4, 8>, 8 * 256 * 64, dim3(std::min(t128, exp_num_cus())), dim3(256), a, stream, ev0, ev1)
+                                 : launch_plain(gemm_bf16_sm<0, 4, 4, 8>, 8 * 256 * 64, dim3(std::min(t128, exp_num_cus())), dim3(256), a, stream, ev0, ev1);
+        }
         default:
             lt_set_error("gemm: variant %d is not an experimental kernel", variant);
             return 2;

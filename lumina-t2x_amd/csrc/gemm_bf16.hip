@@ -32,10 +32,6 @@ template __global__ void gemm_bf16_tn<4, 3, 2, 3, 2>(GemmArgs);
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 1>(GemmArgs);   // SwiGLU on the classic loop (explicit variant 1)
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0>(GemmArgs);   // 8-wave ping-pong (explicit variant 3)
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1>(GemmArgs);   // ... grouped (MoE expert) SwiGLU GEMM
-template __global__ void gemm_bf16_w4p<0, true>(GemmArgs);        // persistent 4 waves x (128 x 128), epilogue inside the next tile
-template __global__ void gemm_bf16_w4p<1, true>(GemmArgs);        // ... the dense SwiGLU GEMM (default)
-template __global__ void gemm_bf16_w4p<0>(GemmArgs);              // variant 13 (epilogue as its own phase)
-template __global__ void gemm_bf16_w4p<1>(GemmArgs);
 template __global__ void gemm_bf16_w4q<0, 8>(GemmArgs);           // persistent 4 waves on 16x16x32 MFMAs: 256 x 256 tiles
 template __global__ void gemm_bf16_w4q<0, 9>(GemmArgs);           // ... 256 x 288 tiles (N = 2304 / 6912: whole rounds over 256 CUs)
 template __global__ void gemm_bf16_w4q<1, 8>(GemmArgs);           // ... SwiGLU
@@ -74,7 +70,6 @@ bool gemm_qkv_fusable(const GemmArgs& a) {
 namespace {
 using lt_gemm::gemm_bf16_tn;
 using lt_gemm::gemm_bf16_pp;
-using lt_gemm::gemm_bf16_w4p;
 using lt_gemm::gemm_bf16_w4q;
 
 // w1/w3 -> 32-row interleaved packed weight (row P: block = P/64; P%64 < 32 -> w1 else w3)
@@ -120,23 +115,6 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
 }
 
 
-template <int EPI, bool OVL>
-int launch_w4p(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    constexpr int SMEM = 4 * 512 * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
-        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4p<EPI, OVL>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_done = true;
-    }
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    const int cus = num_cus();
-    const dim3 grid(tiles < cus ? tiles : cus), block(256);
-    if (ev0) hipExtLaunchKernelGGL((gemm_bf16_w4p<EPI, OVL>), grid, block, SMEM, stream, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL((gemm_bf16_w4p<EPI, OVL>), grid, block, SMEM, stream, a);
-    LT_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 template <int EPI, int NW16>
 int launch_w4q(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BN = 32 * NW16, SMEM = 4 * (256 + BN) * 64;
@@ -156,22 +134,20 @@ int launch_w4q(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
 
 // ---- kernel selection (one place: launch_gemm_bf16 launches what choose() names, lt_gemm_describe prints it) -------------
 enum GemmKernel {
-    GK_TN256, GK_TN288, GK_TN256_VT, GK_TN288_VT, GK_TN256_SWIGLU, GK_PP256, GK_PP256_SWIGLU, GK_W4P, GK_W4P_SWIGLU,
-    GK_W4P13, GK_W4P13_SWIGLU, GK_S128, GK_S128_SWIGLU, GK_S64, GK_W4Q256, GK_W4Q288, GK_W4Q256_SWIGLU, GK_W4Q288_QKV, GK_EXPERIMENTAL, GK_NONE
+    GK_TN256, GK_TN288, GK_TN256_VT, GK_TN288_VT, GK_TN256_SWIGLU, GK_PP256, GK_PP256_SWIGLU,
+    GK_S128, GK_S128_SWIGLU, GK_S64, GK_W4Q256, GK_W4Q288, GK_W4Q256_SWIGLU, GK_W4Q288_QKV, GK_EXPERIMENTAL, GK_NONE
 };
 const char* const kGemmKernelName[] = {
     "gemm_bf16_tn<2,4,4,2,0> (256x256, 8 waves)", "gemm_bf16_tn<4,3,2,3,0> (256x288, 12 waves)",
     "gemm_bf16_tn<2,4,4,2,2> (256x256, V^T epilogue)", "gemm_bf16_tn<4,3,2,3,2> (256x288, V^T epilogue)",
     "gemm_bf16_tn<2,4,4,2,1> (256x256, SwiGLU)", "gemm_bf16_pp<2,4,4,2,0> (256x256 ping-pong)",
-    "gemm_bf16_pp<2,4,4,2,1> (256x256 ping-pong, SwiGLU)", "gemm_bf16_w4p<0,true> (persistent 4x(128x128))",
-    "gemm_bf16_w4p<1,true> (persistent 4x(128x128), SwiGLU)", "gemm_bf16_w4p<0,false>", "gemm_bf16_w4p<1,false>",
+    "gemm_bf16_pp<2,4,4,2,1> (256x256 ping-pong, SwiGLU)",
     "gemm_bf16_pp<2,4,2,1,0,..,1,4> (128x128)", "gemm_bf16_pp<4,2,1,2,1,..,1,4> (128x128, SwiGLU)",
     "gemm_bf16_pp<2,4,1,1,0,..,1,4> (64x128)", "gemm_bf16_w4q<0,8> (persistent 4 waves, 16x16x32 MFMA, 256x256)",
     "gemm_bf16_w4q<0,9> (persistent 4 waves, 16x16x32 MFMA, 256x288)", "gemm_bf16_w4q<1,8> (persistent 4 waves, 16x16x32 MFMA, 256x256, SwiGLU)",
     "gemm_bf16_w4q<3,9> (persistent 4 waves, 16x16x32 MFMA, 256x288, fused QKV: plain Q|K tiles + V^T tiles)", "experimental", "none"};
 
 int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 256x256, 2 = 256x288
-int g_gemm_swiglu_w4p = 1;  // 1: dense SwiGLU GEMMs with >= 2 tile rounds run on the persistent 4-wave kernel (default)
 int g_gemm_stagger = 0;
 int g_gemm_group = 0;
 int g_gemm_w4q = 1;  // 1 (default): large dense GEMMs (>= one tile per CU) run on the persistent 16x16x32 kernel (256 / 288-wide tiles)
@@ -189,9 +165,7 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
         if (!w4p_ok || (epilogue == 1 && variant == 16)) return GK_NONE;
         return epilogue == 1 ? GK_W4Q256_SWIGLU : (variant == 15 ? GK_W4Q256 : GK_W4Q288);
     }
-    if (variant == 13) return w4p_ok ? (epilogue == 1 ? GK_W4P13_SWIGLU : GK_W4P13) : GK_NONE;
-    if (variant == 14) return w4p_ok ? (epilogue == 1 ? GK_W4P_SWIGLU : GK_W4P) : GK_NONE;
-    if (a.trace || variant == 4 || variant == 5 || variant == 6 || (variant >= 9 && variant <= 12)) return GK_EXPERIMENTAL;
+    if (a.trace || variant == 4 || variant == 5 || variant == 6 || (variant >= 9 && variant <= 14) || variant == 17 || variant == 18) return GK_EXPERIMENTAL;
     const int cus = num_cus();
     const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -218,9 +192,6 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     }
     if (epilogue == 1) {
         if (variant == 1) return GK_TN256_SWIGLU;
-        // dense SwiGLU GEMM (N = 2F = 12288 at cfg 2: whole rounds of 256x256 tiles, 6 per CU): the persistent 4-wave kernel
-        // measured 377 us against 393 us (8-wave ping-pong) and 409 us (classic) - profiles/r02/opbench_gemm_call1.log
-        if (variant == 0 && g_gemm_swiglu_w4p && w4p_ok && t256 >= 2LL * cus) return GK_W4P_SWIGLU;
         return GK_PP256_SWIGLU;
     }
     if (variant == 3) return GK_PP256;
@@ -239,7 +210,6 @@ int launch_gemm_experimental(const GemmArgs& a, int epilogue, int variant, hipSt
 #endif
 
 void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
-void lt_set_gemm_swiglu_w4p(int v) { g_gemm_swiglu_w4p = v; }
 void lt_set_gemm_w4q(int v) { g_gemm_w4q = v; }
 int lt_set_gemm_stagger(int v) { g_gemm_stagger = v; return 0; }
 void lt_set_gemm_group(int v) { g_gemm_group = v; }
@@ -270,7 +240,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     }
     LT_REQUIRE(epilogue != 1 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 16, "gemm: unknown variant %d", variant);
+    LT_REQUIRE(variant >= 0 && variant <= 18, "gemm: unknown variant %d", variant);
     const GemmKernel k = choose(a, epilogue, variant);
     switch (k) {
         case GK_TN256: return launch_cfg<2, 4, 4, 2, 0, false>(a, stream, ev0, ev1);
@@ -280,10 +250,6 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         case GK_TN256_SWIGLU: return launch_cfg<2, 4, 4, 2, 1, false>(a, stream, ev0, ev1);
         case GK_PP256: return launch_cfg<2, 4, 4, 2, 0, true>(a, stream, ev0, ev1);
         case GK_PP256_SWIGLU: return launch_cfg<2, 4, 4, 2, 1, true>(a, stream, ev0, ev1);
-        case GK_W4P: return launch_w4p<0, true>(a, stream, ev0, ev1);
-        case GK_W4P_SWIGLU: return launch_w4p<1, true>(a, stream, ev0, ev1);
-        case GK_W4P13: return launch_w4p<0, false>(a, stream, ev0, ev1);
-        case GK_W4P13_SWIGLU: return launch_w4p<1, false>(a, stream, ev0, ev1);
         case GK_S128: return launch_cfg<2, 4, 2, 1, 0, true, 1, 4>(a, stream, ev0, ev1);
         case GK_S128_SWIGLU: return launch_cfg<4, 2, 1, 2, 1, true, 1, 4>(a, stream, ev0, ev1);
         case GK_S64: return launch_cfg<2, 4, 1, 1, 0, true, 1, 4>(a, stream, ev0, ev1);

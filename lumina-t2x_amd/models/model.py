@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..engine import DiTEngine, EngineLimits, ffn_hidden_dim
+from ._base import WeightWatch
 from .components import AffineNorm, Linear, RMSNorm
 
 _normal002 = functools.partial(nn.init.normal_, std=0.02)
@@ -109,7 +110,7 @@ class CapEmbedder(nn.Sequential):
     pass
 
 
-class NextDiT(nn.Module):
+class NextDiT(WeightWatch, nn.Module):
     """Diffusion transformer whose forward passes execute on the MI355X engine.
 
     Constructor signature and defaults follow the reference (model.py:670-685).  Extra, engine-only knobs
@@ -152,11 +153,7 @@ class NextDiT(nn.Module):
         self._engine: Optional[DiTEngine] = None
         self._weights_sig = None
 
-    # ---- engine plumbing ------------------------------------------------------------------------------
-    def _signature(self):
-        # (inference tensors carry no version counter: in-place edits of such parameters are not seen - rebuild the model then)
-        return tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self.parameters())
-
+    # ---- engine plumbing (the weight-change check is WeightWatch._signature, models/_base.py) -------------------------
     def engine(self, x: torch.Tensor, text_len: int) -> DiTEngine:
         """Create / resize the engine for this call's shapes and make sure it holds the current weights."""
         if not (x if isinstance(x, torch.Tensor) else x[0]).is_cuda:

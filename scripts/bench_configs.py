@@ -110,8 +110,12 @@ def main():
             raise SystemExit(f"unknown config {which}")
         if which in ("cfg1", "cfg5") and a.pairs > 1:
             which = f"{which} x{a.pairs} pairs ({ms / a.pairs:.3f} ms/NFE per pair)"
+        # both roofs: MFMA = algorithmic FLOP / 2.5 PFLOP/s; HBM = the bf16 weights every NFE must stream / 8 TB/s
+        wbytes = sum(p.numel() for p in m.parameters()) * 2
         print(f"{which}: {ms:9.3f} ms/NFE  {1e3 / ms:8.2f} NFE/s  {toks / ms * 1e3:12.0f} latent-tokens/s  "
-              f"{fl / ms / 1e9:8.1f} model TFLOP/s", flush=True)
+              f"{fl / ms / 1e9:8.1f} model TFLOP/s = {fl / ms / 1e9 / 2500:.3f} of the MFMA peak; weights {wbytes / 1e9:.2f} GB -> "
+              f"{wbytes / ms / 1e9:.2f} TB/s = {wbytes / ms / 1e9 / 8:.3f} of the HBM peak; ideal {max(fl / 2.5e15, wbytes / 8e12) * 1e3:.3f} ms "
+              f"-> {max(fl / 2.5e15, wbytes / 8e12) * 1e3 / ms:.3f} of the bounding roof", flush=True)
         del m
         torch.cuda.empty_cache()
 

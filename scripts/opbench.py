@@ -77,6 +77,8 @@ def bench_gemm(rounds, variants, zeros=False, shapes=SHAPES_CFG2, cold=0):
                     vi, tail = (int(v[:-2]), int(v[-1])) if isinstance(v, str) and "t" in v else (int(v), 0)
                     pipe = 0
                 assert pipe == 0 and tail == 0, "gemm_pipeline / gemm_pp_tail were round-1 knobs (csrc/experimental, explicit variants)"
+                if vi == 18 and epi == 1:
+                    vi = 17  # 64 x 128 deep-ring tiles have no SwiGLU form either
                 if vi == 16 and epi == 1:
                     vi = 15  # the 288-wide tile has no SwiGLU form (32-column pairing): time the 256-wide one in its place
                 ok(L.lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(out), M, N, K, epi, vi, stream()), "gemm")

@@ -48,7 +48,7 @@ def loop(fn, seconds=1.5):
 
 
 def main():
-    want = sys.argv[1:] or ["idle", "w4q", "w4p", "pingpong", "classic", "vendor", "zeros", "attn", "norm"]
+    want = sys.argv[1:] or ["idle", "w4q", "pingpong", "classic", "vendor", "zeros", "attn", "norm"]  # w4p: EXPERIMENTAL=1 builds only
     L = lib()
     g = torch.Generator(device="cuda").manual_seed(0)
     A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)

@@ -29,6 +29,7 @@ def _experimental_build():
 
 PRODUCT_VARIANTS = [1, 2, 3, 7, 8]
 EXPERIMENTAL_VARIANTS = [4, 5, 6, 9, 10, 11]  # round-1 study kernels (csrc/experimental/, `make EXPERIMENTAL=1`)
+MOVED_R3 = [13, 14, 17, 18]  # round 3: the 32x32x16 persistent kernel and the deep-ring small-M kernel moved there as well
 
 
 def _variant_params():
@@ -36,7 +37,7 @@ def _variant_params():
 
 
 def _skip_unless_built(variant):
-    if variant in EXPERIMENTAL_VARIANTS + [12] and not _experimental_build():
+    if variant in EXPERIMENTAL_VARIANTS + [12] + MOVED_R3 and not _experimental_build():
         pytest.skip(f"gemm variant {variant} lives in csrc/experimental/ (library built without EXPERIMENTAL=1)")
 
 
@@ -81,7 +82,7 @@ def test_gemm_tile_variants(variant, M, N, K):
     assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("variant", _variant_params() + [13, 14, 15, 16])
+@pytest.mark.parametrize("variant", _variant_params() + [pytest.param(13, marks=pytest.mark.experimental), pytest.param(14, marks=pytest.mark.experimental), 15, 16])
 def test_gemm_identity_asymmetric(variant):
     """A = I with an asymmetric W catches a transposed / permuted C-write (guide 5.4 rule 16)."""
     _skip_unless_built(variant)
@@ -107,9 +108,10 @@ def test_gemm_bias_and_edges():
     assert torch.all(big[200:] == 7.0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 7, 14, 15])  # auto, classic loop, 8-wave ping-pong, small tiles, persistent 4 waves (32x32 / 16x16 MFMA)
+@pytest.mark.parametrize("variant", [0, 1, 3, 7, pytest.param(14, marks=pytest.mark.experimental), 15])  # auto, classic loop, 8-wave ping-pong, small tiles, persistent 4 waves (32x32 [experimental] / 16x16 MFMA)
 @pytest.mark.parametrize("M,F_,K", [(256, 128, 64), (300, 1536, 576), (4096, 6144, 2304), (8192, 6144, 2304)])
 def test_gemm_swiglu(M, F_, K, variant):
+    _skip_unless_built(variant)
     if variant in (14, 15) and K < 128:
         pytest.skip("persistent 4-wave kernels: K >= 128")
     g = torch.Generator().manual_seed(F_ + K)
@@ -159,12 +161,14 @@ def test_gemm_experimental_4wave_vgpr_staged(M, N, K, epi):
 
 @pytest.mark.parametrize("M,N,K,epi", [(8192, 12288, 2304, 1), (8300, 6912, 2304, 0), (2100, 1280, 128, 1), (512, 512, 128, 0),
                                        (300, 576, 192, 0), (16384, 2304, 6144, 0), (70000, 520, 256, 0), (256, 131072, 128, 1)])
+@pytest.mark.experimental
 @pytest.mark.parametrize("variant", [13, 14])
 def test_gemm_4wave_persistent(M, N, K, epi, variant):
-    """gemm_bf16_w4p (the engine's SwiGLU kernel = variant 14 with epilogue 1): one workgroup per CU walks its tiles, slab stream and LDS ring carried across tile boundaries; same MFMA
+    """gemm_bf16_w4p (round 2's first persistent 4-wave kernel, superseded by its 16x16x32 form and moved to csrc/experimental/ in round 3): one workgroup per CU walks its tiles, slab stream and LDS ring carried across tile boundaries; same MFMA
     order as every other kernel -> bit-identical to variant 1.  Shapes: 6 tiles per CU, ragged M, one tile per workgroup and
     fewer tiles than CUs, K = 128 (every body is a boundary body), more than two tiles per CU with ragged edges both ways.
     Variant 14 stores a tile from inside the next tile's first body (in-place C = 0 MFMAs behind explicit accumulator copy-outs)."""
+    _skip_unless_built(variant)
     g = torch.Generator().manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g))
     W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
@@ -199,6 +203,85 @@ def test_gemm_4wave_persistent_16x16x32(M, N, K, epi, variant):
     assert float((got.float() != ref.float()).float().mean()) < 0.05  # different summation order flips the odd last bit, no more
     if epi == 0:
         assert rel_l2(got, A.float() @ W.float().t()) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(512, 4608, 1536, 0), (512, 1536, 1536, 0), (512, 8192, 1536, 1), (512, 1536, 4096, 0), (300, 584, 448, 0),
+                                       (130, 136, 1024, 0), (1024, 2048, 448, 1), (2100, 1280, 512, 1), (8192, 2304, 576, 0), (257, 8200, 640, 0)])
+@pytest.mark.experimental
+@pytest.mark.parametrize("variant", [17, 18])
+def test_gemm_small_m_deep_ring(M, N, K, epi, variant):
+    """gemm_bf16_sm (experimental/gemm_small_m.h; round 3's deep-ring candidate for the 512-row problems - passed these tests on the
+    GPU, measured 15-25 % slower than the round-1 small tiles and left out of the product library): persistent 4 waves on 16x16x32 MFMAs,
+    128x128 (17) or 64x128 (18) tiles, LDS-DMA stream 7 / 11 slabs ahead with its own tile iterator.  Shapes: the four GEMMs of
+    cfg 1 (one tile or fewer per CU), ragged M / N on both sides, K of 14 slabs (the ring is deeper than half a tile), several
+    tiles per workgroup (2100 x 1280, 8192 x 2304: the DMA stream crosses tile boundaries with epilogue stores in the queue), a
+    single tile row with 65 tile columns.  Same MFMA (one K = 32 step per slab) as the 256-wide persistent kernel -> equal to it
+    and to the classic kernel up to fp32 summation order; guarded buffer: no store outside [M, N]."""
+    _skip_unless_built(variant)
+    if epi == 1 and variant == 18:
+        pytest.skip("64 x 128 tiles: plain epilogue only")
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    No = N // 2 if epi else N
+    guard = 256
+    buf = torch.full((M * No + 2 * guard,), 7.0, device="cuda", dtype=torch.bfloat16)
+    got = buf[guard:-guard].view(M, No)
+    got.fill_(float("nan"))
+    ok(lib().lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(got), M, N, K, epi, variant, stream()), "gemm")
+    torch.cuda.synchronize()
+    ref = _gemm(A, W, None, epi, variant=1)
+    assert not torch.isnan(got.float()).any(), "unwritten outputs"
+    assert torch.all(buf[:guard] == 7.0) and torch.all(buf[-guard:] == 7.0), "stray store outside C"
+    assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
+    assert float((got.float() != ref.float()).float().mean()) < 0.05
+    if epi == 0:
+        assert rel_l2(got, A.float() @ W.float().t()) < 4e-3
+
+
+@pytest.mark.experimental
+@pytest.mark.parametrize("variant", [17, 18])
+def test_gemm_small_m_identity_asymmetric(variant):
+    _skip_unless_built(variant)
+    K, N = 448, 576
+    A = bf(torch.eye(320, K))
+    W = bf((torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 64.0)
+    out = _gemm(A, W, variant=variant)
+    assert torch.equal(out.float().cpu()[:, :], W.float().t().cpu()[:320])
+
+
+@pytest.mark.experimental
+@pytest.mark.parametrize("variant", [17, 18])
+@pytest.mark.parametrize("epilogue", [0, 1])
+def test_gemm_small_m_grouped_expert_segments(variant, epilogue):
+    """the deep-ring kernel in grouped (MoE) mode: both tile iterators skip padding segments, every tile multiplies with its
+    segment's expert (scalar-cache reads of the tile -> expert table), padding rows stay untouched; K = 1536 as in the 600M MoE"""
+    _skip_unless_built(variant)
+    if epilogue == 1 and variant == 18:
+        pytest.skip("64 x 128 tiles: plain epilogue only")
+    E, K, N = 4, 1536, 640
+    te = [-1, 2, 0, -1, 3, 3, 1, -1]
+    M = 256 * len(te)
+    g = torch.Generator().manual_seed(23 + variant + epilogue)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(E, N, K, generator=g) / math.sqrt(K))
+    tile_expert = torch.tensor(te, dtype=torch.int32, device="cuda")
+    No = N // 2 if epilogue else N
+    out = torch.full((M, No), 3.0, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_gemm_grouped(P(A), P(W), P(tile_expert), N * K, P(out), M, N, K, epilogue, variant, stream()), "grouped")
+    torch.cuda.synchronize()
+    for t, ex in enumerate(te):
+        rows = slice(256 * t, 256 * t + 256)
+        if ex < 0:
+            assert torch.all(out[rows] == 3.0), "padding segment was written"
+            continue
+        y = A[rows].float() @ W[ex].float().t()
+        if epilogue:
+            y = y.view(256, N // 64, 2, 32)
+            ref = r16(r16(F.silu(r16(y[:, :, 0]))) * r16(y[:, :, 1])).reshape(256, No)
+        else:
+            ref = y
+        assert rel_l2(out[rows], ref) < 6e-3, (t, ex, rel_l2(out[rows], ref))
 
 
 @pytest.mark.parametrize("tokens,B,kvh,hd,K,variant", [(4096, 2, 32, 72, 2304, 0), (64, 3, 2, 72, 128, 1), (128, 2, 8, 72, 576, 2),

@@ -89,6 +89,14 @@ def test_imagenet_600m_full_width_vs_oracle():
     f_traj = rel_l2(ref16[-1], ref[-1])
     err = rel_l2(traj[-1], ref[-1])
     assert err < max(5e-2, 1.5 * f_traj), (err, f_traj)
+    # round 3 launch-structure switch of the 512-row regime: q / k / V post-processing in one launch instead of three
+    # (bit-identical: the same per-row arithmetic)
+    from gpu_util import set_option
+    try:
+        set_option("qkv_post_fused", 0)
+        assert torch.equal(model.forward_with_cfg(zb, t.cuda(), y.cuda(), 4.0), got)
+    finally:
+        set_option("qkv_post_fused", 2)
 
 
 def test_flag_engine_matches_reference_golden(golden_dir):

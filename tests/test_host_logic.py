@@ -513,3 +513,27 @@ def test_moe_builder_names_resolve_to_the_reference_files_they_cite():
     assert ka == kd  # GQA changes shapes, not keys
     assert a.layers[0].attention.wk.weight.shape[0] == 8 * 48 and d.layers[0].attention.wk.weight.shape[0] == 32 * 48
     assert any("feed_forward_space" in k for k in c.state_dict()) and not any("feed_forward_space" in k for k in ka)
+
+
+def test_weight_watch_sees_every_kind_of_weight_change():
+    """models/_base.py WeightWatch: the cached flat parameter list must notice in-place edits (version), storage moves (.to), Parameter
+    objects swapped by attribute assignment anywhere in the tree (global registration hook) and load_state_dict(assign=True)"""
+    from lumina_t2x_amd import models
+    with torch.device("meta"):
+        m = models.NextDiT(dim=128, n_layers=2, n_heads=2, cap_feat_dim=64)
+    m = m.to_empty(device="cpu")
+    s0 = m._signature()
+    assert m._signature() == s0 and len(s0) == len(list(m.parameters()))
+    with torch.no_grad():
+        m.layers[1].attention.wq.weight.add_(1)
+    s1 = m._signature()
+    assert s1 != s0
+    m.layers[0].attention.wq.weight = torch.nn.Parameter(torch.zeros_like(m.layers[0].attention.wq.weight))
+    s2 = m._signature()
+    assert s2 != s1 and len(s2) == len(s0)
+    m = m.to(torch.bfloat16)
+    s3 = m._signature()
+    assert s3 != s2
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)
+    assert m._signature() != s3

@@ -252,9 +252,10 @@ def test_fulldepth_oracle_is_pinned_to_the_reference(golden_dir, name):
         f = float((floor - ref).norm() / ref.norm())
         assert 5e-3 < f < (0.35 if "moe" in name else 8e-2), f
         assert torch.equal(ref[0, :3], ref[1, :3])  # CFG on channels [:3]: both rows carry the guided value (model.py:908-913)
-        if "moe" in name:  # routing-pinned yardstick: with the discrete choice held equal the bf16 noise is the dense models'
+        if "moe" in name:  # routing-pinned yardstick: with the discrete top-2 choice held equal to the fp32 run's, the bf16
+            # choreography is 0.11 from fp32 instead of 0.20 (what remains is continuous: gate weights from bf16 router logits)
             ff = torch.from_numpy(g[f"floor_forced_{tag}"])
-            assert 5e-3 < float((ff - ref).norm() / ref.norm()) < 8e-2
+            assert 5e-3 < float((ff - ref).norm() / ref.norm()) < 0.7 * f
             route = g[f"route_{tag}"]
             assert route.shape[:2] == (16, 2) and route.shape[3] == 2 and route.min() >= 0 and route.max() < 4
             assert (route[..., 0] < route[..., 1]).all() and 0.5 < float(g[f"floor_agree_{tag}"]) < 1.0
