@@ -324,6 +324,68 @@ def test_sample_driver_end_to_end_with_injected_encoder(golden_dir, tmp_path):
     assert torch.equal(decoded[0], want / 0.13025)
 
 
+def test_img2img_driver_end_to_end_with_injected_encoders(golden_dir, tmp_path):
+    """lumina_t2x_amd.sample_img2img.run (reference lumina_next_t2i_mini/sample_img2img.py:146-260): image -> VAE latent -> noise mix
+    at the cut grid's first time -> ODE(strength) on the engine -> files.  Third-party stages injected; the latent must equal the
+    same mix + ODE.sample done by hand, and the cut grid must be the reference's (mini_ode.npz)."""
+    import argparse
+
+    from safetensors.torch import save_file
+
+    from lumina_t2x_amd import sample_img2img as S
+    from lumina_t2x_amd.transport.mini import ODE
+
+    g, cfg = _golden(golden_dir, "nextdit_tiny")
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ck / "consolidated_ema.00-of-01.safetensors"))
+    torch.save(argparse.Namespace(model="NextDiT_tiny_test", qk_norm=cfg.qk_norm, image_size=256, vae="sdxl"), str(ck / "model_args.pth"))
+    models.__dict__["NextDiT_tiny_test"] = lambda **kw: models.NextDiT(**{**cfg.ctor_kwargs(), **kw})
+    (tmp_path / "prompts.txt").write_text("a red cube\n")
+    gen = torch.Generator().manual_seed(5)
+    table = {c: torch.randn(16, cfg.cap_feat_dim, generator=gen) for c in ("a red cube", "")}
+    image = torch.rand(3, 128, 128, generator=gen).mul(2).sub(1).cuda()
+
+    def encode(caps):
+        feats = torch.stack([table[c] for c in caps]).to("cuda", torch.bfloat16)
+        mask = torch.ones(len(caps), 16, dtype=torch.int64, device="cuda")
+        mask[-1, 8:] = 0
+        return feats, mask
+
+    def vae_encode(img):  # a stand-in "VAE": 8 x 8 average pooling to 4 channels
+        return torch.nn.functional.avg_pool2d(torch.cat([img, img[:, :1]], dim=1), 8)
+
+    decoded = []
+
+    def decode(lat):
+        decoded.append(lat.clone())
+        return torch.sigmoid(lat[:, :3].float())
+
+    out = tmp_path / "out"
+    args = S.build_parser().parse_args(["--ckpt", str(ck), "--image", "unused.png", "--caption_path", str(tmp_path / "prompts.txt"),
+                                        "--resolution", "256:128x128", "--num_sampling_steps", "9", "--solver", "midpoint", "--strength", "0.6",
+                                        "--time_shifting_factor", "4", "--seed", "13", "--image_save_path", str(out)])
+    try:
+        info = S.run(args, encode_fn=encode, cap_feat_dim=cfg.cap_feat_dim, vae_encode_fn=vae_encode, decode_fn=decode, image=image)
+    finally:
+        del models.__dict__["NextDiT_tiny_test"]
+    assert len(info) == 1 and os.path.exists(info[0]["image_url"]) and info[0]["solver"] == "midpoint"
+    assert json.load(open(out / "data.json")) == info
+    ode = ODE(9, "midpoint", 4.0, strength=0.6)
+    assert len(ode.t) == 9 - int(9 * (1 - 0.6))
+    model = _model(cfg, int(g["seed_w"]))
+    torch.random.manual_seed(13)
+    x1 = vae_encode(image[None]).mul(0.13025)
+    z = torch.randn([1, 4, 16, 16], device="cuda").to(torch.bfloat16)
+    z = (z * (1 - float(ode.t[0])) + x1.to(torch.bfloat16) * float(ode.t[0])).repeat(2, 1, 1, 1)
+    feats, mask = encode(["a red cube", ""])
+    want = ode.sample(z, model.forward_with_cfg, cap_feats=feats, cap_mask=mask, cfg_scale=4.0, proportional_attn=True, base_seqlen=256,
+                      scale_factor=1.0, scale_watershed=1.0)[-1][:1]
+    assert model._engine.last_nfe() == 2 * (len(ode.t) - 1)
+    assert torch.equal(decoded[0], want / 0.13025)
+
+
 def test_lumina_next_cli_infer_with_injected_encoder(golden_dir, tmp_path):
     """lumina_t2x_amd.cli.infer (reference utils/cli.py:161-333 flow): yaml settings -> sampler + model kwargs -> one CFG solve
     on the engine -> decoded file named after the caption.  The latent handed to the (injected) VAE must equal a direct Sampler
