@@ -987,6 +987,10 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
 #endif
     if (g_attn_variant >= 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && (!a.tk || a.Tkpad <= 256))
         return launch_attention_v4(a, stream);
+    // ... and its head_dim 96 form (attention_v4_96.hip): whole tiles, the text phase's mask on the VALU
+    if (g_attn_variant >= 4 && a.hd == 96 && a.bias == nullptr && !a.accumulate && !a.nk_batch && !a.trace && a.Nk % 64 == 0 && a.Nk == a.Nkpad &&
+        (!a.tk || (a.Tkpad <= 256 && a.Tkpad % 64 == 0)))
+        return launch_attention_v4_hd96(a, stream);
     if (g_attn_variant >= 3 && (a.hd == 72 || a.hd == 96) && a.bias == nullptr && !a.accumulate) {
         constexpr int SMEM72 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16, SMEM96 = 4 * (96 * 128) + 4 * (64 * 96 * 2) + 16;
         static bool attr_done = false;

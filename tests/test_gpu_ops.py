@@ -679,6 +679,40 @@ def test_attention_v4_is_bit_identical_to_v3(B, H, Hkv, N, outliers):
     assert rel_l2(outs[2], ref) < 6e-3
 
 
+@pytest.mark.parametrize("B,H,Hkv,N,outliers", [(2, 32, 32, 4160, False), (1, 8, 2, 1024, True), (1, 4, 4, 64, False), (1, 2, 2, 100 * 64, True),
+                                                 # tile counts 2, 3, 5, 6, 7 (mod 4 remainders of the ring-depth unrolled loop), ragged last q-block
+                                                 (1, 4, 4, 128, False), (1, 4, 2, 192, True), (1, 4, 4, 320, True), (2, 2, 2, 384, False), (1, 2, 1, 448, True)])
+def test_attention_v4_hd96_against_the_ping_pong_kernel_and_fp32(B, H, Hkv, N, outliers):
+    """attn_fwd_kernel_v4h96 (round 3: the one-wave-per-SIMD structure at head_dim 96 - running maximum through a seventh, constant-K
+    k-step, row sum by v_dot2 on the packed P, XOR-swizzled 192-byte K rows) against attn_fwd_kernel_v3<96> and the exact softmax.
+    The two kernels round differently on purpose (v3<96>: fp32 maximum and fp32 row sum on the VALU; v4: bf16-pair folded maximum and
+    the sum of the bf16-rounded P the PV MFMA multiplies - as both hd-72 kernels do), so they agree to a few bf16 ulps of the
+    output, not bit for bit; max moves late in the sequence, GQA and every remainder of the unrolled tile loop included."""
+    hd = 96
+    g = torch.Generator().manual_seed(N + H + 96)
+    q = bf(torch.randn(B, H, N, hd, generator=g))
+    k = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    v = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    if outliers:
+        rep = H // Hkv
+        k[:, :, N // 2 + 3] = q[:, ::rep, 7] * 4.0
+        k[:, :, 5] = q[:, ::rep, N - 9] * 2.0
+        k[:, :, N - 64:] += q[:, ::rep, 40:41] * 1.5   # last tile above everything before it for row 40
+        k[:, :, :64] -= q[:, ::rep, 50:51] * 3.0
+    scale = math.sqrt(math.log(N, 64) / hd) if N > 64 else 1 / math.sqrt(hd)
+    outs = {}
+    for variant in (3, 4):
+        set_option("attention_variant", variant)
+        for fold in (True, False):
+            outs[variant, fold] = _run_attn(q, k, v, scale, fold_scale=fold).clone()
+    ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), scale)
+    for key, o in outs.items():
+        assert not torch.isnan(o.float()).any(), key
+        assert rel_l2(o, ref) < 6e-3, (key, rel_l2(o, ref))
+    assert rel_l2(outs[4, True], outs[3, True]) < 3e-3, rel_l2(outs[4, True], outs[3, True])
+    assert max_abs(outs[4, True], ref) < 0.06 * float(ref.abs().max()) + 0.02
+
+
 @pytest.mark.parametrize("B,H,Hkv,N,T,valid1", [(2, 8, 8, 320, 128, 8), (2, 8, 2, 192, 77, 30), (1, 4, 4, 4096, 256, 256), (2, 4, 2, 512, 40, 33),
                                                   (2, 4, 4, 64, 200, 130)])
 def test_attention_v4_fused_text_is_bit_identical_to_v3(B, H, Hkv, N, T, valid1):
