@@ -58,7 +58,7 @@ for step in "$@"; do
       done; done ;;
     configs) timeout 1200 python scripts/bench_configs.py $arg > $OUT/bench_configs.log 2>&1; echo "exit $?"; tail -12 $OUT/bench_configs.log ;;
     opbench) timeout 1200 python scripts/opbench.py $arg > $OUT/opbench_$(echo $arg | tr ' /' '__' | cut -c1-60).log 2>&1; echo "exit $?"; tail -30 $OUT/opbench_*.log | cut -c1-220 ;;
-    prof) PROF_OUT=$OUT bash scripts/gpu_prof.sh 2>&1 | tail -60 ;;
+    prof) PROF_OUT=$OUT/prof bash scripts/gpu_prof.sh 2>&1 | tail -60 ;;
     power) timeout 900 python scripts/power_probe.py $arg > $OUT/power_probe.log 2>&1; echo "exit $?"; cat $OUT/power_probe.log | cut -c1-220 ;;
     sh) bash -c "$arg" > $OUT/sh_$(date +%s).log 2>&1; echo "exit $?"; tail -30 $OUT/sh_*.log | cut -c1-220 ;;
     *) echo "unknown step $step" ;;
