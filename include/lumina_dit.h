@@ -89,18 +89,21 @@ typedef struct lt_step_args {
 } lt_step_args;
 
 const char* lt_last_error(void);
-/* library / build identification: "lumina_dit gfx950 r2", with "+experimental" appended by EXPERIMENTAL=1 builds */
+/* library / build identification: "lumina_dit gfx950 r3", with "+experimental" appended by EXPERIMENTAL=1 builds */
 const char* lt_version(void);
 
 /* process-wide kernel selection knobs (A/B measurements, tests; defaults are the measured-best settings):
  *   "qkv_fused_gemm" 1 (default): Q | K | V projection in one launch where the shapes are whole 256 x 288 tiles
- *   "attention_variant" 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (hd 72 / 96) | 4 one wave per SIMD x 64 query rows,
- *                       asm-owned AGPRs (hd 72 with whole 64-key tiles; variant 3 otherwise) | 5 the same with PV on 16x16x32 MFMAs
+ *   "attention_variant" 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (hd 72 / 96) | 4 (default) one wave per SIMD x 64 query rows,
+ *                       asm-owned AGPRs (hd 72 and, since round 3, hd 96, with whole 64-key tiles; variant 3 otherwise) | 5 the hd-72
+ *                       kernel with PV on 16x16x32 MFMAs (EXPERIMENTAL=1 builds)
  *   "gemm_variant"      0 auto tile shape (default) | 1 256x256 | 2 256x288
- *   "gemm_swiglu_w4p"   1 (default): dense multi-round SwiGLU GEMMs run on the persistent 4-wave kernel | 0: 8-wave ping-pong
- *   "gemm_stagger"      0 (default) .. 64: 4-wave GEMM kernels (explicit variants 10, 13, 14) spread the start of the workgroups
- *                       of an XCD over eight phases, n * ~1024 cycles apart (experiment knob)
- *   "qkv_post_fused"    0 separate launches (default) | 1 one launch for q / k post-processing + V transpose
+ *   "gemm_w4q"          1 (default): large dense GEMMs run on the persistent 4-wave 16x16x32 kernel | 0: classic / ping-pong tiles
+ *   "gemm_stagger"      0 (default) .. 64: 4-wave GEMM kernels (explicit variants 10, 13, 14: EXPERIMENTAL=1 builds) spread the start
+ *                       of the workgroups of an XCD over eight phases, n * ~1024 cycles apart (experiment knob)
+ *   "qkv_post_fused"    2 (default): one launch for q / k post-processing + V transpose below 2048 rows (launch-bound regime), three
+ *                       launches above | 1 always one launch | 0 always separate launches
+ *   "qk_post_pair"      1 (default): q and k post-processing share one persistent launch (>= 2048 rows) | 0: two launches
  *   "qkv_vt_epilogue"   1 (default): the V projection is its own GEMM whose epilogue writes the attention kernels' transposed,
  *                       key-permuted V image directly (no V transpose pass; needs tokens per sample % 64 == 0, large M) | 0: off
  *   "norm_specialize"   1 (default): gated_residual_norm runs instantiations with its three mode switches fixed at compile

@@ -275,6 +275,50 @@ def test_compositional_regional_attention_engine_vs_reference_golden(golden_dir,
     assert torch.equal(a, b)
 
 
+def test_regional_caption_buffer_growth_drops_cached_graphs(golden_dir):
+    """lt_prepare_prompt_regional re-allocates its per-caption output buffer when Y grows; graphs captured with the
+    old pointer must not be replayed afterwards.  4 captions (captured + replayed) -> 5 captions (buffer grows) -> 4 captions again:
+    every result equals the eager (graph = 0) one bit for bit."""
+    from gpu_util import set_option
+    g4, cfg = _golden(golden_dir, "compositional_tiny_1x3")
+    g5, _ = _golden(golden_dir, "compositional_tiny")
+    model = _build(models.compositional.NextDiT, cfg, int(g4["seed_w"]))
+
+    def call(g):
+        z = torch.from_numpy(g["z"]).to("cuda", torch.bfloat16)
+        t = torch.from_numpy(g["t"]).cuda()
+        cap, mask = torch.from_numpy(g["cap"]).to("cuda", torch.bfloat16), torch.from_numpy(g["mask"]).cuda()
+        gcap, gmask = torch.from_numpy(g["gcap"]).to("cuda", torch.bfloat16), torch.from_numpy(g["gmask"]).cuda()
+        hs, ws = (int(v) for v in g["splits"])
+        return model.forward_with_cfg(z, t, cap, mask, 4.0, scale_factor=1.0, scale_watershed=1.0, base_seqlen=16, proportional_attn=True,
+                                      global_cap_feats=gcap, global_cap_mask=gmask, h_split_num=hs, w_split_num=ws)
+
+    assert g4["cap"].shape[0] == 4 and g5["cap"].shape[0] == 5
+    from lumina_t2x_amd.engine import EngineLimits
+
+    def fresh_engine():  # capacity for 8 rows from the start: the 5-caption call then grows the caption buffer of the SAME engine
+        model._engine = None
+        model.engine_limits = EngineLimits(8, 256, 64)
+
+    def runs():
+        return [call(g4) for _ in range(3)] + [call(g5) for _ in range(3)] + [call(g4) for _ in range(3)] + [call(g5) for _ in range(2)]
+
+    try:
+        set_option("graph", 0)
+        fresh_engine()
+        eager = runs()
+        set_option("graph", 1)
+        fresh_engine()
+        graphed = runs()
+        replays = model._engine.graph_replays()
+        assert model._engine.limits.max_batch == 8  # one engine throughout: the growth happened inside it
+    finally:
+        set_option("graph", 1)
+    assert replays >= 4, replays
+    for i, (a, b) in enumerate(zip(graphed, eager)):
+        assert torch.equal(a, b), i
+
+
 @pytest.mark.parametrize("mode", ["ODE", "SDE"])
 def test_imagenet_sample_driver_with_injected_decoder(golden_dir, tmp_path, mode):
     """lumina_t2x_amd.sample_imagenet.run (reference Next-DiT-ImageNet/sample.py:80-203): checkpoint directory -> model -> CFG
