@@ -227,6 +227,12 @@ int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32
  * marks a padding segment whose output rows are left untouched.  M % 256 == 0; tile_expert_dev: int32 [M / 256]. */
 int lt_op_gemm_grouped(const void* A_dev, const void* W_dev, const void* tile_expert_dev, int64_t w_expert_stride,
                        void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* stream);
+/* the same with gather-on-load (round 3: how the engine runs the experts' W1 | W3 GEMM - no gather pass, no expert-sorted copy of
+ * the FFN input): row m of the problem is row row_map_dev[m] (int32 [M]) of A_dev [a_rows, K]; -1 = a padding row that reads as
+ * zero.  Ping-pong tile kernels only (variant 0 picks one for grouped problems; explicit 3 / 7 / 8). */
+int lt_op_gemm_grouped_gather(const void* A_dev, int32_t a_rows, const void* row_map_dev, const void* W_dev, const void* tile_expert_dev,
+                              int64_t w_expert_stride, void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
+                              void* stream);
 /* diagnostics (EXPERIMENTAL=1 builds only): a GEMM built with s_memtime stamps (variant 3 | 4 ping-pong, 5 rendezvous, 10 four-wave LDS-DMA, 12 four-wave
  * VGPR-staged; plain epilogue); trace_dev (>= 64 * waves * 8 uint64, zeroed by the caller) receives, for every 64th workgroup
  * and each of its waves, 8 x uint64: six per-wave tick totals - variant 3 / 4 / 5: {fragment-read issue, vmcnt wait, lgkmcnt

@@ -133,8 +133,8 @@ struct lt_engine {
     // MoE workspace: expert-sorted rows (moe.hip)
     int E = 0, moe_tiles = 0;
     int moe_mode = 0;  // 0: time + space MoE per block (models2.py), 1: time-routed MoE only (models.py), 2: token-routed only (models1.py)
-    u16 *moe_xs = nullptr, *moe_us = nullptr, *moe_ys = nullptr, *moe_logits = nullptr, *moe_wts = nullptr;
-    int *moe_sel = nullptr, *moe_pos = nullptr, *moe_tile_expert = nullptr;
+    u16 *moe_us = nullptr, *moe_ys = nullptr, *moe_logits = nullptr, *moe_wts = nullptr;
+    int *moe_sel = nullptr, *moe_pos = nullptr, *moe_tile_expert = nullptr, *moe_src = nullptr;
     // parity hooks (lt_moe_routing_*): [L][2 branches][max rows][2] expert ids, recorded from / forced onto moe_route_kernel
     int *moe_rec = nullptr, *moe_force = nullptr;
     int moe_rec_on = 0, moe_force_rows = 0, moe_rec_rows = 0;
@@ -383,7 +383,7 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
     // expert GEMM at 512 rows in an engine sized for 8192)
     const int tiles = (int)((2 * (size_t)M + (size_t)e->E * 255 + 255) / 256);
     m.sel = e->moe_sel; m.wts = e->moe_wts; m.pos = e->moe_pos; m.tile_expert = e->moe_tile_expert; m.max_tiles = tiles;
-    m.xs = e->moe_xs; m.ys = e->moe_ys; m.out = e->o;
+    m.src = e->moe_src; m.ys = e->moe_ys; m.out = e->o;
     m.gate_w = nullptr; m.sample_logits = nullptr; m.forced = nullptr;
     {
         ProfScope ps(e, 2, 0, s);
@@ -404,19 +404,19 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
             e->moe_rec_rows = M;
         }
         if (launch_moe_plan(m, s)) return 1;
-        if (launch_moe_gather(m, s)) return 1;
     }
     const int P = tiles * 256;
     GemmArgs g;
     g.bias = nullptr; g.bias_dtype = -1; g.tile_expert = e->moe_tile_expert;
     {   // grouped SwiGLU GEMM: each 256-row tile multiplies with its expert's packed w1|w3
-        g.A = e->moe_xs; g.W = branch == 0 ? w.w13_t : w.w13_s; g.C = e->moe_us; g.M = P; g.N = 2 * F; g.K = d;
+        // (A = the un-sorted FFN input: the GEMM gathers its rows through the plan's inverse map, no expert-sorted copy)
+        g.A = e->h; g.a_row_map = e->moe_src; g.a_map_rows = M; g.W = branch == 0 ? w.w13_t : w.w13_s; g.C = e->moe_us; g.M = P; g.N = 2 * F; g.K = d;
         g.lda = d; g.ldw = d; g.ldc = F; g.w_expert_stride = (long long)2 * F * d;
         ProfScope ps(e, 0, 2.0 * (2.0 * M) * (2.0 * F) * d, s, true);  // algorithmic: every token visits two experts
         if (launch_gemm_bf16(g, 1, 0, s, ps.ev0(), ps.ev1())) return 1;
     }
     {
-        g.A = e->moe_us; g.W = branch == 0 ? w.w2_t : w.w2_s; g.C = e->moe_ys; g.M = P; g.N = d; g.K = F;
+        g.A = e->moe_us; g.a_row_map = nullptr; g.a_map_rows = 0; g.W = branch == 0 ? w.w2_t : w.w2_s; g.C = e->moe_ys; g.M = P; g.N = d; g.K = F;
         g.lda = F; g.ldw = F; g.ldc = d; g.w_expert_stride = (long long)d * F;
         ProfScope ps(e, 0, 2.0 * (2.0 * M) * (double)d * F, s, true);
         if (launch_gemm_bf16(g, 0, 0, s, ps.ev0(), ps.ev1())) return 1;
@@ -891,7 +891,7 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     else {  // expert-sorted buffers: every row appears twice, each expert segment starts on a 256-row tile
         e->moe_tiles = (int)((2 * M + (size_t)e->E * 255 + 255) / 256);
         const size_t P = (size_t)e->moe_tiles * 256;
-        A16(e->moe_xs, P * d); A16(e->moe_us, P * F); A16(e->moe_ys, P * d); A16(e->moe_logits, Bm * e->E); A16(e->moe_wts, 2 * M);
+        A16(e->moe_us, P * F); A16(e->moe_ys, P * d); A16(e->moe_logits, Bm * e->E); A16(e->moe_wts, 2 * M);
         void* q;
         if (dev_alloc(e, &q, 2 * M * sizeof(int))) return fail();
         e->moe_sel = (int*)q;
@@ -899,6 +899,8 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         e->moe_pos = (int*)q;
         if (dev_alloc(e, &q, (size_t)e->moe_tiles * sizeof(int))) return fail();
         e->moe_tile_expert = (int*)q;
+        if (dev_alloc(e, &q, P * sizeof(int))) return fail();
+        e->moe_src = (int*)q;
     }
     A16(e->patches, M * e->kpad); A16(e->frows, M * e->nfinal); A16(e->mod, Bm * e->ld_mod);
     A16(e->tfeat, Bm * 256); A16(e->t1, Bm * A); A16(e->temb, Bm * A);
@@ -1395,6 +1397,19 @@ extern "C" int lt_op_gemm_grouped(const void* A, const void* W, const void* tile
     g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
     g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = -1;
     g.tile_expert = (const int*)tile_expert; g.w_expert_stride = w_expert_stride;
+    return launch_gemm_bf16(g, epilogue, variant, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_gemm_grouped_gather(const void* A, int32_t a_rows, const void* row_map, const void* W, const void* tile_expert,
+                                         int64_t w_expert_stride, void* C, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
+                                         void* stream) {
+    LT_REQUIRE(A && W && C && tile_expert && row_map, "lt_op_gemm_grouped_gather: null pointer");
+    LT_REQUIRE(M > 0 && M % 256 == 0 && a_rows > 0, "lt_op_gemm_grouped_gather: M=%d must be a positive multiple of 256, a_rows > 0", M);
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = -1;
+    g.tile_expert = (const int*)tile_expert; g.w_expert_stride = w_expert_stride;
+    g.a_row_map = (const int*)row_map; g.a_map_rows = a_rows;
     return launch_gemm_bf16(g, epilogue, variant, (hipStream_t)stream);
 }
 

@@ -242,6 +242,11 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
     LT_REQUIRE(epilogue != 1 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
     LT_REQUIRE(variant >= 0 && variant <= 18, "gemm: unknown variant %d", variant);
     const GemmKernel k = choose(a, epilogue, variant);
+    if (a.a_row_map) {  // gather-on-load lives in the ping-pong kernels' staging (the grouped SwiGLU GEMM of the MoE layers)
+        LT_REQUIRE(k == GK_PP256_SWIGLU || k == GK_PP256 || k == GK_S128 || k == GK_S128_SWIGLU || k == GK_S64,
+                   "gemm: a_row_map is supported by the gemm_bf16_pp kernels only (this problem runs %s)", kGemmKernelName[k]);
+        LT_REQUIRE(a.a_map_rows > 0 && (long long)a.a_map_rows * a.lda * 2 < 0x40000000LL, "gemm: a_row_map needs 0 < a_map_rows * lda * 2 < 2^30");
+    }
     switch (k) {
         case GK_TN256: return launch_cfg<2, 4, 4, 2, 0, false>(a, stream, ev0, ev1);
         case GK_TN288: return launch_cfg<4, 3, 2, 3, 0, false>(a, stream, ev0, ev1);

@@ -359,8 +359,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         const bool isA = q < PA;
         const int r0 = RPP * (isA ? q : q - PA) + lane / LPR;
         const int key = KS == 2 ? (r0 >> 2) & 3 : (r0 >> 1) & 7;
-        rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(isA ? a_base : w_base), 0, isA ? a_bytes : w_bytes, 0x00020000);
-        voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + (((lane % LPR) ^ key) << 4);
+        if (isA && p.a_row_map) {  // gather-on-load: this lane's LDS row r0 of the tile comes from row a_row_map[m0 + r0] of A (or is zero)
+            const int src = m0 + r0 < p.M ? p.a_row_map[m0 + r0] : -1;
+            rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_map_rows * p.lda * 2, 0x00020000);
+            voff[i] = (src >= 0 ? src * p.lda * 2 : 0x40000000) + (((lane % LPR) ^ key) << 4);
+        } else {
+            rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(isA ? a_base : w_base), 0, isA ? a_bytes : w_bytes, 0x00020000);
+            voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + (((lane % LPR) ^ key) << 4);
+        }
         ldsoff[i] = q * 1024;
     }
     auto stage = [&](int slab) {

@@ -17,6 +17,10 @@ struct GemmArgs {
     // tile_expert[tm] < 0 -> the tile is padding and the workgroup exits.  Device array of ceil(M / 256) ints.
     const int* tile_expert = nullptr;
     long long w_expert_stride = 0;
+    // gather-on-load (grouped SwiGLU GEMM of the MoE layers, gemm_bf16_pp kernels only): row m of the problem is row a_row_map[m] of A
+    // (-1: a padding row, reads as zero); A then has a_map_rows rows.  Replaces a gather pass + an expert-sorted copy of the FFN input.
+    const int* a_row_map = nullptr;
+    int a_map_rows = 0;
     // epilogue 2 (V^T): C is the attention kernels' transposed, key-permuted V image [M / vt_tokens][N / vt_hd][vt_hd][vt_npad]
     // (AttnArgs::vt) instead of a row-major matrix: the V projection lands in the layout the PV MFMA reads, no transpose pass
     int vt_tokens = 0, vt_hd = 0, vt_npad = 0;
@@ -149,15 +153,14 @@ struct MoeArgs {
     int* sel;                  // [rows, 2] selected experts, ascending expert id (= the reference's accumulation order)
     u16* wts;                  // [rows, 2] bf16 softmax weights aligned with sel
     int* pos;                  // [rows, 2] row of each (token, expert) pair in the expert-sorted buffers
+    int* src;                  // [max_tiles * 256] inverse map: token row of each sorted position, -1 for padding (GemmArgs::a_row_map)
     int* tile_expert;          // [max_tiles] expert of each 256-row tile of the sorted buffers, -1 = padding
     int max_tiles;
-    u16* xs;                   // [max_tiles * 256, d] expert-sorted copy of x
     const u16* ys;             // [max_tiles * 256, d] expert outputs in the same order
     u16* out;                  // [rows, d] combined result
 };
 int launch_moe_route(const MoeArgs& a, hipStream_t stream);    // logits -> top-2, weights
-int launch_moe_plan(const MoeArgs& a, hipStream_t stream);     // counts -> tile-aligned segments, pos, tile_expert
-int launch_moe_gather(const MoeArgs& a, hipStream_t stream);   // xs[pos] = x[row]
+int launch_moe_plan(const MoeArgs& a, hipStream_t stream);     // counts -> tile-aligned segments, pos, src, tile_expert
 int launch_moe_combine(const MoeArgs& a, hipStream_t stream);  // out[row] = sum over its experts, ascending, bf16 steps
 
 // ---- small kernels (misc.hip) ------------------------------------------------------------------

@@ -8,7 +8,7 @@
 //   plan    : per-expert counts -> segments aligned to the GEMM's 256-row tiles, a row position for every
 //             (token, expert) pair, and the tile -> expert table the grouped GEMM reads (single workgroup scan, no atomics
 //             -> bit-reproducible)
-//   gather  : xs[pos] = x[token]
+//   (gather : round 3 - folded into the grouped SwiGLU GEMM, which reads its A rows through the plan's inverse map src[])
 //   combine : out[token] = bf16(bf16(0 + bf16(w_a y_a)) + bf16(w_b y_b)), experts in ascending id = the order of the
 //             reference's `for i, expert in enumerate(self.experts)` loop (:472-476)
 // TimeMoeLayer routes on the timestep embedding, so all tokens of a sample share the two experts; SpaceMoeLayer
@@ -74,30 +74,41 @@ __global__ __launch_bounds__(256) void moe_route_kernel(MoeArgs p) {
     }
 }
 
-// single workgroup: entries (row, k) in row-major order keep their order inside each expert segment
+// single workgroup: entries (row, k) in row-major order keep their order inside each expert segment (bit-reproducible, no atomics).
+// Round 3: the per-expert exclusive scan over the 1024 threads' counts is a wave-level shuffle scan on PACKED counters (four 16-bit
+// fields per 64-bit word: a thread holds <= 32 entries, a wave <= 2048 per expert) plus a 16-step scan over the wave totals; the
+// round-1 form let E threads walk all 1024 counters serially through LDS and took 12.4 us per MoE layer - 0.4 ms per NFE at cfg 5,
+// as much as the attention of that model (profiles/r03/rocprofv3_kernel_stats_cfg5_r03.csv).  Also writes the inverse map
+// src[sorted position] = token row (-1 in the padding of a segment) that the grouped SwiGLU GEMM gathers its A rows through.
 __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
-    __shared__ int cnt[1024][MAX_E + 1];  // +1: avoid the 8-way bank alias of an 8-int row stride
+    __shared__ int wtot[16][MAX_E];   // per wave and expert: entries in the wave, then the exclusive prefix over waves
     __shared__ int seg_off[MAX_E], seg_cnt[MAX_E];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.rows * 2;
     const int per = (n + 1023) / 1024;
     const int lo = tid * per, hi = min(n, lo + per);
-    int mine[MAX_E];
-#pragma unroll
-    for (int e = 0; e < MAX_E; ++e) mine[e] = 0;
+    unsigned long long c0 = 0, c1 = 0;  // this thread's counts: experts 0..3 / 4..7, 16 bits each
     for (int i = lo; i < hi; ++i) {
         const int ex = p.sel[i];
-#pragma unroll
-        for (int e = 0; e < MAX_E; ++e) mine[e] += (ex == e);
+        if (ex < 4) c0 += 1ull << (16 * ex);
+        else c1 += 1ull << (16 * (ex - 4));
     }
+    unsigned long long s0 = c0, s1 = c1;  // inclusive scan inside the wave
 #pragma unroll
-    for (int e = 0; e < MAX_E; ++e) cnt[tid][e] = mine[e];
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long u0 = __shfl_up(s0, d, 64), u1 = __shfl_up(s1, d, 64);
+        if (lane >= d) { s0 += u0; s1 += u1; }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int e = 0; e < MAX_E; ++e) wtot[wave][e] = (int)(((e < 4 ? s0 : s1) >> (16 * (e & 3))) & 0xffff);
+    }
     __syncthreads();
-    if (tid < p.E) {  // exclusive scan of this expert's per-thread counts (1024 serial adds: ~1 us, once per MoE layer)
+    if (tid < p.E) {  // exclusive scan of this expert's 16 wave totals
         int run = 0;
-        for (int t = 0; t < 1024; ++t) {
-            const int c = cnt[t][tid];
-            cnt[t][tid] = run;
+        for (int w = 0; w < 16; ++w) {
+            const int c = wtot[w][tid];
+            wtot[w][tid] = run;
             run += c;
         }
         seg_cnt[tid] = run;
@@ -113,7 +124,10 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
     __syncthreads();
     int next[MAX_E];
 #pragma unroll
-    for (int e = 0; e < MAX_E; ++e) next[e] = e < p.E ? seg_off[e] + cnt[tid][e] : 0;
+    for (int e = 0; e < MAX_E; ++e) {
+        const int incl = (int)(((e < 4 ? s0 : s1) >> (16 * (e & 3))) & 0xffff), own = (int)(((e < 4 ? c0 : c1) >> (16 * (e & 3))) & 0xffff);
+        next[e] = e < p.E ? seg_off[e] + wtot[wave][e] + incl - own : 0;
+    }
     for (int i = lo; i < hi; ++i) {
         const int ex = p.sel[i];
         int q = 0;
@@ -122,6 +136,7 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
             if (ex == e) { q = next[e]; next[e] = q + 1; }
         }
         p.pos[i] = q;
+        p.src[q] = i >> 1;
     }
     for (int t = tid; t < p.max_tiles; t += 1024) {
         int ex = -1;
@@ -131,20 +146,11 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
         }
         p.tile_expert[t] = ex;
     }
-}
-
-__global__ __launch_bounds__(256) void moe_gather_kernel(MoeArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
-    const int nch = p.d >> 3;
-    const u16* src = p.x + (size_t)row * p.d;
-    u16* d0 = p.xs + (size_t)p.pos[2 * row] * p.d;
-    u16* d1 = p.xs + (size_t)p.pos[2 * row + 1] * p.d;
-    for (int c = lane; c < nch; c += 64) {
-        const bf8_t v = *(const bf8_t*)(src + c * 8);
-        *(bf8_t*)(d0 + c * 8) = v;
-        *(bf8_t*)(d1 + c * 8) = v;
+    // padding positions of the map: behind the last entry of every segment up to its tile boundary, and every tile no expert owns
+    for (int q = tid; q < p.max_tiles * TILE; q += 1024) {
+        bool real = false;
+        for (int e = 0; e < p.E; ++e) real |= q >= seg_off[e] && q < seg_off[e] + seg_cnt[e];
+        if (!real) p.src[q] = -1;
     }
 }
 
@@ -186,14 +192,8 @@ int launch_moe_route(const MoeArgs& a, hipStream_t stream) {
 
 int launch_moe_plan(const MoeArgs& a, hipStream_t stream) {
     if (check(a)) return 2;
+    LT_REQUIRE(2LL * a.rows <= 1024LL * 1023, "moe_plan: %d rows exceed the packed 16-bit counters of the scan (523776 rows)", a.rows);
     hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(1024), 0, stream, a);
-    LT_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_moe_gather(const MoeArgs& a, hipStream_t stream) {
-    if (check(a)) return 2;
-    hipLaunchKernelGGL(moe_gather_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -284,6 +284,45 @@ def test_gemm_small_m_grouped_expert_segments(variant, epilogue):
         assert rel_l2(out[rows], ref) < 6e-3, (t, ex, rel_l2(out[rows], ref))
 
 
+@pytest.mark.parametrize("variant", [0, 3, 7])
+@pytest.mark.parametrize("epilogue", [0, 1])
+def test_gemm_grouped_gather_on_load(variant, epilogue):
+    """round 3: the experts' GEMM reads its rows through the routing plan's inverse map (sorted position -> token row, -1 = padding)
+    instead of a gathered copy - must equal, bit for bit, the same kernel on a gathered copy; every token appears twice (top-2),
+    ragged segments, a padding-only tile, padding rows inside real tiles leave zeros x W = 0 rows (they are never read back)."""
+    E, K, N, T = 4, 1536, 512, 600
+    te = [2, 2, 0, -1, 3, 1, 1, -1]
+    M = 256 * len(te)
+    g = torch.Generator().manual_seed(41 + variant + epilogue)
+    X = bf(torch.randn(T, K, generator=g))
+    W = bf(torch.randn(E, N, K, generator=g) / math.sqrt(K))
+    row_map = torch.full((M,), -1, dtype=torch.int32)
+    fill = {0: 256, 1: 256, 2: 200, 4: 131, 5: 256, 6: 97}  # entries per real tile
+    perm = torch.randperm(T, generator=g)
+    cursor = 0
+    for t_, cnt in fill.items():
+        idx = torch.cat([perm, perm])[cursor:cursor + cnt]
+        cursor += cnt
+        row_map[256 * t_: 256 * t_ + cnt] = idx.to(torch.int32)
+    assert cursor == 2 * T - 4  # (almost) every token twice
+    gathered = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+    valid = row_map >= 0
+    gathered[valid.cuda()] = X[row_map[valid].long().cuda()]
+    tile_expert = torch.tensor(te, dtype=torch.int32, device="cuda")
+    No = N // 2 if epilogue else N
+    want = torch.full((M, No), 3.0, device="cuda", dtype=torch.bfloat16)
+    got = torch.full((M, No), 3.0, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_gemm_grouped(P(gathered), P(W), P(tile_expert), N * K, P(want), M, N, K, epilogue, variant, stream()), "grouped")
+    ok(lib().lt_op_gemm_grouped_gather(P(X), T, P(row_map.cuda()), P(W), P(tile_expert), N * K, P(got), M, N, K, epilogue, variant, stream()),
+       "grouped_gather")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.all(got[256 * 3: 256 * 4] == 3.0) and torch.all(got[256 * 7:] == 3.0)
+    y = X[row_map[256 * 4: 256 * 4 + 131].long().cuda()].float() @ W[3].float().t()
+    if not epilogue:
+        assert rel_l2(got[256 * 4: 256 * 4 + 131], y) < 4e-3
+
+
 @pytest.mark.parametrize("tokens,B,kvh,hd,K,variant", [(4096, 2, 32, 72, 2304, 0), (64, 3, 2, 72, 128, 1), (128, 2, 8, 72, 576, 2),
                                                        (4160, 2, 32, 96, 3072, 0), (1024, 2, 32, 48, 1536, 0), (64, 1, 4, 72, 64, 2)])
 def test_gemm_vt_epilogue_matches_gemm_plus_transpose(tokens, B, kvh, hd, K, variant):
