@@ -383,7 +383,7 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
     // expert GEMM at 512 rows in an engine sized for 8192)
     const int tiles = (int)((2 * (size_t)M + (size_t)e->E * 255 + 255) / 256);
     m.sel = e->moe_sel; m.wts = e->moe_wts; m.pos = e->moe_pos; m.tile_expert = e->moe_tile_expert; m.max_tiles = tiles;
-    m.src = e->moe_src; m.ys = e->moe_ys; m.out = e->o;
+    m.src = e->moe_src;
     m.gate_w = nullptr; m.sample_logits = nullptr; m.forced = nullptr;
     {
         ProfScope ps(e, 2, 0, s);
@@ -398,12 +398,12 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
             LT_REQUIRE(e->moe_force_rows == M, "forced MoE routing was given for %d rows, this call has %d", e->moe_force_rows, M);
             m.forced = e->moe_force + slot;
         }
-        if (launch_moe_route(m, s)) return 1;
+        if (branch != 0 && launch_moe_route(m, s)) return 1;  // (the time branch routes inside the plan kernel)
+        if (launch_moe_plan(m, s)) return 1;
         if (e->moe_rec_on) {
             LT_CHECK_HIP(hipMemcpyAsync(e->moe_rec + slot, e->moe_sel, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
             e->moe_rec_rows = M;
         }
-        if (launch_moe_plan(m, s)) return 1;
     }
     const int P = tiles * 256;
     GemmArgs g;
@@ -421,11 +421,13 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
         ProfScope ps(e, 0, 2.0 * (2.0 * M) * (double)d * F, s, true);
         if (launch_gemm_bf16(g, 0, 0, s, ps.ev0(), ps.ev1())) return 1;
     }
-    {
-        ProfScope ps(e, 2, 0, s);
-        if (launch_moe_combine(m, s)) return 1;
-    }
+    // (the top-2 combine of e->moe_ys is formed by the gated_residual_norm launch that consumes this branch: moe_y() below)
     return 0;
+}
+
+// the branch output of a MoE FFN as gated_residual_norm takes it: experts' outputs + routing, combined on the way in
+void moe_y(const lt_engine* e, GatedResArgs& g) {
+    g.y = nullptr; g.moe_ys = e->moe_ys; g.moe_pos = e->moe_pos; g.moe_wts = e->moe_wts;
 }
 
 // one forward pass of the configured family [+ CFG combine]:
@@ -649,7 +651,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             {
                 ProfScope ps(e, 2, 0, s);
                 GatedResArgs g;
-                g.x = e->x; g.y = e->o; g.post_w = w.norm_time; g.gate = chunk(l, 3); g.post_mode = 1; g.gate_mode = 0;
+                g.x = e->x; moe_y(e, g); g.post_w = w.norm_time; g.gate = chunk(l, 3); g.post_mode = 1; g.gate_mode = 0;
                 g.next_w = nullptr; g.next_scale = chunk(l, 4); g.next_shift = nullptr; g.next_mode = 1; g.h = e->h;
                 g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
                 if (launch_gated_residual_norm(g, s)) return 1;
@@ -662,6 +664,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
             g.x = e->x; g.y = e->o; g.post_w = last_post_w; g.gate = last_gate;
+            if (e->E != 0) moe_y(e, g);
             g.post_mode = post_mode; g.gate_mode = gate_mode; g.h = e->h;
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
             if (l + 1 < L) {

@@ -64,6 +64,11 @@ struct GatedResArgs {
     int post_mode, gate_mode, next_mode;
     float eps, eps_next;
     int scale_pre = 0;  // 1: next_scale already holds bf16(1 + scale)
+    // MoE layers: y is the top-2 combine of the experts' outputs, formed on the way in (y may then be null):
+    // ys [sorted rows, d], pos [rows, 2] sorted row of each (token, expert) pair, wts [rows, 2] bf16 routing weights (MoeArgs)
+    const u16* moe_ys = nullptr;
+    const int* moe_pos = nullptr;
+    const u16* moe_wts = nullptr;
 };
 int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream);
 void lt_set_norm_specialize(int v);  // 1: mode-specialised gated_residual_norm instantiations (experiment, default 0)
@@ -147,7 +152,8 @@ const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant);  // 
 struct MoeArgs {
     const u16* x;              // [rows, d] FFN input (after pre-norm + modulate)
     const u16* gate_w;         // space router weight [E, d] (per-token logits) or null
-    const u16* sample_logits;  // time router logits [B, E] bf16 (every token of a sample shares them) or null
+    const u16* sample_logits;  // time router logits [B, E] bf16 (every token of a sample shares them) or null; with them the plan
+                               // kernel routes as well (no separate route launch)
     const int* forced;         // [rows, 2] expert ids that replace the top-2 choice (parity hook, lt_moe_routing_force) or null
     int rows, rows_per_sample, d, E;
     int* sel;                  // [rows, 2] selected experts, ascending expert id (= the reference's accumulation order)
@@ -156,12 +162,9 @@ struct MoeArgs {
     int* src;                  // [max_tiles * 256] inverse map: token row of each sorted position, -1 for padding (GemmArgs::a_row_map)
     int* tile_expert;          // [max_tiles] expert of each 256-row tile of the sorted buffers, -1 = padding
     int max_tiles;
-    const u16* ys;             // [max_tiles * 256, d] expert outputs in the same order
-    u16* out;                  // [rows, d] combined result
 };
 int launch_moe_route(const MoeArgs& a, hipStream_t stream);    // logits -> top-2, weights
 int launch_moe_plan(const MoeArgs& a, hipStream_t stream);     // counts -> tile-aligned segments, pos, src, tile_expert
-int launch_moe_combine(const MoeArgs& a, hipStream_t stream);  // out[row] = sum over its experts, ascending, bf16 steps
 
 // ---- small kernels (misc.hip) ------------------------------------------------------------------
 int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int M, int N, int K, int act_in,

@@ -10,7 +10,8 @@
 //             -> bit-reproducible)
 //   (gather : round 3 - folded into the grouped SwiGLU GEMM, which reads its A rows through the plan's inverse map src[])
 //   combine : out[token] = bf16(bf16(0 + bf16(w_a y_a)) + bf16(w_b y_b)), experts in ascending id = the order of the
-//             reference's `for i, expert in enumerate(self.experts)` loop (:472-476)
+//             reference's `for i, expert in enumerate(self.experts)` loop (:472-476) - round 3: formed inside the
+//             gated_residual_norm launch that consumes the branch (norm.hip, MOE = true), no kernel of its own
 // TimeMoeLayer routes on the timestep embedding, so all tokens of a sample share the two experts; SpaceMoeLayer
 // routes every token on its own FFN input.  Both go through the same four kernels.
 #include "common.h"
@@ -20,6 +21,31 @@ namespace {
 
 constexpr int MAX_E = 8;
 constexpr int TILE = 256;
+
+// top-2 of E logits (lowest index wins ties), fp32 softmax over the two, bf16 weights; (sel, wts) in ascending expert id
+__device__ __forceinline__ void top2_route(const float (&logit)[MAX_E], const int* forced2, int& s0, int& s1, u16& w0, u16& w1) {
+    int i1 = 0;
+#pragma unroll
+    for (int e = 1; e < MAX_E; ++e) if (logit[e] > logit[i1]) i1 = e;
+    int i2 = i1 == 0 ? 1 : 0;
+#pragma unroll
+    for (int e = 0; e < MAX_E; ++e) if (e != i1 && e != i2 && logit[e] > logit[i2]) i2 = e;
+    if (forced2) {  // the discrete choice comes from outside (a reference run's); the weights stay this run's own arithmetic
+        i1 = forced2[0];
+        i2 = forced2[1];
+    }
+    float l1 = 0.f, l2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAX_E; ++e) { l1 = e == i1 ? logit[e] : l1; l2 = e == i2 ? logit[e] : l2; }
+    // softmax over (v1, v2) in fp32, then the cast back to the activation dtype (:466-470)
+    const float ex = __expf(l2 - l1);
+    const float wa = 1.0f / (1.0f + ex), wb = ex / (1.0f + ex);
+    const bool swap = i2 < i1;  // accumulate in ascending expert id
+    s0 = swap ? i2 : i1;
+    s1 = swap ? i1 : i2;
+    w0 = f2bf(swap ? wb : wa);
+    w1 = f2bf(swap ? wa : wb);
+}
 
 __global__ __launch_bounds__(256) void moe_route_kernel(MoeArgs p) {
     const int lane = threadIdx.x & 63;
@@ -53,24 +79,13 @@ __global__ __launch_bounds__(256) void moe_route_kernel(MoeArgs p) {
         for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bfr(wave_sum(acc[e])) : -INFINITY;  // nn.Linear output in bf16
     }
     if (lane == 0) {
-        int i1 = 0;
-#pragma unroll
-        for (int e = 1; e < MAX_E; ++e) if (logit[e] > logit[i1]) i1 = e;
-        int i2 = i1 == 0 ? 1 : 0;
-#pragma unroll
-        for (int e = 0; e < MAX_E; ++e) if (e != i1 && e != i2 && logit[e] > logit[i2]) i2 = e;
-        if (p.forced) {  // the discrete choice comes from outside (a reference run's); the weights stay this run's own arithmetic
-            i1 = p.forced[2 * row];
-            i2 = p.forced[2 * row + 1];
-        }
-        // softmax over (v1, v2) in fp32, then the cast back to the activation dtype (:466-470)
-        const float ex = __expf(logit[i2] - logit[i1]);
-        const float w1 = 1.0f / (1.0f + ex), w2 = ex / (1.0f + ex);
-        const bool swap = i2 < i1;  // accumulate in ascending expert id
-        p.sel[2 * row] = swap ? i2 : i1;
-        p.sel[2 * row + 1] = swap ? i1 : i2;
-        p.wts[2 * row] = f2bf(swap ? w2 : w1);
-        p.wts[2 * row + 1] = f2bf(swap ? w1 : w2);
+        int s0, s1;
+        u16 w0, w1;
+        top2_route(logit, p.forced ? p.forced + 2 * row : nullptr, s0, s1, w0, w1);
+        p.sel[2 * row] = s0;
+        p.sel[2 * row + 1] = s1;
+        p.wts[2 * row] = w0;
+        p.wts[2 * row + 1] = w1;
     }
 }
 
@@ -88,6 +103,20 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
     const int per = (n + 1023) / 1024;
     const int lo = tid * per, hi = min(n, lo + per);
     unsigned long long c0 = 0, c1 = 0;  // this thread's counts: experts 0..3 / 4..7, 16 bits each
+    if (p.sample_logits) {  // time router: the logits are per sample - route here, no separate launch (sel / wts written for combine)
+        for (int i = lo; i < hi; ++i) {
+            const int row = i >> 1, b = row / p.rows_per_sample;
+            float logit[MAX_E];
+#pragma unroll
+            for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[b * p.E + e]) : -INFINITY;
+            int s0, s1;
+            u16 w0, w1;
+            top2_route(logit, p.forced ? p.forced + 2 * row : nullptr, s0, s1, w0, w1);
+            p.sel[i] = (i & 1) ? s1 : s0;
+            p.wts[i] = (i & 1) ? w1 : w0;
+        }
+        __syncthreads();  // (sel is re-read below by the thread that wrote it; the barrier orders the rest of the kernel's reads)
+    }
     for (int i = lo; i < hi; ++i) {
         const int ex = p.sel[i];
         if (ex < 4) c0 += 1ull << (16 * ex);
@@ -154,25 +183,6 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void moe_combine_kernel(MoeArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
-    const int nch = p.d >> 3;
-    const u16* y0 = p.ys + (size_t)p.pos[2 * row] * p.d;
-    const u16* y1 = p.ys + (size_t)p.pos[2 * row + 1] * p.d;
-    const float w0 = bf2f(p.wts[2 * row]), w1 = bf2f(p.wts[2 * row + 1]);
-    u16* dst = p.out + (size_t)row * p.d;
-    for (int c = lane; c < nch; c += 64) {
-        float a[8], b[8], o[8];
-        unpack8(*(const bf8_t*)(y0 + c * 8), a);
-        unpack8(*(const bf8_t*)(y1 + c * 8), b);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = bfr(bfr(0.0f + bfr(w0 * a[i])) + bfr(w1 * b[i]));
-        *(bf8_t*)(dst + c * 8) = pack8(o);
-    }
-}
-
 }  // namespace
 
 static int check(const MoeArgs& a) {
@@ -184,7 +194,7 @@ static int check(const MoeArgs& a) {
 
 int launch_moe_route(const MoeArgs& a, hipStream_t stream) {
     if (check(a)) return 2;
-    LT_REQUIRE((a.gate_w != nullptr) != (a.sample_logits != nullptr), "moe_route: exactly one of gate_w / sample_logits");
+    LT_REQUIRE(a.gate_w != nullptr && a.sample_logits == nullptr, "moe_route: per-token router weights required (per-sample logits are routed by moe_plan)");
     hipLaunchKernelGGL(moe_route_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
@@ -194,13 +204,6 @@ int launch_moe_plan(const MoeArgs& a, hipStream_t stream) {
     if (check(a)) return 2;
     LT_REQUIRE(2LL * a.rows <= 1024LL * 1023, "moe_plan: %d rows exceed the packed 16-bit counters of the scan (523776 rows)", a.rows);
     hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(1024), 0, stream, a);
-    LT_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_moe_combine(const MoeArgs& a, hipStream_t stream) {
-    if (check(a)) return 2;
-    hipLaunchKernelGGL(moe_combine_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -94,7 +94,11 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(NormModArgs p) {
 // PM / GM / NM >= 0: post_mode / gate_mode / next_mode fixed at compile time (the engine's combinations; selected by
 // lt_set_option("norm_specialize", 1), OFF by default until measured) - same statements in the same order, the mode tests inside
 // the per-chunk loops fold away.  -1: the mode is read from the arguments (the kernel as it has always been).
-template <int MAXCH, int PM = -1, int GM = -1, int NM = -1>
+// MOE (round 3): the branch output y is not a buffer but the top-2 combine of the experts' outputs, done on the way in:
+//   y[row] = bfr(bfr(0 + bfr(w_a ys[pos_a])) + bfr(w_b ys[pos_b]))   (ascending expert id = the reference's accumulation order,
+// Next-DiT-MoE/models/models2.py:472-476) - what moe_combine_kernel wrote to `o` before, one launch and one [rows, d] round trip less
+// per MoE layer.
+template <int MAXCH, int PM = -1, int GM = -1, int NM = -1, bool MOE = false>
 __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p) {
     const int post_mode = PM >= 0 ? PM : p.post_mode, gate_mode = GM >= 0 ? GM : p.gate_mode, next_mode = NM >= 0 ? NM : p.next_mode;
     const int lane = threadIdx.x & 63;
@@ -104,8 +108,22 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
     const int nch = p.d >> 3;
     u16* xrow = p.x + (size_t)row * p.d;
     RowRaw<MAXCH> r, xr;
-    load_row(p.y + (size_t)row * p.d, nch, lane, r);
-    load_row(xrow, nch, lane, xr);  // issued with y: one memory round trip for both streams
+    if constexpr (MOE) {
+        RowRaw<MAXCH> ya, yb;
+        load_row(p.moe_ys + (size_t)p.moe_pos[2 * row] * p.d, nch, lane, ya);
+        load_row(p.moe_ys + (size_t)p.moe_pos[2 * row + 1] * p.d, nch, lane, yb);
+        load_row(xrow, nch, lane, xr);
+        const float w0 = bf2f(p.moe_wts[2 * row]), w1 = bf2f(p.moe_wts[2 * row + 1]);
+        const f32x2 w0v = {w0, w0}, w1v = {w1, w1}, zero = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r.c[i].w[k] = pk_bf(bfr2(zero + bfr2(w0v * unpk_bf(ya.c[i].w[k]))) + bfr2(w1v * unpk_bf(yb.c[i].w[k])));
+    } else {
+        load_row(p.y + (size_t)row * p.d, nch, lane, r);
+        load_row(xrow, nch, lane, xr);  // issued with y: one memory round trip for both streams
+    }
     float rinv = 1.f;
     if (post_mode == 1) rinv = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
     const u16* gate = p.gate ? p.gate + (size_t)b * p.ld_mod : nullptr;
@@ -212,9 +230,24 @@ int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH_LIMIT, "gated_residual_norm: d=%d must be a multiple of 8 and <= 4096", a.d);
     LT_REQUIRE(a.rows_per_batch > 0 && a.rows > 0, "gated_residual_norm: empty input");
     LT_REQUIRE(a.gate_mode == 2 || a.gate != nullptr, "gated_residual_norm: gate pointer missing");
+    LT_REQUIRE(a.y != nullptr || a.moe_pos != nullptr, "gated_residual_norm: branch output missing");
     LT_REQUIRE(a.post_mode == 0 || a.post_w != nullptr, "gated_residual_norm: post-norm weight missing");
     LT_REQUIRE(a.next_mode == 0 || a.h != nullptr, "gated_residual_norm: h output missing");
     const dim3 grid((a.rows + 3) / 4);
+    if (a.moe_pos) {  // y = top-2 combine of the experts' outputs (MoE families: d = 1536 ... 4096)
+        LT_REQUIRE(a.moe_ys && a.moe_wts, "gated_residual_norm: incomplete MoE combine arguments");
+        switch (((a.d >> 3) + 63) / 64) {
+            case 1: hipLaunchKernelGGL((gated_residual_norm_kernel<1, -1, -1, -1, true>), grid, dim3(256), 0, stream, a); break;
+            case 2: hipLaunchKernelGGL((gated_residual_norm_kernel<2, -1, -1, -1, true>), grid, dim3(256), 0, stream, a); break;
+            case 3: hipLaunchKernelGGL((gated_residual_norm_kernel<3, -1, -1, -1, true>), grid, dim3(256), 0, stream, a); break;
+            case 4: hipLaunchKernelGGL((gated_residual_norm_kernel<4, -1, -1, -1, true>), grid, dim3(256), 0, stream, a); break;
+            case 5: hipLaunchKernelGGL((gated_residual_norm_kernel<5, -1, -1, -1, true>), grid, dim3(256), 0, stream, a); break;
+            case 6: hipLaunchKernelGGL((gated_residual_norm_kernel<6, -1, -1, -1, true>), grid, dim3(256), 0, stream, a); break;
+            default: hipLaunchKernelGGL((gated_residual_norm_kernel<8, -1, -1, -1, true>), grid, dim3(256), 0, stream, a); break;
+        }
+        LT_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (g_norm_specialize && a.gate_mode == 0 && (a.post_mode == 0 || a.post_mode == 1) && (a.next_mode == 1 || a.next_mode == 2)) {
         const int nch64 = ((a.d >> 3) + 63) / 64;
 #define LT_GRN_SPEC(MC, PMV, NMV) \
