@@ -9,41 +9,68 @@ namespace {
 // ---- y[m,n] = sum_k act(a[m,k]) w[n,k] + b[n]  (adaLN_modulation model.py:560-569, t_embedder :44-60,
 //      cap_embedder :702-711, final adaLN :646-655).  Weight-bandwidth bound: one wave per output column.
 constexpr int SM_MAXM = 8;
+// Round 3: a wave owns SM_NC consecutive output columns instead of one.  The one-column form re-read and re-activated (SiLU + bf16
+// rounding: ~10 VALU per element) the M input rows for every column - 100 k columns at the adaLN GEMV of cfg 1 - and had two 16-byte
+// weight loads in flight per lane: VALU-bound at 2.5 TB/s of weights (61 us x 3 per NFE at cfg 2, 80 us at cfg 1).  Now the
+// activated inputs of a chunk are formed once per SM_NC columns and SM_NC independent weight loads are in flight per chunk.  Every
+// output is still the same lane-strided partial sums followed by the same wave reduction: bit-identical results.
+constexpr int SM_NC = 8;
+template <int MM>  // rows held in registers: 2 (a CFG pair), 4 or 8
 __global__ __launch_bounds__(256) void linear_small_m_kernel(const u16* __restrict__ a, const u16* __restrict__ w,
                                                              const u16* __restrict__ bias, u16* __restrict__ y, int M,
                                                              int N, int K, int act_in) {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SM_NC;
+    if (n0 >= N) return;
     const int nch = K >> 3;
-    float acc[SM_MAXM];
+    float acc[SM_NC][MM];
 #pragma unroll
-    for (int m = 0; m < SM_MAXM; ++m) acc[m] = 0.f;
-    const u16* wrow = w + (size_t)n * K;
+    for (int j = 0; j < SM_NC; ++j)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[j][m] = 0.f;
     for (int c = lane; c < nch; c += 64) {
-        float wf[8];
-        unpack8(*(const bf8_t*)(wrow + c * 8), wf);
+        bf8_t wv[SM_NC];
 #pragma unroll
-        for (int m = 0; m < SM_MAXM; ++m) {
+        for (int j = 0; j < SM_NC; ++j) {  // columns past N re-read the last one (results discarded)
+            const int n = n0 + j < N ? n0 + j : N - 1;
+            wv[j] = *(const bf8_t*)(w + (size_t)n * K + c * 8);
+        }
+        float af[MM][8];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
             if (m < M) {
-                float af[8];
-                unpack8(*(const bf8_t*)(a + (size_t)m * K + c * 8), af);
+                unpack8(*(const bf8_t*)(a + (size_t)m * K + c * 8), af[m]);
+                if (act_in == 1) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float x = af[e];
-                    if (act_in == 1) x = bfr(silu_f(x));
-                    acc[m] += x * wf[e];
+                    for (int e = 0; e < 8; ++e) af[m][e] = bfr(silu_f(af[m][e]));
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[m][e] = 0.f;
             }
+        }
+#pragma unroll
+        for (int j = 0; j < SM_NC; ++j) {
+            float wf[8];
+            unpack8(wv[j], wf);
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][m] += af[m][e] * wf[e];
         }
     }
 #pragma unroll
-    for (int m = 0; m < SM_MAXM; ++m) {
-        if (m < M) {
-            float s = wave_sum(acc[m]);
-            if (lane == 0) {
-                if (bias) s += bf2f(bias[n]);
-                y[(size_t)m * N + n] = f2bf(s);
+    for (int j = 0; j < SM_NC; ++j) {
+        if (n0 + j < N) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                if (m < M) {
+                    float s = wave_sum(acc[j][m]);
+                    if (lane == 0) {
+                        if (bias) s += bf2f(bias[n0 + j]);
+                        y[(size_t)m * N + n0 + j] = f2bf(s);
+                    }
+                }
             }
         }
     }
@@ -342,7 +369,10 @@ int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int 
                           hipStream_t stream) {
     LT_REQUIRE(M >= 1 && M <= SM_MAXM, "linear_small_m: M=%d out of range 1..%d", M, SM_MAXM);
     LT_REQUIRE(K % 8 == 0, "linear_small_m: K=%d must be a multiple of 8", K);
-    hipLaunchKernelGGL(linear_small_m_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, a, w, b, y, M, N, K, act_in);
+    const dim3 grid(((N + SM_NC - 1) / SM_NC + 3) / 4);
+    if (M <= 2) hipLaunchKernelGGL(linear_small_m_kernel<2>, grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in);
+    else if (M <= 4) hipLaunchKernelGGL(linear_small_m_kernel<4>, grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in);
+    else hipLaunchKernelGGL(linear_small_m_kernel<8>, grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -790,15 +790,20 @@ def test_attention_v4_fused_text_is_bit_identical_to_v3(B, H, Hkv, N, T, valid1)
     assert torch.equal(outs[0], outs[1]), rel_l2(outs[1], outs[0])
 
 
-@pytest.mark.parametrize("M,N,K,act", [(2, 1000, 256, 0), (2, 9216, 1024, 1), (1, 37, 128, 1), (8, 64, 2048, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(2, 1000, 256, 0), (2, 9216, 1024, 1), (1, 37, 128, 1), (8, 64, 2048, 0), (3, 1001, 1024, 1), (5, 7, 64, 0),
+                                       (2, 101376, 1024, 1)])
 def test_linear_small_m(M, N, K, act):
+    """eight output columns per wave since round 3: N not a multiple of 8 / 32, fewer columns than one wave's eight, every register
+    height (2 / 4 / 8 rows), the adaLN GEMV of cfg 1 (101 376 columns); a guarded buffer catches stores past [M, N]"""
     g = torch.Generator().manual_seed(N)
     a = bf(torch.randn(M, K, generator=g))
     w = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = bf(torch.randn(N, generator=g))
-    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    buf = torch.full((M * N + 64,), 7.0, device="cuda", dtype=torch.bfloat16)
+    y = buf[:M * N].view(M, N)
     ok(lib().lt_op_linear_small_m(P(a), P(w), P(b), P(y), M, N, K, act, stream()))
     torch.cuda.synchronize()
+    assert torch.all(buf[M * N:] == 7.0)
     af = a.float().cpu()
     if act:
         af = r16(F.silu(af))
