@@ -44,6 +44,8 @@ def ab(cases, rounds):
 SHAPES_CFG2 = [("qkv", 8192, 6912, 2304, 0), ("wo", 8192, 2304, 2304, 0), ("w13", 8192, 12288, 2304, 1),
                ("w2", 8192, 2304, 6144, 0)]
 # BASELINE cfg 1 (Next-DiT-ImageNet 600M, 256 tokens, cond + null row): 512 rows - the small-M regime
+# BASELINE cfg 3 (Flag-DiT 5B at 1024^2): 2 x 4160 = 8320 rows = 32.5 row tiles of 256
+SHAPES_CFG3 = [("qkv", 8320, 9216, 3072, 0), ("wo", 8320, 3072, 3072, 0), ("w13", 8320, 16384, 3072, 1), ("w2", 8320, 3072, 8192, 0)]
 SHAPES_CFG1 = [("qkv", 512, 4608, 1536, 0), ("wo", 512, 1536, 1536, 0), ("w13", 512, 8192, 1536, 1), ("w2", 512, 1536, 4096, 0)]
 
 
@@ -344,6 +346,8 @@ if __name__ == "__main__":
     if "gemm_small" in a.what:
         bench_gemm(a.rounds, [v if ("t" in v or "p" in v) else int(v) for v in a.gemm_variants.split(",")], shapes=SHAPES_CFG1,
                    cold=a.cold)
+    if "gemm_cfg3" in a.what:
+        bench_gemm(a.rounds, [int(v) for v in a.gemm_variants.split(",")], shapes=SHAPES_CFG3)
     if "gemm_vendor" in a.what:
         bench_gemm_vendor(a.rounds)
     if "gemm_moe" in a.what:
