@@ -89,9 +89,8 @@ def plan_inference(config: dict, image_size: int, family: str = "next") -> dict:
             model_kwargs.update(scale_factor=math.sqrt(w * h / image_size ** 2), scale_watershed=float(watershed))
         else:
             model_kwargs.update(scale_factor=1.0, scale_watershed=1.0)
-    if ode.get("likelihood", False):
-        raise NotImplementedError("ode.likelihood: sample_ode_likelihood differentiates through the model (transport.py:393-450); "
-                                  "the engine is forward-only")
+    # ode.likelihood is read and never used by the reference's t2i command line (utils/cli.py:175; only the ImageNet / MoE
+    # sample.py scripts call sample_ode_likelihood): same here
     return dict(
         transport=dict(path_type=tr["path_type"], prediction=tr["prediction"], loss_weight=tr["loss_weight"],
                        train_eps=tr["train_eps"], sample_eps=tr["sample_eps"]),

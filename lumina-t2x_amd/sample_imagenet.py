@@ -8,7 +8,9 @@
 What is ours: the DiT runs on the HIP engine behind ``models.imagenet``; one process, one GPU (the reference asserts
 ``num_gpus == 1`` too, :267).  The VAE stays third-party (``diffusers.AutoencoderKL`` from ``--local_diffusers_model_root``;
 there is no network here) - without it the final latents are written as ``.pt`` next to where the png would go.
-``--likelihood`` needs gradients through the model (transport.py:393-450) and is refused: the engine is forward-only.
+``--likelihood`` (sample.py:134-141; needs ``--cfg_scale 1``) integrates the likelihood ODE with the divergence taken by central
+differences through the forward-only engine (``Sampler.sample_ode_likelihood(divergence="fd")``) where the reference uses autograd;
+like the reference, the run then takes ``[-1]`` of the returned (logp, z) pair = the latent carried to the noise end.
 
     python -m lumina_t2x_amd.sample_imagenet ODE --ckpt /ckpts/next-dit-imagenet --sampling-method euler --num_sampling_steps 50
 """
@@ -63,8 +65,10 @@ def make_vae_decoder(root: Optional[str], vae_name: str, device) -> Optional[Cal
 def build_sample_fn(args, mode: str):
     sampler = Sampler(create_transport(args.path_type, args.prediction, args.loss_weight, args.train_eps, args.sample_eps))
     if mode == "ODE":
-        if getattr(args, "likelihood", False):
-            raise NotImplementedError("--likelihood: sample_ode_likelihood differentiates through the model; the engine is forward-only")
+        if getattr(args, "likelihood", False):  # sample.py:134-141 (the forward-only engine takes the finite-difference divergence)
+            assert args.cfg_scale == 1, "Likelihood is incompatible with guidance"
+            return sampler.sample_ode_likelihood(sampling_method=args.sampling_method, num_steps=args.num_sampling_steps,
+                                                 atol=args.atol, rtol=args.rtol)
         return sampler.sample_ode(sampling_method=args.sampling_method, num_steps=args.num_sampling_steps, atol=args.atol,
                                   rtol=args.rtol, reverse=args.reverse)
     return sampler.sample_sde(sampling_method=args.sampling_method, diffusion_form=args.diffusion_form,

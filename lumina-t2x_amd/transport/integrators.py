@@ -80,13 +80,15 @@ def _rms(x):
     return x.float().pow(2).mean().sqrt()
 
 
-def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 1, stats=None):
+def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 1, stats=None, norm=None):
     """torchdiffeq.odeint(func, y0, t, rtol=rtol, atol=atol, method="dopri5"): solution at every point of ``t`` (dense
     output through the 4th-order interpolant), steps chosen by the embedded error estimate.
 
     Follows torchdiffeq's controller: initial step from Hairer's heuristic (``_select_initial_step``), error ratio =
     rms(err / (atol + rtol max(|y0|, |y1|))), accept if <= 1, next step = dt * min(10, max(0.9 ratio^-1/5, 0.2 or 1)).
-    ``stats`` (optional dict) receives the number of function evaluations and accepted / rejected steps."""
+    ``stats`` (optional dict) receives the number of function evaluations and accepted / rejected steps; ``norm`` replaces the
+    rms norm of the controller (tuple states use torchdiffeq's mixed norm, see ``tuple_odeint``)."""
+    nrm = norm if norm is not None else _rms
     t = t.to(device=y0.device)
     tdt = t.dtype
 
@@ -99,12 +101,12 @@ def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 
     nfe += 1
     # _select_initial_step(func, t0, y0, order = 4, ...)
     scale = atol + y0.abs() * rtol
-    d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
+    d0, d1 = nrm(y0 / scale), nrm(f0 / scale)
     h0 = 0.01 * d0 / d1 if (float(d0) >= 1e-5 and float(d1) >= 1e-5) else th.tensor(1e-6, device=y0.device)
     h0 = h0.to(tdt)
     f1 = f(t0 + h0, y0 + h0.to(y0.dtype) * f0)
     nfe += 1
-    d2 = _rms((f1 - f0) / scale) / h0
+    d2 = nrm((f1 - f0) / scale) / h0
     if float(d1) <= 1e-15 and float(d2) <= 1e-15:
         h1 = th.max(th.tensor(1e-6, dtype=tdt, device=y0.device), h0 * 1e-3)
     else:
@@ -143,7 +145,7 @@ def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 
                     err = err + kj * cj
             err = dty * err
             tol = atol + rtol * th.max(y.abs(), y1.abs())
-            ratio = float(_rms(err / tol))
+            ratio = float(nrm(err / tol))
             if ratio <= 1.0:  # accept: dense-output coefficients of this step, then move on
                 mid = k[0] * _DP_C_MID[0]
                 for kj, cj in zip(k[1:], _DP_C_MID[1:]):
@@ -177,6 +179,35 @@ def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 
     return out
 
 
+def tuple_odeint(func, y0, t, *, method, rtol=1e-3, atol=1e-6):
+    """torchdiffeq.odeint on a TUPLE state (the likelihood ODE's (x, delta_logp), reference transport.py:431-433): the tuple is
+    flattened into one 1-d state (``_check_inputs``: cat of reshape(-1)), the user function wrapped (``_TupleFunc``), the solution
+    split back into a tuple of [len(t), *shape] tensors; the adaptive controller then measures with the MIXED norm = max over the
+    components of their rms norms (``_mixed_norm``).  One tolerance for all components (the reference passes [atol] * len(x))."""
+    shapes = [tuple(y.shape) for y in y0]
+    sizes = [y.numel() for y in y0]
+
+    def split(flat, lead=()):
+        out, o = [], 0
+        for sh, n in zip(shapes, sizes):
+            out.append(flat[..., o:o + n].reshape(lead + sh))
+            o += n
+        return tuple(out)
+
+    def f(tt, flat):
+        return th.cat([g.reshape(-1) for g in func(tt, split(flat))])
+
+    def mixed_norm(flat):
+        return th.stack([_rms(c) for c in split(flat)]).max()
+
+    flat0 = th.cat([y.reshape(-1) for y in y0])
+    if method == "dopri5":
+        sol = dopri5_odeint(f, flat0, t, rtol=rtol, atol=atol, norm=mixed_norm)
+    else:
+        sol = fixed_grid_odeint(f, flat0, t, method=method)
+    return split(sol, (len(t),))
+
+
 def _engine_target(model):
     """(NextDiT instance, use_cfg) when ``model`` is one of our engine-backed bound methods, else None."""
     owner = getattr(model, "__self__", None)
@@ -206,8 +237,13 @@ class ode:
         self.t_round_to_state_dtype = True
 
     def sample(self, x, model, **model_kwargs):
-        if isinstance(x, tuple):
-            raise NotImplementedError("tuple states (likelihood ODE) are a later row (SURVEY.md 8f)")
+        if isinstance(x, tuple):  # the likelihood ODE (reference integrators.py:105-115 with a tuple state)
+            device = x[0].device
+
+            def _fn_tuple(t, y):
+                return self.drift(y, th.ones(y[0].size(0)).to(device) * t, model, **model_kwargs)
+
+            return tuple_odeint(_fn_tuple, x, self.t.to(device), method=self.sampler_type, rtol=self.rtol, atol=self.atol)
         target = _engine_target(model)
         if (target is not None and getattr(self.drift, "is_plain_velocity", False) and x.is_cuda
                 and self.sampler_type in FIXED_GRID_METHODS):

@@ -231,6 +231,38 @@ def transport_kats():
     print("transport_kat.npz:", len(cases), "sde cases")
 
 
+def likelihood_kats():
+    """``Sampler.sample_ode_likelihood`` (transport.py:393-450) run from the UNMODIFIED reference modules: the Hutchinson probe
+    draws (``th.randint`` per function call), the autograd divergence ``eps^T d(drift . eps)/dx``, the reversed time ``1 - t``,
+    the sign of the returned drift, ``prior_logp`` and the final ``prior - delta`` - everything that is the reference's own
+    code.  The fixed-grid stepping of the (x, logp) TUPLE state goes through the torchdiffeq stub (oracle/odeint_oracle.py:
+    flatten, step, split - parity unpinned like every torchdiffeq piece).  Toy velocity fields with known divergence so the
+    fixture can be checked by hand: `lin` has div = -D (0.5 + t') exactly for every probe, `cos` adds a state dependent term."""
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
+        del sys.modules[m]
+    _, T = R.load_reference("lumina_next_t2i")
+    d = {}
+    fields = {"lin": lambda x, t, **kw: -x * (0.5 + t.view(-1, 1, 1, 1)),
+              "cos": lambda x, t, **kw: -x * (0.5 + t.view(-1, 1, 1, 1)) + 0.1 * torch.cos(3.0 * x)}
+    x0 = torch.linspace(-1.0, 1.0, 2 * 3 * 4 * 4).view(2, 3, 4, 4).clone() * 0.8
+    cases = []
+    for path_type, eps in (("Linear", (None, None)), ("GVP", (None, None))):
+        tr = T.create_transport(path_type, "velocity", None, eps[0], eps[1])
+        for fname, model in fields.items():
+            for method, n in (("euler", 6), ("midpoint", 5), ("rk4", 4)):
+                key = f"lik_{path_type}_{fname}_{method}"
+                torch.manual_seed(4321)
+                fn = T.Sampler(tr).sample_ode_likelihood(sampling_method=method, num_steps=n)
+                with torch.no_grad():
+                    logp, z = fn(x0.clone(), model)
+                d[key + "_logp"], d[key + "_z"] = _np(logp), _np(z)
+                cases.append([key, path_type, fname, method, n])
+    d["x0"] = _np(x0)
+    d["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(OUT, "likelihood_kat.npz"), **d)
+    print("likelihood_kat.npz:", len(cases), "cases", {k: v.tolist() for k, v in d.items() if k.endswith("euler_logp")})
+
+
 def _fresh_import(pkg, module):
     """import <pkg>/<module> of the reference with a clean `models` namespace (every sub-project calls its package `models`)"""
     for m in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "transport" or k.startswith("transport.")]:
@@ -373,6 +405,8 @@ def main():
     torch.set_grad_enabled(False)
     if sys.argv[1:] == ["solver"]:  # python -m oracle.make_golden solver: only tests/golden/solver_kat.npz
         return solver_kats()
+    if sys.argv[1:] == ["likelihood"]:  # ... only tests/golden/likelihood_kat.npz
+        return likelihood_kats()
     models_mod, transport_mod = R.load_reference()
     kats(models_mod, transport_mod)
     model_case("nextdit_tiny", synth.TINY, "lumina_next_t2i", (16, 16), 16, 8, 0, 1)
@@ -389,6 +423,7 @@ def main():
     compositional_case("compositional_tiny", synth.TINY, (16, 24), (2, 2), 16, 15, 16)
     compositional_case("compositional_tiny_1x3", synth.TINY, (12, 24), (1, 3), 13, 17, 18)
     solver_kats()
+    likelihood_kats()
 
 
 if __name__ == "__main__":

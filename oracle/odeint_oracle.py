@@ -10,9 +10,31 @@ the state dtype; ``rk4`` is the 3/8-rule ``rk4_alt_step_func``.  Anchors: the re
 import torch
 
 
+def _odeint_tuple(func, y0, t, **kw):
+    """tuple states (the likelihood ODE, transport.py:431-433): torchdiffeq flattens the tuple into ONE 1-d state
+    (``_check_inputs``: cat of reshape(-1)), wraps the user function (``_TupleFunc``) and splits the solution back."""
+    shapes = [tuple(y.shape) for y in y0]
+    sizes = [y.numel() for y in y0]
+
+    def split(flat, lead=()):
+        out, o = [], 0
+        for sh, n in zip(shapes, sizes):
+            out.append(flat[..., o:o + n].reshape(lead + sh))
+            o += n
+        return tuple(out)
+
+    def f(tt, flat):
+        return torch.cat([g.reshape(-1) for g in func(tt, split(flat))])
+
+    sol = odeint(f, torch.cat([y.reshape(-1) for y in y0]), t, **kw)
+    return split(sol, (len(t),))
+
+
 def odeint(func, y0, t, *, method="euler", atol=None, rtol=None, t_cast=True):
     if method not in ("euler", "midpoint", "rk4"):
         raise NotImplementedError(method)
+    if isinstance(y0, tuple):
+        return _odeint_tuple(func, y0, t, method=method, t_cast=t_cast)
 
     def f(tt, y):
         return func(tt.to(y.dtype) if t_cast else tt, y)

@@ -72,6 +72,48 @@ def test_dopri5_on_the_engine_vs_oracle_driven_solver(golden_dir, state_dtype):
         assert rel_l2(got[i], ref[i]) < tol, (i, rel_l2(got[i], ref[i]))
 
 
+def test_likelihood_ode_on_the_engine_fd_divergence_vs_oracle_autograd(golden_dir, monkeypatch):
+    """Sampler.sample_ode_likelihood (transport.py:393-450) with the ENGINE as the model: the forward-only engine takes the
+    divergence by central differences (`divergence="auto"` -> "fd" for an engine-backed bound method), the fp32 oracle on the CPU
+    takes it the reference's way (autograd).  Both sides see the same Hutchinson probes (drawn from torch's CPU generator).
+    `forward` (no guidance: sample.py:135 asserts cfg_scale == 1) keeps the samples independent - through `forward_with_cfg`
+    the second half of the batch is computed from the first (:model.py forward_with_cfg), and the reference's per-sample split of
+    eps^T J^T eps differs from eps^T J eps by a zero-mean cross term; only their batch sums agree (checked on the CPU oracle).
+
+    The gate: z within the per-evaluation bf16 tolerance; logp within a few percent of |delta logp| - the finite difference
+    divides the engine's bf16 rounding noise by 2 h (documented in sample_ode_likelihood)."""
+    g, cfg, sd, model = _imagenet(golden_dir)
+    z, y = torch.from_numpy(g["z"]), torch.from_numpy(g["y"])
+    real = torch.randint
+
+    def cpu_randint(*a, device=None, **k):
+        out = real(*a, **k)
+        return out.to(device) if device is not None else out
+
+    monkeypatch.setattr(torch, "randint", cpu_randint)
+    tr = create_transport("Linear", "velocity", None, None, None)
+    kw = dict(sampling_method="euler", num_steps=5)
+    torch.manual_seed(5)
+    logp, zz = Sampler(tr).sample_ode_likelihood(**kw)(z.cuda(), model.forward, y=y.cuda())
+    torch.manual_seed(5)
+    rlogp, rz = Sampler(tr).sample_ode_likelihood(divergence="autograd", **kw)(z.clone(), lambda x, t, **k: V.imagenet_forward(sd, cfg, x, t, **k), y=y)
+    torch.manual_seed(5)
+    flogp, fz = Sampler(tr).sample_ode_likelihood(divergence="fd", **kw)(z.clone(), lambda x, t, **k: V.imagenet_forward(sd, cfg, x, t, **k), y=y)
+    def prior(v):
+        return -z[0].numel() / 2.0 * np.log(2 * np.pi) - v.float().cpu().flatten(1).pow(2).sum(1) / 2.0
+
+    # logp = log N(z) - delta: the divergence integral (what this sampler adds) and the prior of the carried state, separately
+    delta, rdelta, fdelta = prior(zz) - logp.cpu(), prior(rz) - rlogp, prior(fz) - flogp
+    print("delta engine-fd", delta.tolist(), "oracle autograd", rdelta.tolist(), "oracle fd", fdelta.tolist(),
+          "| prior engine", prior(zz).tolist(), "oracle", prior(rz).tolist())
+    assert logp.shape == (2,) and zz.shape == z.shape and torch.isfinite(logp).all()
+    assert rel_l2(zz, rz) < 3e-2 and rel_l2(fz, rz) < 1e-5
+    assert ((fdelta - rdelta).abs() < 1e-2 * rdelta.abs() + 0.1).all()        # fp32 model: fd == autograd to O(h^2) (0.7 % here)
+    assert ((delta - rdelta).abs() < 0.1 * rdelta.abs() + 1.0).all(), (delta, rdelta)
+    # the prior term moves with |z|^2 / 2 (~900 here): 3e-2 on z is up to ~5e-2 on it, with any bf16 model
+    assert ((prior(zz) - prior(rz)).abs() < 5e-2 * rz.flatten(1).pow(2).sum(1) / 2.0).all()
+
+
 @pytest.mark.parametrize("method,last_step", [("Euler", "Mean"), ("Heun", "Tweedie"), ("Euler", "Euler")])
 def test_sample_sde_on_the_engine_vs_oracle_driven_sampler(golden_dir, method, last_step):
     g, cfg, sd, model = _next(golden_dir)

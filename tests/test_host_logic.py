@@ -284,6 +284,48 @@ def test_sde_samplers_paths_and_losses_match_reference(golden_dir):
             torch.testing.assert_close(val * torch.ones(1), torch.from_numpy(g[f"{tag}_{nm}"]), rtol=1e-5, atol=1e-6, msg=f"{tag}_{nm}")
 
 
+def _lik_field(name):
+    if name == "lin":
+        return lambda x, t, **kw: -x * (0.5 + t.view(-1, 1, 1, 1))
+    return lambda x, t, **kw: -x * (0.5 + t.view(-1, 1, 1, 1)) + 0.1 * torch.cos(3.0 * x)
+
+
+def test_likelihood_ode_matches_the_reference_run(golden_dir):
+    """Sampler.sample_ode_likelihood against (logp, z) pairs produced by the UNMODIFIED reference transport.py:393-450 under the
+    same torch seed (tests/golden/likelihood_kat.npz, oracle/make_golden.py: likelihood_kats): probe draws, reversed time, sign
+    conventions, prior_logp, tuple-state stepping.  `autograd` is the reference's own expression; `fd` (what the forward-only
+    engine gets) is exact for the linear field and O(h^2) for the cosine one."""
+    g = np.load(os.path.join(golden_dir, "likelihood_kat.npz"))
+    cases = json.loads(str(g["cases"]))
+    assert len(cases) == 12
+    x0 = torch.from_numpy(g["x0"])
+    for key, path_type, fname, method, n in cases:
+        smp = Sampler(create_transport(path_type, "velocity", None, None, None))
+        for div, tol in (("auto", 1e-5), ("fd", 1e-5 if fname == "lin" else 3e-3)):
+            torch.manual_seed(4321)
+            with torch.no_grad():
+                logp, z = smp.sample_ode_likelihood(sampling_method=method, num_steps=n, divergence=div, fd_step=2.0 ** -6)(
+                    x0.clone(), _lik_field(fname))
+            torch.testing.assert_close(z, torch.from_numpy(g[key + "_z"]), rtol=1e-5, atol=1e-6, msg=f"{key} {div}")
+            torch.testing.assert_close(logp, torch.from_numpy(g[key + "_logp"]), rtol=tol, atol=tol, msg=f"{key} {div}")
+    with pytest.raises(ValueError):
+        smp.sample_ode_likelihood(divergence="vjp")
+
+
+def test_likelihood_ode_adaptive_solver_on_the_tuple_state_closed_form():
+    """default solver of sample_ode_likelihood (dopri5) on the (x, delta_logp) tuple, mixed-norm controller: dx/dt' = x (1.5 - t),
+    div = -D (1.5 - t) -> z = x0 e, delta = -D, logp = log N(z; 0, I) + D, for any probe."""
+    x0 = torch.linspace(-1.0, 1.0, 2 * 3 * 4 * 4).view(2, 3, 4, 4) * 0.5
+    smp = Sampler(create_transport("Linear", "velocity", None, None, None))
+    for div in ("autograd", "fd"):
+        torch.manual_seed(0)
+        logp, z = smp.sample_ode_likelihood(num_steps=3, atol=1e-7, rtol=1e-6, divergence=div)(x0.clone(), _lik_field("lin"))
+        ze = x0 * math.e
+        torch.testing.assert_close(z, ze, rtol=2e-5, atol=2e-6)
+        want = -48 / 2 * math.log(2 * math.pi) - ze.flatten(1).pow(2).sum(1) / 2 + 48.0
+        torch.testing.assert_close(logp, want, rtol=2e-5, atol=1e-4)
+
+
 def test_prompt_cache_needs_the_same_unmodified_tensor_objects():
     """The engine skips the caption work when a step passes the tensors it was prepared from.  An address-based key would
     also 'hit' on a NEW prompt whose storage happens to reuse a freed block; identity + version + a kept reference cannot."""
@@ -369,9 +411,8 @@ def test_cli_plan_matches_reference_inference_conventions(tmp_path):
     cfg["infer"].update(resolution="1024x1024", proportional_attn=False)
     mk = cli.plan_inference(cfg, 1024)["model_kwargs"]
     assert (mk["scale_factor"], mk["scale_watershed"], mk["base_seqlen"], mk["proportional_attn"]) == (1.0, 1.0, None, False)
-    cfg["ode"]["likelihood"] = True
-    with pytest.raises(NotImplementedError):
-        cli.plan_inference(cfg, 1024)
+    cfg["ode"]["likelihood"] = True  # read and dropped by the reference's t2i cli (utils/cli.py:175)
+    assert cli.plan_inference(cfg, 1024)["model_kwargs"] == mk
     # Flag-DiT (lumina_t2i/utils/cli.py:204-214): base length counts the end-of-line tokens, NTK factor = token-count ratio,
     # and the optional keys are only passed when switched on
     cfg["ode"]["likelihood"] = False
@@ -430,8 +471,10 @@ def test_imagenet_driver_command_line_and_grid():
     with pytest.raises(AssertionError):
         S.parse(["ODE", "--ckpt", "/c", "--num_gpus", "2"])
     mode, a = S.parse(["ODE", "--ckpt", "/c", "--likelihood"])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match="incompatible with guidance"):  # sample.py:135 (default --cfg_scale 4)
         S.build_sample_fn(a, mode)
+    mode, a = S.parse(["ODE", "--ckpt", "/c", "--likelihood", "--cfg_scale", "1"])
+    assert callable(S.build_sample_fn(a, mode))
     # grid: torchvision.utils.save_image(nrow=8) layout - 2-pixel black frame around every tile
     imgs = torch.stack([torch.full((3, 4, 5), (i + 1) / 16.0) for i in range(11)])
     grid = S.make_grid(imgs, nrow=8)
