@@ -8,7 +8,7 @@
 #   tests[:<pytest -k expr>]   python -m pytest tests -m gpu -q -x [-k expr]          -> pytest_gpu.log
 #   bench[:<extra args>]       python bench.py <extra>                                 -> bench.json (+ one-line digest)
 #   ab:<opt>=<v0>,<v1>[,...]   interleaved same-box A/B of one lt_set_option knob, 2 rounds  -> ab_<opt>.log
-#   ablib:<path>               interleaved A/B of two builds of the library (LUMINA_DIT_LIB)  -> ab_lib.log
+#   ablib:<path>[,<path>...]   interleaved A/B of the default and other builds of the library (LUMINA_DIT_LIB)  -> ab_lib.log
 #   configs:<names>            scripts/bench_configs.py <names: cfg1 cfg3 cfg4 cfg5, space separated by '+'>
 #   opbench:<args>             scripts/opbench.py <args with '+' for spaces>
 #   prof                       rocprofv3 --kernel-trace --stats of bench.py + two --pmc passes (scripts/gpu_prof.sh)
@@ -53,7 +53,7 @@ for step in "$@"; do
         timeout 600 python bench.py --no-cpu-baseline --opt $opt=$v > $OUT/ab.tmp 2>/dev/null; digest $OUT/ab.tmp "$opt=$v" | tee -a $OUT/ab_$opt.log
       done; done ;;
     ablib)
-      for i in 1 2; do for lib in "" "$arg"; do
+      for i in 1 2; do for lib in "" ${arg//,/ }; do
         LUMINA_DIT_LIB=$lib timeout 600 python bench.py --no-cpu-baseline > $OUT/ab.tmp 2>/dev/null; digest $OUT/ab.tmp "lib=${lib:-default}" | tee -a $OUT/ab_lib.log
       done; done ;;
     configs) timeout 1200 python scripts/bench_configs.py $arg > $OUT/bench_configs.log 2>&1; echo "exit $?"; tail -12 $OUT/bench_configs.log ;;
