@@ -745,8 +745,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 // shapes exactly 3 / 1 tiles per CU.  Structure = gemm_bf16_w4p (one workgroup per CU walks its tiles; 4-slot LDS ring of 32-deep
 // slabs filled by LDS-DMA three slabs ahead, running across tile boundaries; fragments of slab g+1 read while slab g multiplies;
 // one barrier per slab; epilogue stores issued and not waited for), with these differences:
-//  * one MFMA covers the slab's whole depth (K = 32): 8 x NT MFMAs of 16 cycles per slab, one fragment read per MFMA in the first
-//    8 + NT of them, one LDS-DMA per 8 MFMAs;
+//  * one MFMA covers the slab's whole depth (K = 32): 8 x NT MFMAs of 16 cycles per slab, one fragment read per 4 MFMAs (8 + NT reads
+//    spread over the whole body since round 3: all four waves leave the barrier together, and 68 KiB of reads in the first quarter
+//    of the body queued behind each other - GEMM class +1 %, profiles/r03/bench_ab_w4q_fragment_read_spacing.log), one LDS-DMA per 8;
 //  * a 16-row fragment read (lane l: row l & 15, 16-byte chunk l >> 4 of the 64-byte row) is bank-conflict free when chunk c of row
 //    r sits at position c ^ (3 * ((r >> 3) & 1)) - on the LDS-DMA's source address and on the read (guide rule 21);
 //  * D' = W_frag x A_frag puts 4 consecutive columns of one C row in a lane; v_permlane16_swap of two neighbouring accumulator
@@ -767,10 +768,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     constexpr int PA = BM / 16, PW = BN / 16, NP = PA + PW;   // 1-KiB staging pieces (16 rows x 64 B) per slab
     constexpr int IP = (NP + NW - 1) / NW;                    // pieces per wave and slab (a surplus slot re-loads the wave's last piece)
     constexpr int SLAB = (BM + BN) * 64, W_OFF = BM * 64;
-    constexpr int NM = MT * NT, RD = MT + NT, EVERY = NM / IP;
+    constexpr int NM = MT * NT, RD = MT + NT, EVERY = NM / IP, RS = NM / RD;
     constexpr int NST = EPI != 1 ? MT * (NT / 2) + (NT % 2 ? MT : 0) : MT * (NT / 4);  // store instructions per wave and tile
     constexpr int NST_V = (MT / 2) * NT;  // ... of a V^T tile (EPI 3)
-    static_assert(NM % IP == 0 && RD <= NM, "one LDS-DMA per EVERY MFMAs, one fragment read per MFMA in the first RD");
+    static_assert(NM % IP == 0 && RS >= 1 && (RD - 1) * RS + 4 <= NM, "one LDS-DMA per EVERY MFMAs, one fragment read per RS MFMAs, the last one >= 4 MFMAs before the wait");
     static_assert(EPI != 1 || NT % 4 == 0, "SwiGLU pairs 32-column groups");
     static_assert(PA % NW == 0, "A pieces first: slot i < PA / NW is an A piece for every wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -906,8 +907,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
                 if (id < 64) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(ac[mt]), "v"(wc[nt]));
                 else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(ac[mt]), "v"(wc[nt]));
             }
-            if (i < NT) wn_[i] = *(const bf16x8*)(sb + w_row_off + i * 1024);
-            else if (i < RD) an[i - NT] = *(const bf16x8*)(sb + a_row_off + (i - NT) * 1024);
+            if (i % RS == 0 && i / RS < RD) {  // one fragment read per RS MFMAs, spread over the whole body
+                const int j = i / RS;
+                if (j < NT) wn_[j] = *(const bf16x8*)(sb + w_row_off + j * 1024);
+                else an[j - NT] = *(const bf16x8*)(sb + a_row_off + (j - NT) * 1024);
+            }
             if (i % EVERY == EVERY / 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(i / EVERY < PA / NW ? dA : dW, LDS_PTR(db + ldsoff[i / EVERY]), 16, voff[i / EVERY], d_soff, 0, 0);
             // the next body's scalar state, a few instructions under each of the last MFMAs
