@@ -99,8 +99,9 @@ const char* lt_version(void);
  *                       kernel with PV on 16x16x32 MFMAs (EXPERIMENTAL=1 builds)
  *   "gemm_variant"      0 auto tile shape (default) | 1 256x256 | 2 256x288
  *   "gemm_w4q"          1 (default): large dense GEMMs run on the persistent 4-wave 16x16x32 kernel | 0: classic / ping-pong tiles
- *   "gemm_stagger"      0 (default) .. 64: 4-wave GEMM kernels (explicit variants 10, 13, 14: EXPERIMENTAL=1 builds) spread the start
- *                       of the workgroups of an XCD over eight phases, n * ~1024 cycles apart (experiment knob)
+ *   "gemm_stagger"      0 (default) .. 256: the persistent 4-wave GEMM kernels spread the start of the workgroups of an XCD over
+ *                       eight phases, n * ~256 cycles apart (experiment knob: de-synchronises the tile-end store bursts; measured
+ *                       -0.5 % .. 0 depending on the box)
  *   "qkv_post_fused"    2 (default): one launch for q / k post-processing + V transpose below 2048 rows (launch-bound regime), three
  *                       launches above | 1 always one launch | 0 always separate launches
  *   "qk_post_pair"      1 (default): q and k post-processing share one persistent launch (>= 2048 rows) | 0: two launches

@@ -290,14 +290,14 @@ __device__ __forceinline__ void pp_barrier() {
 // use the unified-VGPR form whenever the kernel fits 256 registers, which the 8-wave kernels do; the vendor library's kernels
 // keep their accumulators in AGPRs and run ~25 % faster clocks on the same problem - profiles/r01/vendor_vs_engine_pmc.log.)
 // Experiment knob of the 4-wave kernels (variants 10, 13, 14; lt_set_option("gemm_stagger", n)): workgroup b sleeps
-// ((b >> 3) & 7) * n * ~1024 cycles before its first load, which spreads the CUs of an XCD over eight tile phases.  All tiles of
+// ((b >> 3) & 7) * n * ~256 cycles before its first load, which spreads the CUs of an XCD over eight tile phases.  All tiles of
 // a GEMM take the same time, so without it every CU of the chip is in its prologue / epilogue at the same moment; whether that
 // synchronised idle phase is what keeps the clock low is one of the next round's questions.  A __device__ word
 // instead of a GemmArgs field: the kernels of the product path do not read it and keep their argument layout.
 __device__ __forceinline__ void stagger_start(int n) {
     if (n > 0) {
         const int reps = ((blockIdx.x >> 3) & 7) * n;
-        for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(16);
+        for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(4);
     }
 }
 

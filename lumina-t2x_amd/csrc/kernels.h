@@ -144,7 +144,7 @@ void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
 void lt_set_gemm_w4q(int v);           // 1: large dense GEMMs on the persistent 16x16x32 kernel (variants 15 / 16)
 void lt_set_gemm_group(int v);          // tile rows per group in the tile order of the 16x16x32 kernel (experiment; 0 = default 4)
-int lt_set_gemm_stagger(int v);        // 4-wave kernels (variants 10, 13, 14): start-phase spread per XCD, units of ~1024 cycles (0 = off)
+int lt_set_gemm_stagger(int v);        // 4-wave kernels (variants 10, 13, 14): start-phase spread per XCD, units of ~256 cycles (0 = off)
 bool lt_gemm_has_experimental();       // built with EXPERIMENTAL=1 (variants 4-6, 9-12, trace builds, pipeline knobs)
 const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant);  // name of the kernel launch_gemm_bf16 would run
 

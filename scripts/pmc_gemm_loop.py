@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""a few launches of the engine's W1|W3 GEMM (plain epilogue) and of the vendor GEMM on the same operands, for PMC passes"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lumina_t2x_amd  # noqa: F401
+from lumina_t2x_amd import _lib
+import ctypes as C
+
+lib = _lib.load()
+M, N, K = 8192, 12288, 2304
+g = torch.Generator(device="cuda").manual_seed(0)
+A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+W = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+s = torch.cuda.current_stream().cuda_stream
+for _ in range(6):
+    _lib.check(lib.lt_op_gemm_bf16(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(None), 1, C.c_void_p(out.data_ptr()), M, N, K, 0, 15, C.c_void_p(s)), "lt_op_gemm_bf16")
+for _ in range(6):
+    torch.matmul(A, W.t(), out=out)
+torch.cuda.synchronize()
+print("done")
