@@ -756,9 +756,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 //    equal to fp32 rounding, not bit-identical to variant 1.
 // EPI 1 (SwiGLU) needs NT % 4 == 0 (w1 / w3 interleaved in 32-row groups = pairs of 16-column tiles).  K % 64 == 0, K >= 128, no bias.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-#ifndef LT_W4Q_ORDER
-#define LT_W4Q_ORDER 0
-#endif
 // TRACE (experimental build, lt_op_gemm_trace variants 15 / 16): per workgroup 8 x u64 = s_memrealtime (100 MHz) at entry | prologue
 // done | last main loop done | last epilogue issued | exit (stores acknowledged), shader clocks of the first tile's main loop,
 // HW_ID, tiles walked.
@@ -886,13 +883,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-#if LT_W4Q_ORDER == 2   // probe: the W fragment stays for MT consecutive MFMAs (default: the A fragment stays for NT)
-            const int mt = i % MT, nt = i / MT;
-#elif LT_W4Q_ORDER == 1  // probe: serpentine - exactly one operand changes from one MFMA to the next
-            const int mt = i / NT, nt = (mt & 1) ? NT - 1 - i % NT : i % NT;
-#else
             const int mt = i / NT, nt = i % NT;
-#endif
             const int id = mt * NT + nt;  // accumulator tile: the first 64 live in AGPRs
             if constexpr (FIRST && !SWAP) {
                 if (id < 64) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[mt][nt]) : "v"(wc[nt]), "v"(ac[mt]));
