@@ -215,7 +215,8 @@ int lt_op_gemm_vt(const void* A_dev, const void* W_dev, void* vt_dev, int32_t M,
                   int32_t hd, int32_t variant, void* stream);
 /* fused QKV projection (the engine's form at large M): C[M, N] gets columns [0, split) as a plain GEMM (row stride N; columns >= split
  * are left untouched), vt gets the V columns [split, N) as the transposed image of lt_op_gemm_vt.  One launch of the persistent
- * 256 x 288 kernel: split and N - split multiples of 288, tokens % 256 == 0, M % tokens == 0, K % 64 == 0, M / 256 * N / 288 >= #CUs. */
+ * kernel on 256 x 288 tiles (split and N - split multiples of 288) or, round 3, 256 x 256 tiles (multiples of 256: Flag-DiT 5B);
+ * tokens % 64 == 0 (a sample may end inside a row tile), M % tokens == 0, K % 64 == 0, ceil(M / 256) * N / tile width >= #CUs. */
 int lt_op_gemm_qkv(const void* A_dev, const void* W_dev, void* C_dev, void* vt_dev, int32_t M, int32_t N, int32_t K, int32_t split,
                    int32_t tokens, int32_t hd, void* stream);
 /* 1 if the engine runs this QKV projection as ONE launch (lt_op_gemm_qkv's conditions and the options allow it), else 0 */

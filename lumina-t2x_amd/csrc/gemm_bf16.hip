@@ -36,6 +36,7 @@ template __global__ void gemm_bf16_w4q<0, 8>(GemmArgs);           // persistent 
 template __global__ void gemm_bf16_w4q<0, 9>(GemmArgs);           // ... 256 x 288 tiles (N = 2304 / 6912: whole rounds over 256 CUs)
 template __global__ void gemm_bf16_w4q<1, 8>(GemmArgs);           // ... SwiGLU
 template __global__ void gemm_bf16_w4q<3, 9>(GemmArgs);           // ... fused QKV projection: plain tiles for Q | K, V^T tiles for V
+template __global__ void gemm_bf16_w4q<3, 8>(GemmArgs);           // ... the same on 256-wide tiles (Flag-DiT 5B: 3072-wide Q, K, V)
 template __global__ void gemm_bf16_pp<2, 4, 2, 1, 0, false, 0, 1, 4>(GemmArgs);  // 128 x 128, small-M problems, one barrier per 64-deep slab
 template __global__ void gemm_bf16_pp<4, 2, 1, 2, 1, false, 0, 1, 4>(GemmArgs);  // 128 x 128 with the SwiGLU epilogue (needs NT even)
 template __global__ void gemm_bf16_pp<2, 4, 1, 1, 0, false, 0, 1, 4>(GemmArgs);  //  64 x 128
@@ -55,17 +56,23 @@ int num_cus() {
 }
 
 
-// the fused QKV projection (epilogue 3) runs on the 256 x 288 persistent kernel only: whole tiles on both sides of the split, a
-// 256-row tile inside one sample, at least one tile per CU, offsets that fit the buffer instructions' 32-bit arithmetic
-bool gemm_qkv_fusable(const GemmArgs& a) {
-    if (a.tile_expert || a.trace || a.bias_dtype >= 0 || a.K % 64 != 0 || a.K < 128 || !a.VT) return false;
-    if (a.vt_split <= 0 || a.vt_split % 288 != 0 || a.N <= a.vt_split || (a.N - a.vt_split) % 288 != 0) return false;
-    if (a.vt_hd <= 0 || (a.N - a.vt_split) % a.vt_hd != 0 || a.vt_tokens <= 0 || a.vt_tokens % 256 != 0 || a.M % a.vt_tokens != 0) return false;
-    if (a.vt_npad != a.vt_tokens) return false;
-    if (255LL * a.ldc * 2 + (long long)a.N * 2 >= 0x7fffffffLL) return false;
-    if ((long long)a.M * (a.N - a.vt_split) * 2 >= 0x7fffffffLL) return false;
-    return (long long)(a.M / 256) * (a.N / 288) >= num_cus();
+// the fused QKV projection (epilogue 3) runs on the persistent kernel only: whole 288- or 256-wide tiles on both sides of the split,
+// a 32-row pair of V^T tiles inside one sample, at least one tile per CU, offsets that fit the buffer instructions' 32-bit arithmetic.
+// Returns the tile width (288 / 256) or 0.
+int gemm_qkv_fused_tile(const GemmArgs& a) {
+    if (a.tile_expert || a.trace || a.bias_dtype >= 0 || a.K % 64 != 0 || a.K < 128 || !a.VT) return 0;
+    if (a.vt_split <= 0 || a.N <= a.vt_split) return 0;
+    int bn = 0;
+    if (a.vt_split % 288 == 0 && (a.N - a.vt_split) % 288 == 0) bn = 288;
+    else if (a.vt_split % 256 == 0 && (a.N - a.vt_split) % 256 == 0) bn = 256;
+    else return 0;
+    if (a.vt_hd <= 0 || (a.N - a.vt_split) % a.vt_hd != 0 || a.vt_tokens <= 0 || a.vt_tokens % 64 != 0 || a.M % a.vt_tokens != 0) return 0;
+    if (a.vt_npad != a.vt_tokens) return 0;
+    if (255LL * a.ldc * 2 + (long long)a.N * 2 >= 0x7fffffffLL) return 0;
+    if ((long long)a.M * (a.N - a.vt_split) * 2 >= 0x7fffffffLL) return 0;
+    return (long long)((a.M + 255) / 256) * (a.N / bn) >= num_cus() ? bn : 0;
 }
+bool gemm_qkv_fusable(const GemmArgs& a) { return gemm_qkv_fused_tile(a) != 0; }
 
 namespace {
 using lt_gemm::gemm_bf16_tn;
@@ -135,7 +142,7 @@ int launch_w4q(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
 // ---- kernel selection (one place: launch_gemm_bf16 launches what choose() names, lt_gemm_describe prints it) -------------
 enum GemmKernel {
     GK_TN256, GK_TN288, GK_TN256_VT, GK_TN288_VT, GK_TN256_SWIGLU, GK_PP256, GK_PP256_SWIGLU,
-    GK_S128, GK_S128_SWIGLU, GK_S64, GK_W4Q256, GK_W4Q288, GK_W4Q256_SWIGLU, GK_W4Q288_QKV, GK_EXPERIMENTAL, GK_NONE
+    GK_S128, GK_S128_SWIGLU, GK_S64, GK_W4Q256, GK_W4Q288, GK_W4Q256_SWIGLU, GK_W4Q288_QKV, GK_W4Q256_QKV, GK_EXPERIMENTAL, GK_NONE
 };
 const char* const kGemmKernelName[] = {
     "gemm_bf16_tn<2,4,4,2,0> (256x256, 8 waves)", "gemm_bf16_tn<4,3,2,3,0> (256x288, 12 waves)",
@@ -145,7 +152,8 @@ const char* const kGemmKernelName[] = {
     "gemm_bf16_pp<2,4,2,1,0,..,1,4> (128x128)", "gemm_bf16_pp<4,2,1,2,1,..,1,4> (128x128, SwiGLU)",
     "gemm_bf16_pp<2,4,1,1,0,..,1,4> (64x128)", "gemm_bf16_w4q<0,8> (persistent 4 waves, 16x16x32 MFMA, 256x256)",
     "gemm_bf16_w4q<0,9> (persistent 4 waves, 16x16x32 MFMA, 256x288)", "gemm_bf16_w4q<1,8> (persistent 4 waves, 16x16x32 MFMA, 256x256, SwiGLU)",
-    "gemm_bf16_w4q<3,9> (persistent 4 waves, 16x16x32 MFMA, 256x288, fused QKV: plain Q|K tiles + V^T tiles)", "experimental", "none"};
+    "gemm_bf16_w4q<3,9> (persistent 4 waves, 16x16x32 MFMA, 256x288, fused QKV: plain Q|K tiles + V^T tiles)",
+    "gemm_bf16_w4q<3,8> (persistent 4 waves, 16x16x32 MFMA, 256x256, fused QKV: plain Q|K tiles + V^T tiles)", "experimental", "none"};
 
 int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 256x256, 2 = 256x288
 int g_gemm_stagger = 0;
@@ -159,7 +167,7 @@ int g_gemm_w4q = 1;  // 1 (default): large dense GEMMs (>= one tile per CU) run 
 GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     const bool w4p_ok = !a.tile_expert && !a.trace && a.bias_dtype < 0 && a.K % 64 == 0 && a.K >= 128 &&
                         255LL * a.ldc * 2 + (long long)a.N * 2 < 0x7fffffffLL && epilogue != 2;
-    if (epilogue == 3) return gemm_qkv_fusable(a) ? GK_W4Q288_QKV : GK_NONE;
+    if (epilogue == 3) { const int bn = gemm_qkv_fused_tile(a); return bn == 288 ? GK_W4Q288_QKV : bn == 256 ? GK_W4Q256_QKV : GK_NONE; }
     if (a.trace) return GK_EXPERIMENTAL;
     if (variant == 15 || variant == 16) {
         if (!w4p_ok || (epilogue == 1 && variant == 16)) return GK_NONE;
@@ -230,7 +238,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
     LT_REQUIRE(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm: unknown epilogue %d", epilogue);
-    LT_REQUIRE(epilogue != 3 || gemm_qkv_fusable(a), "gemm: the fused QKV epilogue needs 288-column tiles on both sides of the split and 256-row tiles inside a sample");
+    LT_REQUIRE(epilogue != 3 || gemm_qkv_fusable(a), "gemm: the fused QKV epilogue needs whole 288- or 256-column tiles on both sides of the split, tokens per sample %% 64 == 0 and at least one tile per CU");
     if (epilogue == 2) {
         LT_REQUIRE(a.bias_dtype < 0 && !a.tile_expert && !a.trace, "gemm: the V^T epilogue takes dense problems without bias");
         LT_REQUIRE(a.vt_hd > 0 && a.vt_hd % 8 == 0 && a.N % a.vt_hd == 0, "gemm: V^T epilogue: N=%d must be whole heads of vt_hd=%d", a.N, a.vt_hd);
@@ -262,6 +270,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         case GK_W4Q288: return launch_w4q<0, 9>(a, stream, ev0, ev1);
         case GK_W4Q256_SWIGLU: return launch_w4q<1, 8>(a, stream, ev0, ev1);
         case GK_W4Q288_QKV: return launch_w4q<3, 9>(a, stream, ev0, ev1);
+        case GK_W4Q256_QKV: return launch_w4q<3, 8>(a, stream, ev0, ev1);
         case GK_EXPERIMENTAL:
 #ifdef LT_EXPERIMENTAL
             return launch_gemm_experimental(a, epilogue, variant, stream, ev0, ev1);

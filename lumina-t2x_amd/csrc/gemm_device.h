@@ -990,17 +990,24 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     // attention kernels (AttnArgs::vt; positions inside every group of 16 tokens: 0-3, 8-11, 4-7, 12-15).  After the swapped MFMAs a
     // lane holds, per 16x16 accumulator tile, column l15 and rows 4 q4 + r = one quad of the group.  v_permlane32_swap of two row
     // tiles' packed registers puts quads (0, 2) resp. (1, 3) of ONE tile side by side: 8 consecutive positions = one 16-byte store.
-    // A 256-row tile lies inside one sample (tokens per sample % 256 == 0, launcher).
     auto store_vt = [&](const Tile& t) __attribute__((always_inline)) {
         const int hd = p.vt_hd, kvh = (p.N - p.vt_split) / hd;
-        const int b = t.m0 / p.vt_tokens, tok0 = t.m0 - b * p.vt_tokens + wm * (MT * 16);
         const long long vt_all = (long long)(p.M / p.vt_tokens) * kvh * hd * p.vt_npad * 2;
         const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)p.VT, 0, (int)(vt_all > 0x7fffffffLL ? 0x7fffffffLL : vt_all), 0x00020000);
+        // a pair of 16-row tiles = 32 consecutive tokens lies inside one sample (tokens per sample % 32 == 0, launcher), the 256-row
+        // tile need not (Flag-DiT: 4160 tokens per sample); rows past M land past the image's last sample = outside num_records
+        int pair_off[MT / 2];
+#pragma unroll
+        for (int mp = 0; mp < MT / 2; ++mp) {
+            const int r = t.m0 + wm * (MT * 16) + mp * 32;
+            const int b = r / p.vt_tokens;
+            pair_off[mp] = (b * kvh * hd * p.vt_npad + (r - b * p.vt_tokens)) * 2;  // bytes (< 2^31: launcher)
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int c = t.n0 - p.vt_split + wn * (NT * 16) + nt * 16 + l15;
             const int head = c / hd, d = c - head * hd;
-            const int row_off = (((b * kvh + head) * hd + d) * p.vt_npad + tok0 + (q4 >> 1) * 16 + (q4 & 1) * 8) * 2;  // bytes (< 2^31: launcher)
+            const int col_off = ((head * hd + d) * p.vt_npad + (q4 >> 1) * 16 + (q4 & 1) * 8) * 2;
 #pragma unroll
             for (int mp = 0; mp < MT / 2; ++mp) {
                 const f32x4 a = acc[2 * mp][nt], bb = acc[2 * mp + 1][nt];
@@ -1010,7 +1017,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
                 auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                 // lane rows 0 / 1: row tile 2 mp, positions 0-7 / 8-15; lane rows 2 / 3: row tile 2 mp + 1
                 const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                __builtin_amdgcn_raw_buffer_store_b128(o, rV, row_off + mp * 64, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rV, col_off + pair_off[mp], 0, 0);
             }
         }
     };

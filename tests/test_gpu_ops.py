@@ -346,11 +346,14 @@ def test_gemm_vt_epilogue_matches_gemm_plus_transpose(tokens, B, kvh, hd, K, var
     assert torch.all(buf[:guard] == 7.0) and torch.all(buf[-guard:] == 7.0), "stray store outside the V^T image"
 
 
-@pytest.mark.parametrize("tokens,B,H,Hkv,hd,K", [(4096, 2, 32, 32, 72, 2304), (4096, 2, 32, 8, 72, 2304), (1024, 8, 16, 16, 72, 1152), (16384, 1, 32, 8, 72, 256)])
+@pytest.mark.parametrize("tokens,B,H,Hkv,hd,K", [(4096, 2, 32, 32, 72, 2304), (4096, 2, 32, 8, 72, 2304), (1024, 8, 16, 16, 72, 1152), (16384, 1, 32, 8, 72, 256),
+                                                 (4160, 2, 32, 32, 96, 3072), (320, 16, 16, 16, 96, 256), (320, 24, 16, 16, 72, 192)])
 def test_gemm_fused_qkv_matches_separate_launches(tokens, B, H, Hkv, hd, K):
-    """one launch of the persistent 256 x 288 kernel for the whole QKV projection (lt_op_gemm_qkv: plain tiles for the Q | K columns,
-    swapped-operand V^T tiles for the V columns) against the same kernel run as a plain GEMM + lt_op_v_transpose: identical MFMA
-    sequences per output element -> bit-identical; MHA and GQA splits, several tiles per CU, short K"""
+    """one launch of the persistent 256 x 288 (or 256 x 256: Flag-DiT's 3072-wide Q, K, V) kernel for the whole QKV projection
+    (lt_op_gemm_qkv: plain tiles for the Q | K columns, swapped-operand V^T tiles for the V columns) against the same kernel run as a
+    plain GEMM + lt_op_v_transpose: identical MFMA sequences per output element -> bit-identical; MHA and GQA splits, several tiles
+    per CU, short K; round 3: samples that end inside a 256-row tile (4160 = Flag-DiT's 64 x 65 tokens, 320) and a ragged last
+    row tile (M = 8320)"""
     d, dkv = H * hd, Hkv * hd
     M, N, split = B * tokens, H * hd + 2 * Hkv * hd, H * hd + Hkv * hd
     g = torch.Generator().manual_seed(tokens + Hkv)
