@@ -376,3 +376,51 @@ def test_imagenet_sample_driver_with_injected_decoder(golden_dir, tmp_path, mode
         z = torch.cat([z, z], 0)
     want = fn(z, model.forward_with_cfg, y=y, cfg_scale=4.0)[-1].chunk(2, dim=0)[0]
     assert torch.equal(decoded[0], want / 0.18215)
+
+
+def test_imagenet_sample_driver_likelihood_flag(golden_dir, tmp_path):
+    """`sample.py ODE --likelihood --cfg_scale 1` (reference Next-DiT-ImageNet/sample.py:134-141, :186): the run integrates the
+    likelihood ODE and, like the reference, hands `[-1]` of the returned (logp, z) pair - the latent carried to the noise end - to
+    the decoder.  Here: the driver's decoded latents equal a direct sample_ode_likelihood call under the same seeds (the engine
+    takes the divergence by central differences), and guidance != 1 is refused with the reference's message."""
+    import argparse
+
+    from lumina_t2x_amd import sample_imagenet as S
+
+    cfg, seed_w, image_size = synth.NextDiTConfig(dim=384, n_layers=2, n_heads=8, family="imagenet", num_classes=1000), 21, 32
+    kw = cfg.ctor_kwargs()
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    torch.save({k: v.contiguous() for k, v in synth.synth_state_dict(cfg, seed=seed_w).items()}, str(ck / "consolidated_ema.00-of-01.pth"))
+    torch.save(argparse.Namespace(model="DiT_Llama_tiny_test", qk_norm=cfg.qk_norm, image_size=image_size, num_classes=1000, vae="ema"),
+               str(ck / "model_args.pth"))
+    S.models.__dict__["DiT_Llama_tiny_test"] = lambda **over: models.imagenet.DiT_Llama(**{**kw, **over})
+    decoded = []
+
+    def decode(lat):
+        decoded.append(lat.clone())
+        return torch.tanh(lat[:, :3].float())
+
+    labels = [3, 207]
+    base = ["ODE", "--ckpt", str(ck), "--class_labels"] + [str(v) for v in labels] + ["--precision", "fp32", "--num_sampling_steps", "4", "--seed", "9",
+                                                                                     "--image_save_path", str(tmp_path / "grid.png"),
+                                                                                     "--sampling-method", "euler", "--likelihood"]
+    try:
+        mode_, args = S.parse(base)  # default --cfg_scale 4
+        with pytest.raises(AssertionError, match="incompatible with guidance"):
+            S.run(args, mode_, decode_fn=decode)
+        mode_, args = S.parse(base + ["--cfg_scale", "1"])
+        out = S.run(args, mode_, decode_fn=decode)
+    finally:
+        del S.models.__dict__["DiT_Llama_tiny_test"]
+    assert os.path.exists(out) and len(decoded) == 1 and decoded[0].shape[0] == 2
+    model = _build(models.imagenet.DiT_Llama, cfg, seed_w).float()
+    torch.manual_seed(9)
+    n, ls = len(labels), image_size // 4
+    z = torch.randn(n, 4, ls, ls, dtype=torch.float32, device="cuda")
+    z = torch.cat([z, z], 0)
+    y = torch.cat([torch.tensor(labels, device="cuda"), torch.tensor([1000] * n, device="cuda")], 0)
+    fn = Sampler(create_transport("Linear", "velocity", None, None, None)).sample_ode_likelihood(sampling_method="euler", num_steps=4, atol=1e-6, rtol=1e-3)
+    logp, zT = fn(z, model.forward_with_cfg, y=y, cfg_scale=1.0)
+    assert logp.shape == (2 * n,) and torch.isfinite(logp).all()
+    assert torch.equal(decoded[0], zT.chunk(2, dim=0)[0] / 0.18215)
