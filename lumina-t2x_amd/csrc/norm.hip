@@ -23,6 +23,7 @@ struct RowRaw {
     bf8_t c[MAXCH];
 };
 
+typedef __attribute__((ext_vector_type(4))) unsigned nt_u32x4;
 template <int MAXCH>
 __device__ __forceinline__ void load_row(const u16* row, int nch, int lane, RowRaw<MAXCH>& r) {
 #pragma unroll
@@ -148,7 +149,10 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
                 }
                 r.c[i].w[k] = pk_bf(unpk_bf(xr.c[i].w[k]) + yn);
             }
-            *(bf8_t*)(xrow + ch * 8) = r.c[i];
+            // the residual stream is not read again before the next row kernel (a GEMM or two and the attention later): stored
+            // non-temporal, so that it does not push the pre-norm output - the next GEMM's A operand - out of the L2 / MALL
+            // (step -0.2 %, four of four same-box pairs: profiles/r03/bench_ab_residual_stream_nontemporal_store.log)
+            { const nt_u32x4 v = {r.c[i].w[0], r.c[i].w[1], r.c[i].w[2], r.c[i].w[3]}; __builtin_nontemporal_store(v, (nt_u32x4*)(xrow + ch * 8)); }
         }
     }
     if (next_mode == 0) return;
