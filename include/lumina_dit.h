@@ -231,7 +231,8 @@ int lt_op_gemm_grouped(const void* A_dev, const void* W_dev, const void* tile_ex
                        void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* stream);
 /* the same with gather-on-load (round 3: how the engine runs the experts' W1 | W3 GEMM - no gather pass, no expert-sorted copy of
  * the FFN input): row m of the problem is row row_map_dev[m] (int32 [M]) of A_dev [a_rows, K]; -1 = a padding row that reads as
- * zero.  Ping-pong tile kernels only (variant 0 picks one for grouped problems; explicit 3 / 7 / 8). */
+ * zero.  Ping-pong tile kernels (explicit 3 / 7 / 8) and the grouped mode of the persistent 16x16x32 kernel (explicit 15; K >= 256, all of A
+ * below 2^30 bytes, at most 1024 row segments); variant 0 picks the persistent kernel from two 256 x 256 tiles per CU on. */
 int lt_op_gemm_grouped_gather(const void* A_dev, int32_t a_rows, const void* row_map_dev, const void* W_dev, const void* tile_expert_dev,
                               int64_t w_expert_stride, void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
                               void* stream);

@@ -993,11 +993,9 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
         return launch_attention_v4_hd96(a, stream);
     if (g_attn_variant >= 3 && (a.hd == 72 || a.hd == 96) && a.bias == nullptr && !a.accumulate) {
         constexpr int SMEM72 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16, SMEM96 = 4 * (96 * 128) + 4 * (64 * 96 * 2) + 16;
-        static bool attr_done = false;
-        if (!attr_done) {
+        if (!func_attr_done(device_slot(), (const void*)attn_fwd_kernel_v3<72>)) {  // per (device, kernel)
             LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<72>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM72));
             LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<96>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM96));
-            attr_done = true;
         }
         const int nqb3 = (a.N + 255) / 256;
         if (a.trace) {

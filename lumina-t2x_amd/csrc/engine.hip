@@ -1336,6 +1336,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }
+    if (strcmp(name, "gemm_w4q_grouped") == 0) { lt_set_gemm_w4q_grouped(value != 0); return 0; }
     if (strcmp(name, "gemm_group") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_group must be 0..64"); lt_set_gemm_group(value); return 0; }
     if (strcmp(name, "gemm_stagger") == 0) { LT_REQUIRE(value >= 0 && value <= 256, "gemm_stagger must be 0..256"); return lt_set_gemm_stagger(value); }
     if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }

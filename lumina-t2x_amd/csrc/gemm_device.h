@@ -759,7 +759,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 // TRACE (experimental build, lt_op_gemm_trace variants 15 / 16): per workgroup 8 x u64 = s_memrealtime (100 MHz) at entry | prologue
 // done | last main loop done | last epilogue issued | exit (stores acknowledged), shader clocks of the first tile's main loop,
 // HW_ID, tiles walked.
-template <int EPI, int NW16, bool TRACE = false>
+// GROUPED (round 4; the experts' GEMMs of Next-DiT-MoE at 1024^2, Next-DiT-MoE/models/models2.py:459-506 - 16 384 routed rows per MoE
+// FFN is the MFMA-bound regime): the persistent walk runs over the VALID row tiles only (tile_expert[tm] >= 0, compacted into an LDS
+// list once per workgroup), every tile multiplies with W + tile_expert[tm] * w_expert_stride, and - gather-on-load, a_row_map - row r
+// of a tile is row a_row_map[m0 + r] of A (-1: reads as zero).  The A stream then goes through ONE descriptor over all of A with
+// per-tile lane offsets; the 256 map entries of the tile after next are fetched by a 4-byte LDS-DMA at every tile boundary (counted
+// in the hand-kept vmcnt like the slabs) and turned into lane offsets where the DMA stream crosses into that tile.  K >= 256.
+template <int EPI, int NW16, bool TRACE = false, bool GROUPED = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     constexpr int MT = 8, NT = NW16, NW = 4, BM = 256, BN = 2 * NW16 * 16;
     constexpr int PA = BM / 16, PW = BN / 16, NP = PA + PW;   // 1-KiB staging pieces (16 rows x 64 B) per slab
@@ -777,7 +783,28 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, q4 = lane >> 4;
-    const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    const int TMall = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
+    int TM = TMall;
+    // GROUPED: behind the slab ring - two 1-KiB slots of gather-map entries (tile parity), the list of valid row tiles (<= 1024) + count
+    char* const g_map = smem + 4 * SLAB;
+    int* const g_list = (int*)(smem + 4 * SLAB + 2048);
+    const bool gather = GROUPED && p.a_row_map != nullptr;
+    if constexpr (GROUPED) {
+        if (wave == 0) {
+            int cnt = 0;
+            for (int base = 0; base < TMall; base += 64) {
+                const int idx = base + lane;
+                const int ex = idx < TMall ? p.tile_expert[idx] : -1;
+                const bool ok = ex >= 0;
+                const unsigned long long b = __ballot(ok);
+                if (ok) g_list[cnt + __popcll(b & ((1ull << lane) - 1ull))] = idx | (ex << 16);  // row tile | its expert
+                cnt += __popcll(b);
+            }
+            if (lane == 0) g_list[1024] = cnt;
+        }
+        __syncthreads();
+        TM = __builtin_amdgcn_readfirstlane(g_list[1024]);
+    }
     const int ntiles = TM * TN;
     const int ns = p.K / 32;
     unsigned long long tr_entry = 0, tr_pro = 0, tr_loop = 0, tr_epi = 0, tr_clk = 0;
@@ -802,12 +829,22 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     auto setup = [&](int v) __attribute__((always_inline)) {
         int tm, tn;
         tile_coords(v, ntiles, TM, TN, tm, tn, p.group_rows > 0 ? p.group_rows : 4);
+        const u16* wbase = p.W;
+        if constexpr (GROUPED) {
+            // (from LDS, not from the table in memory: a global load at a tile boundary is followed by s_waitcnt vmcnt(0) = a drain of
+            //  the slabs in flight and of the epilogue's stores; readfirstlane: a W descriptor derived from a VGPR costs a waterfall
+            //  loop around every LDS-DMA)
+            const int e = __builtin_amdgcn_readfirstlane(g_list[tm]);
+            tm = e & 0xffff;
+            wbase += (size_t)(e >> 16) * p.w_expert_stride;
+        }
         const int m0 = tm * BM, n0_ = tn * BN;
-        const long long a_left = (long long)(p.M - m0) * p.lda * 2;
+        // GROUPED: one descriptor over ALL of A (the lanes' offsets carry the rows: a_row_map[m0 + r] or m0 + r)
+        const long long a_left = GROUPED ? (long long)(p.a_row_map ? p.a_map_rows : p.M) * p.lda * 2 : (long long)(p.M - m0) * p.lda * 2;
         const long long w_left = (long long)(p.N - n0_) * p.ldw * 2;
         const long long c_left = (long long)(p.M - m0) * p.ldc * 2;
         Tile t;
-        t.a = p.A + (size_t)m0 * p.lda; t.w = p.W + (size_t)n0_ * p.ldw; t.c = p.C + (size_t)m0 * p.ldc;
+        t.a = GROUPED ? p.A : p.A + (size_t)m0 * p.lda; t.w = wbase + (size_t)n0_ * p.ldw; t.c = p.C + (size_t)m0 * p.ldc;
         t.a_bytes = (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left);
         t.w_bytes = (int)(w_left > 0x7fffffffLL ? 0x7fffffffLL : w_left);
         t.c_bytes = (int)(c_left > 0x7fffffffLL ? 0x7fffffffLL : c_left);
@@ -832,14 +869,50 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     bool has_next = v + (int)gridDim.x < ntiles;
     Tile nxt = has_next ? setup(v + gridDim.x) : t_null;
 
+    // GROUPED: byte offsets of this lane's four A-piece rows in the tile the DMA stream is in (ga) - dense: voff[0..3], tile-invariant
+    constexpr int NGA = PA / NW;
+    int ga[NGA];
+    // (the lane id comes from lane_now(): an opaque, fresh value - terms derived from the kernel's `lane` were hoisted out of the tile
+    //  loop, spilled, and re-loaded from scratch in every tile's first body with an s_waitcnt vmcnt(0) behind the re-load)
+    auto lane_now = [&]() __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    auto ga_of_tile = [&](const Tile& t, const int* map, int (&o)[NGA]) __attribute__((always_inline)) {  // map: the tile's 256 entries, or null
+        const int ln = lane_now();
+        const int swz = ((ln & 3) ^ (((ln >> 5) & 1) * 3)) * 16;
+#pragma unroll
+        for (int i = 0; i < NGA; ++i) {
+            const int r = 16 * (wave + NW * i) + (ln >> 2);
+            const int src = t.c_bytes == 0 ? -1 : (map ? map[r] : t.m0 + r);  // the null tile behind the last one: every lane out of range
+            o[i] = (src >= 0 ? src * p.lda * 2 : 0x40000000) + swz;
+        }
+    };
+    // GROUPED: ONE loop-invariant descriptor over all of A (< 2^30 bytes, launcher) - a descriptor carried from tile to tile ended up in
+    // VGPRs here (four waterfall loops per slab)
+    const __amdgpu_buffer_rsrc_t gA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, GROUPED ? (p.a_row_map ? p.a_map_rows : p.M) * p.lda * 2 : 0, 0x00020000);
+    // the 256 gather-map entries of tile `t` -> LDS slot `slot` (one 4-byte LDS-DMA per wave: 64 entries); a null tile reads nothing
+    auto map_dma = [&](const Tile& t, int slot, bool real) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a_row_map + t.m0), 0, real ? 1024 : 0, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rM, LDS_PTR(g_map + slot * 1024 + wave * 256), 4, (wave * 64 + lane_now()) * 4, 0, 0, 0);
+    };
+    if constexpr (GROUPED) {
+        ga_of_tile(cur, gather ? p.a_row_map + cur.m0 : nullptr, ga);  // (plain loads: the compiler waits for them right here)
+        if (gather) map_dma(nxt, 1, has_next);  // oldest vmcnt entry of the prologue: every wait below covers it
+    } else {
+#pragma unroll
+        for (int i = 0; i < NGA; ++i) ga[i] = voff[i];
+    }
+    int map_slot = 1;  // LDS slot holding the map of the tile AFTER the one the DMA stream is in
     auto stage_from = [&](int g, int slab_in_tile, const Tile& t) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)t.a, 0, t.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rA = GROUPED ? gA : __builtin_amdgcn_make_buffer_rsrc((void*)t.a, 0, t.a_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)t.w, 0, t.w_bytes, 0x00020000);
         char* base = smem + (g & 3) * SLAB;
         const int soff = slab_in_tile * 64;
 #pragma unroll
         for (int i = 0; i < IP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, voff[i], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, i < NGA ? ga[i] : voff[i], soff, 0, 0);
     };
     stagger_start(p.stagger);
     // prologue (once per workgroup): slabs 0..2 in flight, slab 0 read into the first fragment set, slab 1 landed and visible
@@ -880,6 +953,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         char* db = smem + wr_off;
         int n_rd = rd_off, n_wr = wr_off, n_soff = d_soff;
         __amdgpu_buffer_rsrc_t nA = dA, nW = dW;
+        int n_ga[NGA];
+#pragma unroll
+        for (int i = 0; i < NGA; ++i) n_ga[i] = ga[i];
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
@@ -904,26 +980,34 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
                 else an[j - NT] = *(const bf16x8*)(sb + a_row_off + (j - NT) * 1024);
             }
             if (i % EVERY == EVERY / 2)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(i / EVERY < PA / NW ? dA : dW, LDS_PTR(db + ldsoff[i / EVERY]), 16, voff[i / EVERY], d_soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(i / EVERY < PA / NW ? (GROUPED ? gA : dA) : dW, LDS_PTR(db + ldsoff[i / EVERY]), 16,
+                                                         i / EVERY < NGA ? ga[i / EVERY < NGA ? i / EVERY : 0] : voff[i / EVERY], d_soff, 0, 0);
             // the next body's scalar state, a few instructions under each of the last MFMAs
             if (i == NM - 4) { n_rd = rd_off + SLAB; n_rd = n_rd == 4 * SLAB ? 0 : n_rd; }
             if (i == NM - 3) { n_wr = wr_off + SLAB; n_wr = n_wr == 4 * SLAB ? 0 : n_wr; n_soff = d_soff + 64; }
             if (i == NM - 2) {
                 if (n_soff == kbytes) {  // the DMA stream moves on to the next tile (its last three slabs ride in this tile's bodies)
                     n_soff = 0;
-                    nA = __builtin_amdgcn_make_buffer_rsrc((void*)nxt.a, 0, nxt.a_bytes, 0x00020000);
+                    if constexpr (!GROUPED) nA = __builtin_amdgcn_make_buffer_rsrc((void*)nxt.a, 0, nxt.a_bytes, 0x00020000);
                     nW = __builtin_amdgcn_make_buffer_rsrc((void*)nxt.w, 0, nxt.w_bytes, 0x00020000);
+                    // GROUPED: the next tile's lane offsets (its map entries landed in LDS >= 2 barriers ago: K >= 256, launcher)
+                    if constexpr (GROUPED) ga_of_tile(nxt, gather ? (const int*)(g_map + map_slot * 1024) : nullptr, n_ga);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
         rd_off = n_rd; wr_off = n_wr; d_soff = n_soff; dA = nA; dW = nW;
+        if constexpr (GROUPED) {
+#pragma unroll
+            for (int i = 0; i < NGA; ++i) ga[i] = n_ga[i];
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): slab g+1's fragments are in registers
         // slab g+2 landed; still allowed in flight: this body's IP DMAs and, right after a tile boundary, the NST stores issued
         // between slab g+2's DMAs and them (loads and stores retire in issue order, one counter)
         if constexpr (FIRST) {
-            if (after_epilogue == 1) wait_vmcnt<IP + NST>();
+            if (GROUPED && after_epilogue == 1 && gather) wait_vmcnt<IP + NST + 1>();  // + the map LDS-DMA issued behind the stores
+            else if (after_epilogue == 1) wait_vmcnt<IP + NST>();
             else if (EPI == 3 && after_epilogue == 2) wait_vmcnt<IP + NST_V>();
             else wait_vmcnt<IP>();
             after_epilogue = 0;
@@ -935,8 +1019,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     // epilogue through the tile's C descriptor (rows past M fall outside num_records, columns past N get an out-of-range offset):
     // every wave issues exactly NST store instructions per tile.  Lane holds, per 16x16 accumulator tile, C row l15 and columns
     // 4 q4 + r (register r).
+    // (round 4) The epilogues take their lane coordinates from a fresh, opaque lane id: derived from the kernel's `lane` the compiler
+    // hoisted the tile-invariant address terms out of the tile loop, spilled them (the main loop owns all 512 registers) and
+    // re-loaded them from scratch here - and a scratch re-load is followed by s_waitcnt vmcnt(0), i.e. by a drain of the next tile's
+    // three slabs in flight AND of every store this epilogue has issued so far ("stores issued and not waited for" was not true).
+    // (lane_now(): defined above, next to the grouped mode's lane offsets)
     auto store_out = [&](const Tile& t) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)t.c, 0, t.c_bytes, 0x00020000);
+        const int lane_e = lane_now(), l15 = lane_e & 15, q4 = lane_e >> 4;  // shadow the kernel-scope values
         const int nbase = t.n0 + wn * (NT * 16);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -994,6 +1084,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         const int hd = p.vt_hd, kvh = (p.N - p.vt_split) / hd;
         const long long vt_all = (long long)(p.M / p.vt_tokens) * kvh * hd * p.vt_npad * 2;
         const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)p.VT, 0, (int)(vt_all > 0x7fffffffLL ? 0x7fffffffLL : vt_all), 0x00020000);
+        const int lane_e = lane_now(), l15 = lane_e & 15, q4 = lane_e >> 4;  // (see store_out)
         // a pair of 16-row tiles = 32 consecutive tokens lies inside one sample (tokens per sample % 32 == 0, launcher), the 256-row
         // tile need not (Flag-DiT: 4160 tokens per sample); rows past M land past the image's last sample = outside num_records
         int pair_off[MT / 2];
@@ -1028,6 +1119,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             has_next = v + (int)gridDim.x < ntiles;
             nxt = has_next ? setup(v + gridDim.x) : t_null;
         }
+        if constexpr (GROUPED) {
+            if (gather) {  // the new nxt's map -> the slot the stream's crossing into `cur` has just finished with
+                map_slot ^= 1;
+                map_dma(nxt, map_slot, has_next);
+            }
+        }
     };
     // one tile: slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
     auto run_tile = [&](auto swap_tag) __attribute__((always_inline)) {
@@ -1038,20 +1135,36 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             body(std::false_type{}, swap_tag, wf2, af2, wf, af);
         }
     };
-    for (int t = 0; t < my_tiles; ++t) {
-        if (EPI == 3 && cur.n0 >= p.vt_split) {
-            run_tile(std::true_type{});
-            if constexpr (TRACE) { tr_loop = __builtin_amdgcn_s_memrealtime(); if (t == 0) tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
-            if constexpr (EPI == 3) store_vt(cur);
-            after_epilogue = 2;
-        } else {
-            run_tile(std::false_type{});
-            if constexpr (TRACE) { tr_loop = __builtin_amdgcn_s_memrealtime(); if (t == 0) tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
-            store_out(cur);
-            after_epilogue = 1;
-        }
+    // EPI 3: runs of plain tiles and runs of V^T tiles are two separate inner loops.  (As one loop with an if / else per tile the two
+    // bodies met at a join in EVERY iteration and the register allocator reconciled their fragment-register assignments through
+    // scratch: 68 VGPRs stored after every plain tile's second body and re-loaded - with an s_waitcnt vmcnt(0) behind them - before
+    // every V^T tile, profiles/r03 VERDICT.  Now a reconciliation can only sit on the edge between two runs; at cfg 2 a
+    // workgroup's tiles are Q, K, V in this order: one edge per launch.)
+    int t = 0;
+    auto plain_tile = [&]() __attribute__((always_inline)) {
+        run_tile(std::false_type{});
+        if constexpr (TRACE) { tr_loop = __builtin_amdgcn_s_memrealtime(); if (t == 0) tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
+        store_out(cur);
+        after_epilogue = 1;
         if constexpr (TRACE) tr_epi = __builtin_amdgcn_s_memrealtime();
         advance();
+        ++t;
+    };
+    if constexpr (EPI == 3) {
+        while (t < my_tiles) {
+            while (t < my_tiles && cur.n0 < p.vt_split) plain_tile();
+            while (t < my_tiles && cur.n0 >= p.vt_split) {
+                run_tile(std::true_type{});
+                if constexpr (TRACE) { tr_loop = __builtin_amdgcn_s_memrealtime(); if (t == 0) tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
+                store_vt(cur);
+                after_epilogue = 2;
+                if constexpr (TRACE) tr_epi = __builtin_amdgcn_s_memrealtime();
+                advance();
+                ++t;
+            }
+        }
+    } else {
+        while (t < my_tiles) plain_tile();
     }
     wait_vmcnt<0>();  // no LDS-DMA (the null ones of the last bodies included) may outlive the workgroup's LDS allocation
     if constexpr (TRACE) {

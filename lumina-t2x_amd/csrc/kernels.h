@@ -143,6 +143,9 @@ bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attent
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
 void lt_set_gemm_w4q(int v);           // 1: large dense GEMMs on the persistent 16x16x32 kernel (variants 15 / 16)
+void lt_set_gemm_w4q_grouped(int v);   // 1: grouped (MoE expert) GEMMs with >= 2 tiles per CU on the persistent kernel too (default 1)
+int device_slot();                     // current HIP device id (0..63)
+bool func_attr_done(int dev, const void* fn);  // first call per (device, kernel) returns false: set the kernel's dynamic-LDS attribute then
 void lt_set_gemm_group(int v);          // tile rows per group in the tile order of the 16x16x32 kernel (experiment; 0 = default 4)
 int lt_set_gemm_stagger(int v);        // 4-wave kernels (variants 10, 13, 14): start-phase spread per XCD, units of ~256 cycles (0 = off)
 bool lt_gemm_has_experimental();       // built with EXPERIMENTAL=1 (variants 4-6, 9-12, trace builds, pipeline knobs)

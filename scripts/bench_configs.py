@@ -8,6 +8,7 @@ cfg1  Next-DiT-ImageNet 600M, 256x256 (256 tokens), class-conditional CFG, Euler
 cfg3  Flag-DiT 5B (lumina_t2i), 1024x1024 (64 x 65 tokens incl. eol), text T=128/8, CFG 4
 cfg4  Next-DiT 2B GQA, 2048x2048 (16384 tokens), time-aware scaling 2.0 / watershed 0.3, proportional attention
 cfg5  Next-DiT-MoE 600M "Both" (4 time + 4 space experts, top-2), 256x256
+cfg5-1024  the same model at BASELINE configs[4]'s stated 1024x1024: 4096 tokens, 8192 rows, 16 384 routed rows per MoE FFN
 Synthetic weights drawn on the GPU (SURVEY.md 8d statistics), inputs resident in HBM, wall clock around the sampler call.
 """
 import argparse
@@ -23,8 +24,7 @@ import lumina_t2x_amd  # noqa: E402,F401
 from bench import random_init_  # noqa: E402
 from lumina_t2x_amd import _lib, models  # noqa: E402
 from lumina_t2x_amd.transport import Sampler, create_transport  # noqa: E402
-from oracle import synth  # noqa: E402  (FLOP model only)
-from oracle.nextdit_oracle import flops_per_nfe  # noqa: E402
+from lumina_t2x_amd.flops import flops_per_nfe  # noqa: E402  (the product's own algorithmic-work model; no oracle import)
 
 
 def timed(model, z, nfe, warm, **kw):
@@ -75,7 +75,7 @@ def main():
             z = torch.randn(a.pairs, 4, 32, 32, device=dev, generator=g).repeat(2, 1, 1, 1)  # fp32 state (BASELINE: fp32 for cfg 1)
             y = torch.tensor([207] * a.pairs + [1000] * a.pairs, device=dev)
             ms = timed(m.eval(), z, a.nfe, 2, y=y, cfg_scale=4.0)
-            fl = flops_per_nfe(synth.IMAGENET_600M, 256, 0, 2 * a.pairs)
+            fl = flops_per_nfe(dim=1536, n_layers=16, n_heads=32, n_tokens=256, batch=2 * a.pairs)
             toks = 256 * a.pairs
         elif which == "cfg5":
             with torch.device(dev):
@@ -84,8 +84,17 @@ def main():
             z = torch.randn(a.pairs, 4, 32, 32, device=dev, generator=g).to(torch.bfloat16).repeat(2, 1, 1, 1)
             y = torch.tensor([207] * a.pairs + [1000] * a.pairs, device=dev)
             ms = timed(m.eval(), z, a.nfe, 2, y=y, cfg_scale=4.0)
-            fl = 1.41e12 * a.pairs  # SURVEY.md 8d (both-MoE, 600 M dims, N = 256)
+            fl = flops_per_nfe(dim=1536, n_layers=16, n_heads=32, n_tokens=256, batch=2 * a.pairs, adaln_chunks=6, ffn_visits=4)  # 1.41e12 per pair
             toks = 256 * a.pairs
+        elif which == "cfg5-1024":
+            with torch.device(dev):
+                m = models.moe.DiT_Llama_600M_patch2_Both(qk_norm=True).to(torch.bfloat16)
+            random_init_(m, 0)
+            z = torch.randn(1, 4, 128, 128, device=dev, generator=g).to(torch.bfloat16).repeat(2, 1, 1, 1)
+            y = torch.tensor([207, 1000], device=dev)
+            ms = timed(m.eval(), z, a.nfe, 2, y=y, cfg_scale=4.0)
+            fl = flops_per_nfe(dim=1536, n_layers=16, n_heads=32, n_tokens=4096, batch=2, adaln_chunks=6, ffn_visits=4)
+            toks = 4096
         elif which == "cfg4":
             with torch.device(dev):
                 m = models.NextDiT_2B_GQA_patch2(qk_norm=True, cap_feat_dim=2048).to(torch.bfloat16)
@@ -94,7 +103,7 @@ def main():
             feats, mask = text_inputs(128, 2048, dev)
             ms = timed(m.eval(), z, min(a.nfe, 4), 1, cap_feats=feats, cap_mask=mask, cfg_scale=4.0, proportional_attn=True,
                        base_seqlen=4096, scale_factor=2.0, scale_watershed=0.3, _shift=4)
-            fl = flops_per_nfe(synth.NextDiTConfig(n_kv_heads=8), 16384, 128, 2)
+            fl = flops_per_nfe(dim=2304, n_layers=24, n_heads=32, n_kv_heads=8, cap_feat_dim=2048, n_tokens=16384, text_len=128)
             toks = 16384
         elif which == "cfg3":
             with torch.device(dev):
@@ -104,7 +113,7 @@ def main():
             feats, mask = text_inputs(128, 4096, dev)
             ms = timed(m.eval(), z, min(a.nfe, 4), 1, cap_feats=feats, cap_mask=mask, cfg_scale=4.0, proportional_attn=True,
                        base_seqlen=4096, _shift=4)
-            fl = 75.6e12
+            fl = flops_per_nfe(dim=3072, n_layers=32, n_heads=32, cap_feat_dim=4096, n_tokens=4160, text_len=128, adaln_chunks=6)  # 75.6e12 at 4096 tokens
             toks = 4160
         else:
             raise SystemExit(f"unknown config {which}")

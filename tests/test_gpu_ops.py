@@ -323,6 +323,64 @@ def test_gemm_grouped_gather_on_load(variant, epilogue):
         assert rel_l2(got[256 * 4: 256 * 4 + 131], y) < 4e-3
 
 
+@pytest.mark.parametrize("epilogue", [0, 1])
+@pytest.mark.parametrize("K,N,ntile,gather", [(512, 4096, 44, True), (1536, 640, 9, True), (256, 2048, 40, False), (4096, 1536, 36, False)])
+def test_gemm_grouped_persistent_kernel(K, N, ntile, gather, epilogue):
+    """round 4: grouped (MoE expert) mode of the persistent 16x16x32 kernel (variant 15 with a tile -> expert table; the engine picks
+    it for >= 2 tiles per CU, Next-DiT-MoE at 1024^2).  Holes in the table (padding segments anywhere, not only behind the last
+    expert), several tiles per workgroup (44 x 16 = 704 tiles on 256 CUs: the LDS gather-map slots alternate and the DMA stream crosses
+    tile boundaries with per-tile lane offsets), ragged N (640 = 2.5 tiles), the shortest K the mode accepts (256), gather-on-load with
+    padding rows inside real tiles, every token twice.  Against the 8-wave ping-pong kernel on a gathered copy (same products, other
+    accumulation order inside a 32-deep slab: equal to fp32 rounding) and an fp32 reference; padding segments stay untouched; the
+    gathered and the copy form of the SAME kernel are bit-identical."""
+    E = 4
+    g = torch.Generator().manual_seed(K + N + ntile + epilogue)
+    te = torch.randint(0, E, (ntile,), generator=g).tolist()
+    for hole in (1, ntile // 2, ntile - 1):
+        te[hole] = -1
+    M = 256 * ntile
+    T = M // 2 - 37
+    X = bf(torch.randn(T, K, generator=g))
+    W = bf(torch.randn(E, N, K, generator=g) / math.sqrt(K))
+    row_map = torch.full((M,), -1, dtype=torch.int32)
+    src = torch.cat([torch.randperm(T, generator=g), torch.randperm(T, generator=g)]).to(torch.int32)
+    cursor = 0
+    for t_, ex in enumerate(te):
+        if ex < 0:
+            continue
+        cnt = 256 if t_ % 3 else 256 - 7 * (t_ % 11) - 1  # ragged fill: padding rows behind the entries of some real tiles
+        cnt = min(cnt, src.numel() - cursor)
+        row_map[256 * t_: 256 * t_ + cnt] = src[cursor:cursor + cnt]
+        cursor += cnt
+    valid = (row_map >= 0).cuda()
+    gathered = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+    gathered[valid] = X[row_map[row_map >= 0].long().cuda()]
+    tile_expert = torch.tensor(te, dtype=torch.int32, device="cuda")
+    No = N // 2 if epilogue else N
+    fill = lambda: torch.full((M, No), 3.0, device="cuda", dtype=torch.bfloat16)
+    pp, copy, got = fill(), fill(), fill()
+    ok(lib().lt_op_gemm_grouped(P(gathered), P(W), P(tile_expert), N * K, P(pp), M, N, K, epilogue, 3, stream()), "grouped pp")
+    ok(lib().lt_op_gemm_grouped(P(gathered), P(W), P(tile_expert), N * K, P(copy), M, N, K, epilogue, 15, stream()), "grouped w4q")
+    if gather:
+        ok(lib().lt_op_gemm_grouped_gather(P(X), T, P(row_map.cuda()), P(W), P(tile_expert), N * K, P(got), M, N, K, epilogue, 15, stream()),
+           "grouped_gather w4q")
+    torch.cuda.synchronize()
+    if gather:
+        assert torch.equal(got, copy)
+    for t_, ex in enumerate(te):
+        rows = slice(256 * t_, 256 * t_ + 256)
+        if ex < 0:
+            assert torch.all(copy[rows] == 3.0), "padding segment was written"
+            continue
+        assert rel_l2(copy[rows], pp[rows]) < 4e-3, (t_, ex, rel_l2(copy[rows], pp[rows]))
+        if t_ % 7 == 0:
+            y = gathered[rows].float() @ W[ex].float().t()
+            if epilogue:
+                y = y.view(256, N // 64, 2, 32)
+                y = r16(r16(F.silu(r16(y[:, :, 0]))) * r16(y[:, :, 1])).reshape(256, No)
+            assert rel_l2(copy[rows], y) < 6e-3, (t_, ex, rel_l2(copy[rows], y))
+
+
 @pytest.mark.parametrize("tokens,B,kvh,hd,K,variant", [(4096, 2, 32, 72, 2304, 0), (64, 3, 2, 72, 128, 1), (128, 2, 8, 72, 576, 2),
                                                        (4160, 2, 32, 96, 3072, 0), (1024, 2, 32, 48, 1536, 0), (64, 1, 4, 72, 64, 2)])
 def test_gemm_vt_epilogue_matches_gemm_plus_transpose(tokens, B, kvh, hd, K, variant):
