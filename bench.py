@@ -67,6 +67,8 @@ def maybe_self_launch(args, argv) -> None:
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
     env = dict(os.environ)
+    if args.share_device:
+        env["LUMINA_SHARE_DEVICE"] = "1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "8")
     rc = subprocess.run(launcher_command(argv, args.gpus), env=env).returncode
@@ -270,6 +272,34 @@ def cpu_baseline(latent, n_tokens):
     return res
 
 
+def box_probe(lib, torch):
+    """Which box did this run draw?  Boxes of this pool differ by up to 10 % under identical code (DESIGN.md status log: 29.2-30.7 vs
+    32.97-34.5 ms per step), more than a round usually moves.  A fixed probe - the W1|W3-shaped GEMM (8192 x 12288 x 2304, random bf16
+    operands, plain epilogue) run 40 times back to back after the timed regions - gives a number that depends on the box and the
+    library's one GEMM kernel only; `class` compares it with 1270 TFLOP/s (fast boxes read 1320-1340, slow ones 1190-1230)."""
+    import ctypes as C
+    M, N, K = 8192, 12288, 2304
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+
+    def launch(n):
+        for _ in range(n):
+            rc = lib.lt_op_gemm_bf16(P(a), P(w), None, 1, P(c), M, N, K, 0, 0, st)
+            assert rc == 0
+    launch(10)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch(40)
+    e1.record()
+    torch.cuda.synchronize()
+    tf = 2.0 * M * N * K * 40 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return {"probe": "gemm 8192x12288x2304 bf16, 40 launches back to back", "tflops": tf, "class": "fast" if tf >= 1270.0 else "slow", "threshold_tflops": 1270.0}
+
+
 def gemm_kernel_label(lib, M, d, F, dkv, tokens, hd):
     """names of the kernels the engine's dispatcher runs for this workload's GEMM shapes (lt_op_gemm_describe), and the number of
     GEMM launches per layer (4 when the QKV projection is one launch, else 5)"""
@@ -303,6 +333,13 @@ def main():
                     help="bit mask of kernel classes bracketed by HIP events IN THE TIMED REGION: 1 GEMM (the roofline kernel, "
                          "default), 2 attention, 4 other.  Every bracketed launch costs two event packets (all classes: +4 %% "
                          "wall), so the attention / other breakdown is taken in a short untimed pass after the timed region")
+    ap.add_argument("--share-device", action="store_true",
+                    help="with --gpus N > 1: all N ranks drive GPU 0 and the collectives run over gloo with a host hop.  Exercises the "
+                         "self-launch / rank / shard / max-over-ranks / JSON relay logic with the real engine on a ONE-GPU box; it is NOT "
+                         "a scaling measurement (the line says n_gpus 1, ranks N, shared_device true) and says nothing about RCCL")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed regions run back to back in this process: `value` / `ms_per_step` are the FIRST (the contract's K steps); "
+                         "`ms_per_step_repeats` lists all of them so that a round-over-round delta can be told from run-to-run noise")
     ap.add_argument("--gqa", action="store_true", help="shorthand for --workload cfg2-gqa")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B knob: 1 baseline, 2 VALU-diet, 3 ping-pong, 4 one wave per SIMD (default)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B knob: 0 auto (default), 1 256x256, 2 256x288")
@@ -330,7 +367,8 @@ def main():
     if args.gemm_variant is not None:
         _lib.check(_lib.load().lt_set_option(b"gemm_variant", args.gemm_variant))
 
-    rank, world, local = parallel.init_distributed("nccl" if args.gpus > 1 else None)
+    share = args.share_device or os.environ.get("LUMINA_SHARE_DEVICE", "0") == "1"
+    rank, world, local = parallel.init_distributed("nccl" if args.gpus > 1 else None, share_device=share)
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(0)
@@ -391,6 +429,16 @@ def main():
     eng.profile_enable(False)
     assert eng.last_nfe() == args.steps
     gemm_prof = eng.profile_read(0)
+    # further timed regions, same process, same bracket: not part of `value`
+    repeats_ms = [dt / args.steps * 1e3]
+    for _ in range(max(0, args.repeats - 1)):
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        repeats_ms.append(parallel.max_over_ranks(time.perf_counter() - t0, dev) / args.steps * 1e3)
     # untimed pass for the per-class breakdown (events around every launch)
     nb = min(4, args.steps)
     eng.profile_set_budget(0, -1)
@@ -416,8 +464,10 @@ def main():
             "metric": "denoising-steps/s & latent-tokens/s, Next-DiT 2B %d^2 CFG" % res,
             "value": world * n_tokens * args.steps / dt,
             "unit": "latent-tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": 1 if share else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_repeats": repeats_ms,
+            "box": box_probe(_lib.load(), torch),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (wl["desc"] + ", text T=128, CFG=4 (cond+uncond B=2), proportional attention, "
@@ -451,6 +501,10 @@ def main():
                                    "generate.py:212-219, tests/golden/solver_kat.npz); rk4 / dopri5 restate torchdiffeq (absent "
                                    "everywhere) and stay unpinned, DESIGN.md 6",
         }
+        if share:
+            out.update(ranks=world, shared_device=True,
+                       note="ranks share GPU 0 over gloo: exercises launcher / rank / shard / relay logic with the real engine; NOT a scaling "
+                            "measurement and no evidence about RCCL or xGMI")
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             out["cpu_baseline"] = cpu_baseline(latent, n_tokens)
         print(json.dumps(out), flush=True)

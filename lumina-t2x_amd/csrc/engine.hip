@@ -892,13 +892,20 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     A16(e->vt, Bm * Hkv * hd * Npad); A16(e->attn, M * d); A16(e->o, M * d);
     if (e->E == 0) A16(e->u, M * F);
     else {  // expert-sorted buffers: every row appears twice, each expert segment starts on a 256-row tile
+        // the experts' W1 | W3 GEMM gathers its rows through ONE buffer descriptor over the FFN input (launch_gemm_bf16: a_row_map):
+        // fail here, with the sizes, not at the first forward
+        if ((long long)M * d * 2 >= 0x40000000LL) {
+            lt_set_error("lt_create: mixture-of-experts engine with max_batch * max_tokens = %zu rows of d = %d: the FFN input (%.2f GB) exceeds "
+                         "the 1 GB the gather-on-load GEMM addresses; lower max_batch / max_tokens", M, d, (double)M * d * 2 / 1e9);
+            return fail();
+        }
         e->moe_tiles = (int)((2 * M + (size_t)e->E * 255 + 255) / 256);
         const size_t P = (size_t)e->moe_tiles * 256;
         A16(e->moe_us, P * F); A16(e->moe_ys, P * d); A16(e->moe_logits, Bm * e->E); A16(e->moe_wts, 2 * M);
         void* q;
-        if (dev_alloc(e, &q, 2 * M * sizeof(int))) return fail();
+        if (dev_alloc(e, &q, (2 * M + 4) * sizeof(int))) return fail();  // (+4: moe_plan reads / writes whole 16-byte quads)
         e->moe_sel = (int*)q;
-        if (dev_alloc(e, &q, 2 * M * sizeof(int))) return fail();
+        if (dev_alloc(e, &q, (2 * M + 4) * sizeof(int))) return fail();
         e->moe_pos = (int*)q;
         if (dev_alloc(e, &q, (size_t)e->moe_tiles * sizeof(int))) return fail();
         e->moe_tile_expert = (int*)q;
@@ -1235,9 +1242,23 @@ extern "C" int lt_moe_routing_force(lt_engine* e, const int32_t* host_sel, int32
     LT_REQUIRE(e && e->E > 0, "lt_moe_routing_force: not a mixture-of-experts engine");
     if (!host_sel || rows <= 0) { e->moe_force_rows = 0; return 0; }
     LT_REQUIRE((long long)rows <= (long long)e->cfg.max_batch * e->cfg.max_tokens, "lt_moe_routing_force: %d rows exceed the engine's capacity", rows);
-    for (size_t i = 0; i < (size_t)e->L * 2 * rows * 2; ++i) {
-        // branches the variant does not run carry -1 and are never read
-        LT_REQUIRE(host_sel[i] >= -1 && host_sel[i] < e->E, "lt_moe_routing_force: expert id %d outside 0..%d", host_sel[i], e->E - 1);
+    // per (layer, branch): a branch this variant RUNS needs two distinct expert ids in 0..E-1 for every row (a -1 there reached
+    // the plan kernel's packed counters as a negative shift and corrupted the plan silently - ADVICE r3); a branch it does not run
+    // (moe_mode 1: space, 2: time) may carry anything, -1 by convention, and is never read
+    for (int lb = 0; lb < e->L * 2; ++lb) {
+        const int branch = lb & 1;
+        const bool runs = e->moe_mode == 0 || (e->moe_mode == 1 && branch == 0) || (e->moe_mode == 2 && branch == 1);
+        const int32_t* tb = host_sel + (size_t)lb * rows * 2;
+        for (int r = 0; r < rows; ++r) {
+            const int a = tb[2 * r], b = tb[2 * r + 1];
+            if (!runs) {
+                LT_REQUIRE(a >= -1 && a < e->E && b >= -1 && b < e->E, "lt_moe_routing_force: expert id outside -1..%d (layer %d, branch %d, row %d)", e->E - 1, lb >> 1, branch, r);
+                continue;
+            }
+            LT_REQUIRE(a >= 0 && a < e->E && b >= 0 && b < e->E, "lt_moe_routing_force: layer %d branch %d row %d: expert ids (%d, %d) must lie in 0..%d (this branch runs)",
+                       lb >> 1, branch, r, a, b, e->E - 1);
+            LT_REQUIRE(a != b, "lt_moe_routing_force: layer %d branch %d row %d selects expert %d twice (top-2 picks two different experts)", lb >> 1, branch, r, a);
+        }
     }
     if (!e->moe_force) LT_CHECK_HIP(hipMalloc((void**)&e->moe_force, moe_table_ints(e) * sizeof(int)));
     LT_CHECK_HIP(hipDeviceSynchronize());

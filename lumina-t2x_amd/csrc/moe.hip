@@ -95,32 +95,69 @@ __global__ __launch_bounds__(256) void moe_route_kernel(MoeArgs p) {
 // round-1 form let E threads walk all 1024 counters serially through LDS and took 12.4 us per MoE layer - 0.4 ms per NFE at cfg 5,
 // as much as the attention of that model (profiles/r03/rocprofv3_kernel_stats_cfg5_r03.csv).  Also writes the inverse map
 // src[sorted position] = token row (-1 in the padding of a segment) that the grouped SwiGLU GEMM gathers its A rows through.
+// Round 4: PER > 0 = the thread's (at most PER, a multiple of 4) entries live in REGISTERS, fetched with 16-byte loads that are all
+// in flight together, and pos[] leaves as 16-byte stores.  The round-3 form walked its entries with one dependent 4-byte load per
+// iteration, twice (count, then place): 2 x 16 serial memory round trips of one CU = 62 us per MoE FFN at 16 384 entries, 2 ms per NFE of
+// Next-DiT-MoE at 1024^2 (profiles/r04/rocprofv3_kernel_stats_cfg5_1024_baseline.csv).  PER == 0 keeps that walk for larger problems.
+template <int PER>
 __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
     __shared__ int wtot[16][MAX_E];   // per wave and expert: entries in the wave, then the exclusive prefix over waves
     __shared__ int seg_off[MAX_E], seg_cnt[MAX_E];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.rows * 2;
-    const int per = (n + 1023) / 1024;
+    const int per = PER > 0 ? PER : (n + 1023) / 1024;
     const int lo = tid * per, hi = min(n, lo + per);
     unsigned long long c0 = 0, c1 = 0;  // this thread's counts: experts 0..3 / 4..7, 16 bits each
+    int ex_r[PER > 0 ? PER : 1];        // PER > 0: the thread's entries (-1 past the end)
     if (p.sample_logits) {  // time router: the logits are per sample - route here, no separate launch (sel / wts written for combine)
+        int cached_b = -1, s0 = 0, s1 = 0;
+        u16 w0 = 0, w1 = 0;
         for (int i = lo; i < hi; ++i) {
             const int row = i >> 1, b = row / p.rows_per_sample;
-            float logit[MAX_E];
+            if (b != cached_b || p.forced) {  // every token of a sample shares the two experts (unless the parity hook forces per-row choices)
+                float logit[MAX_E];
 #pragma unroll
-            for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[b * p.E + e]) : -INFINITY;
-            int s0, s1;
-            u16 w0, w1;
-            top2_route(logit, p.forced ? p.forced + 2 * row : nullptr, s0, s1, w0, w1);
-            p.sel[i] = (i & 1) ? s1 : s0;
+                for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[b * p.E + e]) : -INFINITY;
+                top2_route(logit, p.forced ? p.forced + 2 * row : nullptr, s0, s1, w0, w1);
+                cached_b = b;
+            }
+            const int ex = (i & 1) ? s1 : s0;
+            p.sel[i] = ex;
             p.wts[i] = (i & 1) ? w1 : w0;
+            if constexpr (PER > 0) ex_r[i - lo] = ex;
         }
-        __syncthreads();  // (sel is re-read below by the thread that wrote it; the barrier orders the rest of the kernel's reads)
+        if constexpr (PER > 0) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) if (lo + j >= hi) ex_r[j] = -1;
+        }
+        if constexpr (PER == 0) __syncthreads();  // (sel is re-read below by the thread that wrote it)
+    } else if constexpr (PER > 0) {
+        // n is even and lo a multiple of 4, but n need not be a multiple of 4: the last quad may run 2 entries past the end of sel -
+        // the engine's table has room (capacity rows), the op-level entry pads its buffer; values past hi are masked below
+#pragma unroll
+        for (int j = 0; j < PER; j += 4) {
+            int4 v = {-1, -1, -1, -1};
+            if (lo + j < hi) v = *(const int4*)(p.sel + lo + j);
+            ex_r[j] = v.x; ex_r[j + 1] = v.y; ex_r[j + 2] = v.z; ex_r[j + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) if (lo + j >= hi) ex_r[j] = -1;
     }
-    for (int i = lo; i < hi; ++i) {
-        const int ex = p.sel[i];
-        if (ex < 4) c0 += 1ull << (16 * ex);
-        else c1 += 1ull << (16 * (ex - 4));
+    if constexpr (PER > 0) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int ex = ex_r[j];
+            if (ex >= 0) {
+                if (ex < 4) c0 += 1ull << (16 * ex);
+                else c1 += 1ull << (16 * (ex - 4));
+            }
+        }
+    } else {
+        for (int i = lo; i < hi; ++i) {
+            const int ex = p.sel[i];
+            if (ex < 4) c0 += 1ull << (16 * ex);
+            else c1 += 1ull << (16 * (ex - 4));
+        }
     }
     unsigned long long s0 = c0, s1 = c1;  // inclusive scan inside the wave
 #pragma unroll
@@ -157,15 +194,38 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
         const int incl = (int)(((e < 4 ? s0 : s1) >> (16 * (e & 3))) & 0xffff), own = (int)(((e < 4 ? c0 : c1) >> (16 * (e & 3))) & 0xffff);
         next[e] = e < p.E ? seg_off[e] + wtot[wave][e] + incl - own : 0;
     }
-    for (int i = lo; i < hi; ++i) {
-        const int ex = p.sel[i];
-        int q = 0;
+    if constexpr (PER > 0) {
 #pragma unroll
-        for (int e = 0; e < MAX_E; ++e) {
-            if (ex == e) { q = next[e]; next[e] = q + 1; }
+        for (int j = 0; j < PER; j += 4) {
+            int q4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ex = ex_r[j + u];
+                int q = 0;
+#pragma unroll
+                for (int e = 0; e < MAX_E; ++e) {
+                    if (ex == e) { q = next[e]; next[e] = q + 1; }
+                }
+                q4[u] = q;
+                if (ex >= 0) p.src[q] = (lo + j + u) >> 1;
+            }
+            if (lo + j + 3 < hi) *(int4*)(p.pos + lo + j) = int4{q4[0], q4[1], q4[2], q4[3]};
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (lo + j + u < hi) p.pos[lo + j + u] = q4[u];
+            }
         }
-        p.pos[i] = q;
-        p.src[q] = i >> 1;
+    } else {
+        for (int i = lo; i < hi; ++i) {
+            const int ex = p.sel[i];
+            int q = 0;
+#pragma unroll
+            for (int e = 0; e < MAX_E; ++e) {
+                if (ex == e) { q = next[e]; next[e] = q + 1; }
+            }
+            p.pos[i] = q;
+            p.src[q] = i >> 1;
+        }
     }
     for (int t = tid; t < p.max_tiles; t += 1024) {
         int ex = -1;
@@ -203,7 +263,12 @@ int launch_moe_route(const MoeArgs& a, hipStream_t stream) {
 int launch_moe_plan(const MoeArgs& a, hipStream_t stream) {
     if (check(a)) return 2;
     LT_REQUIRE(2LL * a.rows <= 1024LL * 1023, "moe_plan: %d rows exceed the packed 16-bit counters of the scan (523776 rows)", a.rows);
-    hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(1024), 0, stream, a);
+    const int per = (2 * a.rows + 1023) / 1024;  // entries per thread; the register forms hold a multiple of 4
+    if (per <= 4) hipLaunchKernelGGL(moe_plan_kernel<4>, dim3(1), dim3(1024), 0, stream, a);
+    else if (per <= 8) hipLaunchKernelGGL(moe_plan_kernel<8>, dim3(1), dim3(1024), 0, stream, a);
+    else if (per <= 16) hipLaunchKernelGGL(moe_plan_kernel<16>, dim3(1), dim3(1024), 0, stream, a);
+    else if (per <= 32) hipLaunchKernelGGL(moe_plan_kernel<32>, dim3(1), dim3(1024), 0, stream, a);
+    else hipLaunchKernelGGL(moe_plan_kernel<0>, dim3(1), dim3(1024), 0, stream, a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

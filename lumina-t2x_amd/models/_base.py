@@ -12,9 +12,12 @@ from .. import _lib
 from ..engine import DiTEngine, EngineLimits
 
 
-# Any (re-)registration of a Parameter object anywhere (setattr of an nn.Parameter, load_state_dict(assign=True), ...) bumps this
-# epoch; the cached flat parameter lists below are rebuilt when it moves.  In-place edits and .to() / .half() conversions keep the
-# Parameter objects and show up as a changed (data_ptr, version) pair instead.
+# Any (re-)registration of a Parameter OR of a sub-module anywhere (setattr of an nn.Parameter, load_state_dict(assign=True),
+# `m.layers[0] = prebuilt_block`, ...) bumps this epoch; the cached flat MODULE lists below are rebuilt when it moves.  In-place edits
+# and .to() / .half() conversions keep the Parameter objects and show up as a changed (data_ptr, version) pair instead; parameters
+# that disappear without a registration (`del m.a.bias`, `m.a.bias = None`) show up because the signature is read from the live
+# `_parameters` dicts of the cached modules, not from a cached parameter list (the round-3 form cached the parameters and
+# was driven by the parameter hook alone - a pre-built sub-module swapped in, or a parameter removed, kept the engine on OLD weights).
 _PARAM_EPOCH = [0]
 
 
@@ -23,16 +26,22 @@ def _on_parameter_registration(module, name, param):
     return None
 
 
+def _on_module_registration(module, name, submodule):
+    _PARAM_EPOCH[0] += 1
+    return None
+
+
 torch.nn.modules.module.register_module_parameter_registration_hook(_on_parameter_registration)
+torch.nn.modules.module.register_module_module_registration_hook(_on_module_registration)
 
 
 class WeightWatch:
-    """'did any weight change since the engine last loaded them?' at ~40 us per call instead of ~0.3 ms: the module tree (567
-    parameters under ~230 modules for the 2B model) is walked once and the flat list kept; every per-step call of a host-driven
-    sampler (dopri5, SDE: the default of Next-DiT-ImageNet/sample.py) goes through this check."""
+    """'did any weight change since the engine last loaded them?' at ~50 us per call instead of ~0.3 ms: the module tree (567
+    parameters under ~230 modules for the 2B model) is walked once and the flat module list kept; every per-step call of a
+    host-driven sampler (dopri5, SDE: the default of Next-DiT-ImageNet/sample.py) goes through this check."""
 
     def _watch_reset(self) -> None:
-        self._watch_params = None
+        self._watch_modules = None
         self._watch_epoch = -1
 
     def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .half(): may swap the Parameter objects without registering them
@@ -46,11 +55,12 @@ class WeightWatch:
         return out
 
     def _signature(self):
-        if getattr(self, "_watch_params", None) is None or self._watch_epoch != _PARAM_EPOCH[0]:
-            self._watch_params = list(self.parameters())
+        if getattr(self, "_watch_modules", None) is None or self._watch_epoch != _PARAM_EPOCH[0]:
+            self._watch_modules = [m for m in self.modules() if m._parameters]
             self._watch_epoch = _PARAM_EPOCH[0]
         # (inference tensors carry no version counter: in-place edits of such parameters are not seen - rebuild the model then)
-        return tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self._watch_params)
+        return tuple((p.data_ptr(), -1 if p.is_inference() else p._version)
+                     for m in self._watch_modules for p in m._parameters.values() if p is not None)
 
 
 class EngineBackedModel(WeightWatch, nn.Module):

@@ -166,7 +166,9 @@ def DiT_Llama_600M_patch2_Both(**kwargs):
 def DiT_Llama_600M_GQA_patch2(**kwargs):
     """reference models.py:1021-1024: like its siblings above, the name resolves to the file the un-suffixed builders come from
     (models.py = time-routed experts).  The reference defines the same name in models1.py / models2.py for the other two routings;
-    those are spelled out below."""
+    those are spelled out below.  NOTE (rename in round 3, recorded here and in INTEGRATION.md): rounds 1-2 bound this name to the
+    time + space model of models2.py; checkpoints / train_args written with it then must now name DiT_Llama_600M_GQA_patch2_Both.
+    tests/test_host_logic.py pins every builder name to its variant."""
     return DiT_Llama_TimeMoE(patch_size=2, dim=1536, n_layers=16, n_heads=32, n_kv_heads=8, **kwargs)
 
 

@@ -16,11 +16,18 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from the torchrun environment; initialises the default group if world > 1."""
+def init_distributed(backend: Optional[str] = None, share_device: bool = False) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the default group if world > 1.
+
+    ``share_device`` (or LUMINA_SHARE_DEVICE=1): every rank drives GPU 0 and the collectives run over gloo with a host hop (RCCL
+    cannot put two ranks on one device).  It exists to run the REAL engine under the real launcher / rank / shard / relay logic on a
+    one-GPU lease; it says nothing about RCCL, xGMI or scaling - the returned local rank is 0 for every rank."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    share_device = share_device or os.environ.get("LUMINA_SHARE_DEVICE", "0") == "1"
+    if share_device:
+        local, backend = 0, "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -30,10 +37,27 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device("cuda", local))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
             dist.init_process_group(backend)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
     return rank, world, local
+
+
+def _host_hop() -> bool:
+    """gloo moves host memory: device tensors take a D2H / H2D hop around the collective (the CPU twin of the RCCL path, and the
+    shared-device mode of init_distributed)"""
+    return dist.get_backend() == "gloo"
+
+
+def _broadcast(t: torch.Tensor, src: int) -> None:
+    if t.is_cuda and _host_hop():
+        h = t.cpu()
+        dist.broadcast(h, src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src)
 
 
 def shard_range(n_items: int, rank: int, world: int) -> range:
@@ -57,7 +81,7 @@ def broadcast_prompts(cap_feats: Optional[torch.Tensor], cap_mask: Optional[torc
         hdr = torch.tensor(list(cap_feats.shape) + [dtypes.index(cap_feats.dtype)], dtype=torch.int64, device=dev)
     else:
         hdr = torch.zeros(5, dtype=torch.int64, device=dev)
-    dist.broadcast(hdr, src)
+    _broadcast(hdr, src)
     n, two, T, C, di = (int(v) for v in hdr.tolist())
     if rank != src:
         cap_feats = torch.empty(n, two, T, C, dtype=dtypes[di], device=dev)
@@ -65,8 +89,8 @@ def broadcast_prompts(cap_feats: Optional[torch.Tensor], cap_mask: Optional[torc
     else:
         cap_feats = cap_feats.to(dev).contiguous()
         cap_mask = cap_mask.to(device=dev, dtype=torch.int32).contiguous()
-    dist.broadcast(cap_feats, src)
-    dist.broadcast(cap_mask, src)
+    _broadcast(cap_feats, src)
+    _broadcast(cap_mask, src)
     return cap_feats, cap_mask
 
 
@@ -79,17 +103,20 @@ def gather_latents(local: torch.Tensor, n_items: int, *, dst: int = 0) -> Option
     cap = max(counts)
     pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
+    out_dev = pad.device
+    if pad.is_cuda and _host_hop():
+        pad = pad.cpu()
     bufs: Optional[List[torch.Tensor]] = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(out_dev)
 
 
 def max_over_ranks(value: float, device: torch.device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if _host_hop() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

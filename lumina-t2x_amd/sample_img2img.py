@@ -101,7 +101,12 @@ def run(args, *, encode_fn=None, cap_feat_dim=None, vae_encode_fn: Optional[Call
             torch.random.manual_seed(int(args.seed))
         img = image if image is not None else load_image(args.image, w, h, device)
         x1 = vae_encode_fn(img[None] if img.dim() == 3 else img).mul(factor)          # :179-181
-        z = torch.randn([1, 4, w // 8, h // 8], device=device).to(dtype)              # :187 (width first, as the reference)
+        # :187 draws [1, 4, w // 8, h // 8] (width first) while the VAE latent is [1, 4, h // 8, w // 8]: identical for squares, a
+        # broadcast error at the mix below for every other resolution.  Deviation: the noise takes the latent's own shape -
+        # the same values for squares, and non-square resolutions work instead of dying.
+        z = torch.randn([1, 4, h // 8, w // 8], device=device).to(dtype)
+        if tuple(x1.shape[-2:]) != (h // 8, w // 8):
+            raise ValueError(f"VAE latent {tuple(x1.shape)} does not match the requested resolution {w}x{h} (expected [..., {h // 8}, {w // 8}])")
         t0 = float(ode.t[0])
         z = z * (1 - t0) + x1.to(dtype) * t0                                          # :190
         z = z.repeat(2, 1, 1, 1)
@@ -150,6 +155,12 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--debug", action="store_true", help="random-init weights (no checkpoint load), as in the reference")
     p.add_argument("--text_encoder", type=str, default="google/gemma-2b", help="local path of the text encoder (no network)")
     p.add_argument("--vae", type=str, default="", help="local path of the diffusers AutoencoderKL weights (encoder AND decoder)")
+    # accepted for command-line compatibility with lumina_next_t2i_mini/sample_img2img.py:262-300 and ignored: one process drives one GPU
+    # here (no model-parallel group), the tokenizer comes with --text_encoder, there is one attention implementation, captions run one by one
+    p.add_argument("--num_gpus", type=int, default=1, help="ignored (reference: model-parallel world size, asserted == 1)")
+    p.add_argument("--tokenizer_path", type=str, default="", help="ignored (the tokenizer is loaded from --text_encoder)")
+    p.add_argument("--use_flash_attn", type=lambda v: str(v).lower() not in ("0", "false", "no"), default=True, help="ignored")
+    p.add_argument("--batch_size", type=int, default=1, help="ignored (captions are sampled one at a time, as in the reference loop)")
     return p
 
 

@@ -1,4 +1,4 @@
-"""-m gpu: the N > 1 sampling path over RCCL (backend "nccl") - runs when the box exposes >= 2 GPUs, skips otherwise (the
+"""-m gpu: the N > 1 sampling path - over RCCL (backend "nccl") - runs when the box exposes >= 2 GPUs, skips otherwise (the
 authoring leases are single-GPU; the CPU twin of this test is tests/test_dist_gloo.py, world size 2 over gloo).
 
 1. parallel.broadcast_prompts / gather_latents / max_over_ranks across 2 ranks, one per GPU;
@@ -73,3 +73,53 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
+
+
+# ---- the same N > 1 code on ONE GPU: both ranks drive device 0, collectives over gloo with a host hop (parallel.init_distributed
+#      share_device).  Runs on every lease; proves the launcher / rank / shard / relay logic with the real engine - not RCCL, not scaling.
+def _worker_shared(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      LUMINA_SHARE_DEVICE="1")
+    r, w, local = parallel.init_distributed("nccl")  # the environment switch overrides the backend
+    assert local == 0 and torch.distributed.get_backend() == "gloo" and torch.cuda.current_device() == 0
+    dev = torch.device("cuda", 0)
+    n_img, T, C = 3, 8, 32
+    feats = mask = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(9)
+        feats = torch.randn(n_img, 2, T, C, generator=g).to(dev, torch.bfloat16)
+        mask = (torch.rand(n_img, 2, T, generator=g) > 0.3).int().to(dev)
+    feats, mask = parallel.broadcast_prompts(feats, mask, src=0, device=dev)
+    g = torch.Generator().manual_seed(9)
+    want = torch.randn(n_img, 2, T, C, generator=g).to(torch.bfloat16)
+    assert feats.device == dev and torch.equal(feats.cpu(), want) and mask.dtype == torch.int32 and mask.device == dev
+    mine = parallel.shard_range(n_img, rank, world)
+    local_lat = torch.stack([feats[i, 0].float().mean().expand(4, 2, 2) + i for i in mine])
+    full = parallel.gather_latents(local_lat, n_img, dst=0)
+    assert parallel.max_over_ranks(1.0 + rank, dev) == float(world)
+    parallel.barrier()
+    if rank == 0:
+        expect = torch.stack([want[i, 0].float().mean().expand(4, 2, 2) + i for i in range(n_img)])
+        assert full.device == dev and torch.allclose(full.cpu(), expect)
+        open(os.path.join(out_dir, "ok"), "w").write("1")
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_prompt_broadcast_and_gather(tmp_path):
+    mp.spawn(_worker_shared, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_bench_launches_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 --share-device` as the driver would start an N > 1 run (no torchrun, no WORLD_SIZE): the script launches
+    its own two ranks under torch.distributed.run, each builds the real engine on GPU 0 and denoises its own image, the prompt is
+    broadcast from rank 0, the time is the max over ranks and rank 0 alone prints the JSON line - labelled as what it is."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LUMINA_SHARE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--share-device", "--steps", "3", "--warmup", "1",
+                          "--repeats", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["ranks"] == 2 and rec["shared_device"] is True and rec["steps"] == 3 and rec["value"] > 0
+    assert "NOT a scaling" in rec["note"]

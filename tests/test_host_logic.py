@@ -580,4 +580,22 @@ def test_weight_watch_sees_every_kind_of_weight_change():
     assert s3 != s2
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     m.load_state_dict(sd, assign=True)
-    assert m._signature() != s3
+    s4 = m._signature()
+    assert s4 != s3
+    # changes that register no NEW Parameter - a pre-built sub-module swapped in (EMA / LoRA-merge flows), a parameter
+    # deleted, a parameter set to None - must be seen as well
+    import copy
+    spare = copy.deepcopy(m.layers[0])          # built BEFORE the last signature, so none of its parameters registers again
+    assert m._signature() == s4
+    m.layers[0] = spare
+    s5 = m._signature()
+    assert s5 != s4 and len(s5) == len(s4)
+    del m.layers[1].attention_norm1.weight
+    s6 = m._signature()
+    assert s6 != s5 and len(s6) == len(s5) - 1
+    m.layers[1].ffn_norm1.weight = None
+    s7 = m._signature()
+    assert s7 != s6 and len(s7) == len(s6) - 1
+    spare_leaf = copy.deepcopy(m.layers[0].attention.wq)
+    m.layers[0].attention.wq = spare_leaf       # a leaf module swap deep in the tree
+    assert m._signature() != s7

@@ -233,7 +233,7 @@ def test_oracle_compositional_regional_attention_matches_reference(golden_dir, n
 
 # ---- full-depth, full-width fixtures of the BASELINE configs (oracle/make_fulldepth_golden.py) -----------------------------------
 
-FULL = ["full_2b", "full_2b_gqa_ntk", "full_flag5b", "full_moe600m", "full_moe600m_256"]
+FULL = ["full_2b", "full_2b_gqa_ntk", "full_flag5b", "full_moe600m", "full_moe600m_256", "full_moe600m_4096", "full_imagenet600m"]
 
 
 @pytest.mark.parametrize("name", FULL)
@@ -250,7 +250,7 @@ def test_fulldepth_oracle_is_pinned_to_the_reference(golden_dir, name):
         assert ref.shape == ora.shape == floor.shape and torch.isfinite(ref).all()
         assert float((ora - ref).norm() / ref.norm()) < 1e-5
         f = float((floor - ref).norm() / ref.norm())
-        assert 5e-3 < f < (0.35 if "moe" in name else 8e-2), f
+        assert 5e-3 < f < (0.35 if "moe" in name else 8e-2), f  # (ImageNet 600M at cfg 4: 6.6e-2, SURVEY A.6 measured 4.0e-2 on another draw)
         assert torch.equal(ref[0, :3], ref[1, :3])  # CFG on channels [:3]: both rows carry the guided value (model.py:908-913)
         if "moe" in name:  # routing-pinned yardstick: with the discrete top-2 choice held equal to the fp32 run's, the bf16
             # choreography is 0.11 from fp32 instead of 0.20 (what remains is continuous: gate weights from bf16 router logits)
@@ -259,6 +259,23 @@ def test_fulldepth_oracle_is_pinned_to_the_reference(golden_dir, name):
             route = g[f"route_{tag}"]
             assert route.shape[:2] == (16, 2) and route.shape[3] == 2 and route.min() >= 0 and route.max() < 4
             assert (route[..., 0] < route[..., 1]).all() and 0.5 < float(g[f"floor_agree_{tag}"]) < 1.0
+
+
+def test_fulldepth_16k_fixture_is_the_pinned_restatement(golden_dir):
+    """full_2b_gqa_16k (BASELINE configs[3] at its own 16 384 tokens, round 4): the unmodified reference cannot run this size on the
+    authoring host (its SDPA fallback wants an fp32 [B, H, N, N] mask = 69 GB), so the fixture holds the RESTATEMENT's output - and
+    must say so.  What pins it: the same restatement code on the SAME weights (seed_w 71) equals the reference module bit for bit at
+    4096 tokens on both RoPE branches (full_2b_gqa_ntk, test above)."""
+    g = _load(golden_dir, "full_2b_gqa_16k")
+    pinned = _load(golden_dir, "full_2b_gqa_ntk")
+    assert "restatement only" in str(g["pinned_by"]) and not any(k.startswith("ref_") for k in g.files)
+    assert int(g["seed_w"]) == int(pinned["seed_w"]) and np.array_equal(g["wsum"], pinned["wsum"]) and str(g["config"]) == str(pinned["config"])
+    assert tuple(g["latent_hw"]) == (256, 256)  # 128 x 128 patches = 16 384 tokens
+    for tag, _, kw in json.loads(str(g["calls"])):
+        assert kw["scale_factor"] == 2.0 and kw["base_seqlen"] == 4096 and kw["proportional_attn"]
+        ora, floor = torch.from_numpy(g[f"oracle_{tag}"]), torch.from_numpy(g[f"floor_{tag}"])
+        assert ora.shape == (2, 4, 256, 256) and torch.isfinite(ora).all() and torch.equal(ora[0, :3], ora[1, :3])
+        assert 5e-3 < float((floor - ora).norm() / ora.norm()) < 8e-2
 
 
 def test_fulldepth_weight_draw_is_reproducible(golden_dir):
