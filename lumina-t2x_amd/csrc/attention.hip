@@ -987,6 +987,13 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
 #endif
     if (g_attn_variant >= 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && (!a.tk || a.Tkpad <= 256))
         return launch_attention_v4(a, stream);
+    // ... its head_dim 48 form (attention_v4_48.hip, round 4: the 600M ImageNet / MoE models)
+    // (no text keys: no head_dim 48 model of the reference has a text branch, and the kernel's inherited text phase has no test)
+    // From ~200 workgroups of 256 query rows on (2 x 32 heads x 1024 tokens): at the 600M models' 256 tokens the round-1 kernel's 128-row
+    // workgroups fill the chip better (11.4 vs 12.2 us, profiles/r04/opbench_attn_hd48_v4_vs_v2.log); attention_variant 6 forces it.
+    if (g_attn_variant >= 4 && a.hd == 48 && a.bias == nullptr && !a.accumulate && !a.nk_batch && !a.trace && a.Nk % 64 == 0 && !a.tk &&
+        (g_attn_variant == 6 || (long long)a.B * a.H * ((a.N + 255) / 256) >= 200))
+        return launch_attention_v4_hd48(a, stream);
     // ... and its head_dim 96 form (attention_v4_96.hip): whole tiles, the text phase's mask on the VALU
     if (g_attn_variant >= 4 && a.hd == 96 && a.bias == nullptr && !a.accumulate && !a.nk_batch && !a.trace && a.Nk % 64 == 0 && a.Nk == a.Nkpad &&
         (!a.tk || (a.Tkpad <= 256 && a.Tkpad % 64 == 0)))

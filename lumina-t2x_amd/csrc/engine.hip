@@ -1350,14 +1350,14 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     LT_REQUIRE(name, "lt_set_option: null name");
     ++g_option_gen;  // captured graphs bake the kernel selection: every option change starts new graph keys
     if (strcmp(name, "graph") == 0) { g_graph = value != 0; return 0; }
-    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 5, "attention_variant must be 1 .. 5"); lt_set_attention_variant(value); return 0; }
+    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 6, "attention_variant must be 1 .. 6 (6 = 4 with the hd-48 one-wave kernel forced at every size)"); lt_set_attention_variant(value); return 0; }
     if (strcmp(name, "qkv_post_fused") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "qkv_post_fused must be 0, 1 or 2 (auto)"); g_qkv_post_fused = value; return 0; }
     if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
     if (strcmp(name, "qkv_fused_gemm") == 0) { g_qkv_fused_gemm = value != 0; return 0; }
     if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }
-    if (strcmp(name, "gemm_w4q_grouped") == 0) { lt_set_gemm_w4q_grouped(value != 0); return 0; }
+    if (strcmp(name, "gemm_w4q_grouped") == 0) { lt_set_gemm_w4q_grouped(value); return 0; }
     if (strcmp(name, "gemm_group") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_group must be 0..64"); lt_set_gemm_group(value); return 0; }
     if (strcmp(name, "gemm_stagger") == 0) { LT_REQUIRE(value >= 0 && value <= 256, "gemm_stagger must be 0..256"); return lt_set_gemm_stagger(value); }
     if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }

@@ -175,7 +175,7 @@ int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 25
 int g_gemm_stagger = 0;
 int g_gemm_group = 0;
 int g_gemm_w4q = 1;  // 1 (default): large dense GEMMs (>= one tile per CU) run on the persistent 16x16x32 kernel (256 / 288-wide tiles)
-int g_gemm_w4q_grouped = 1;  // 1 (default): grouped (MoE expert) GEMMs with >= one tile per CU as well (round 4)
+int g_gemm_w4q_grouped = 1;  // 1 (default): grouped (MoE expert) GEMMs with >= 1.5 tiles per CU as well (round 4; at one tile per CU - the 600M MoE at 256 tokens - the 8-wave tiles are 4 % faster)
 
 // the persistent kernel's grouped mode: expert segments (and gather-on-load) - one descriptor over all of A, lane offsets < 2^31
 // (gather: < 2^30, the out-of-range offset of a padding row is 2^30), <= 1024 row tiles in the LDS list, K >= 256 (the map of the
@@ -197,7 +197,7 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     if (epilogue == 3) { const int bn = gemm_qkv_fused_tile(a); return bn == 288 ? GK_W4Q288_QKV : bn == 256 ? GK_W4Q256_QKV : GK_NONE; }
     if (a.trace) return GK_EXPERIMENTAL;
     if (a.tile_expert && (variant == 15 || (variant == 0 && g_gemm_variant == 0 && g_gemm_w4q && g_gemm_w4q_grouped &&
-                                             (long long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 1LL * num_cus()))) {
+                                             2LL * ((a.M + 255) / 256) * ((a.N + 255) / 256) >= (g_gemm_w4q_grouped == 2 ? 4LL : 3LL) * num_cus()))) {
         if (w4q_grouped_ok(a, epilogue)) return epilogue == 1 ? GK_W4Q256_SWIGLU_GROUPED : GK_W4Q256_GROUPED;
         if (variant == 15) return GK_NONE;
     }
@@ -251,7 +251,7 @@ int launch_gemm_experimental(const GemmArgs& a, int epilogue, int variant, hipSt
 
 void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
 void lt_set_gemm_w4q(int v) { g_gemm_w4q = v; }
-void lt_set_gemm_w4q_grouped(int v) { g_gemm_w4q_grouped = v; }
+void lt_set_gemm_w4q_grouped(int v) { g_gemm_w4q_grouped = v; }  // 0 off, 1 from 1.5 tiles per CU (default), 2 from 2 tiles per CU (A/B)
 int lt_set_gemm_stagger(int v) { g_gemm_stagger = v; return 0; }
 void lt_set_gemm_group(int v) { g_gemm_group = v; }
 bool lt_gemm_has_experimental() {

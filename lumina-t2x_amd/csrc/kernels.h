@@ -137,6 +137,7 @@ int launch_region_text_combine(u16* out, const u16* txt, const u16* gate, int Y,
                                int h_split, int w_split, hipStream_t stream);
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 int launch_attention_v4(const AttnArgs& a, hipStream_t stream);  // hd 72, 4 waves x 64 query rows (attention_v4.hip)
+int launch_attention_v4_hd48(const AttnArgs& a, hipStream_t stream);  // hd 48, the same structure, softmax-bound (attention_v4_48.hip)
 int launch_attention_v4_hd96(const AttnArgs& a, hipStream_t stream);  // hd 96, the same structure without pad slots (attention_v4_96.hip)
 int launch_attention_v5(const AttnArgs& a, hipStream_t stream);  // the same with the PV product on 16x16x32 MFMAs (attention_v5.hip)
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch

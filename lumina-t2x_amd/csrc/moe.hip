@@ -112,8 +112,8 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
     if (p.sample_logits) {  // time router: the logits are per sample - route here, no separate launch (sel / wts written for combine)
         int cached_b = -1, s0 = 0, s1 = 0;
         u16 w0 = 0, w1 = 0;
-        for (int i = lo; i < hi; ++i) {
-            const int row = i >> 1, b = row / p.rows_per_sample;
+        auto route_row = [&](int row) __attribute__((always_inline)) {
+            const int b = row / p.rows_per_sample;
             if (b != cached_b || p.forced) {  // every token of a sample shares the two experts (unless the parity hook forces per-row choices)
                 float logit[MAX_E];
 #pragma unroll
@@ -121,16 +121,30 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
                 top2_route(logit, p.forced ? p.forced + 2 * row : nullptr, s0, s1, w0, w1);
                 cached_b = b;
             }
-            const int ex = (i & 1) ? s1 : s0;
-            p.sel[i] = ex;
-            p.wts[i] = (i & 1) ? w1 : w0;
-            if constexpr (PER > 0) ex_r[i - lo] = ex;
-        }
+        };
         if constexpr (PER > 0) {
+            // lo is even: the thread's entries are whole rows (entry 2 r = the row's first expert, 2 r + 1 its second) -> one 8-byte
+            // store of the pair's experts and one 4-byte store of its two bf16 weights per row; static register indices (a loop over
+            // [lo, hi) indexed ex_r dynamically, which put the array into scratch: 50 us per call)
 #pragma unroll
-            for (int j = 0; j < PER; ++j) if (lo + j >= hi) ex_r[j] = -1;
+            for (int j = 0; j < PER; j += 2) {
+                if (lo + j < hi) {
+                    route_row((lo + j) >> 1);
+                    ex_r[j] = s0; ex_r[j + 1] = s1;
+                    *(int2*)(p.sel + lo + j) = int2{s0, s1};
+                    *(unsigned*)(p.wts + lo + j) = (unsigned)w0 | ((unsigned)w1 << 16);
+                } else {
+                    ex_r[j] = -1; ex_r[j + 1] = -1;
+                }
+            }
+        } else {
+            for (int i = lo; i < hi; ++i) {
+                route_row(i >> 1);
+                p.sel[i] = (i & 1) ? s1 : s0;
+                p.wts[i] = (i & 1) ? w1 : w0;
+            }
+            __syncthreads();  // (sel is re-read below by the thread that wrote it)
         }
-        if constexpr (PER == 0) __syncthreads();  // (sel is re-read below by the thread that wrote it)
     } else if constexpr (PER > 0) {
         // n is even and lo a multiple of 4, but n need not be a multiple of 4: the last quad may run 2 entries past the end of sel -
         // the engine's table has room (capacity rows), the op-level entry pads its buffer; values past hi are masked below

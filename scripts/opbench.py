@@ -366,6 +366,9 @@ if __name__ == "__main__":
     if "gemm_b4" in a.what:  # cfg 1 at four image pairs per call (2048 rows)
         bench_gemm(a.rounds, [v if ("t" in v or "p" in v) else int(v) for v in a.gemm_variants.split(",")],
                    shapes=[(n, 4 * m, nn, k, e) for n, m, nn, k, e in SHAPES_CFG1], cold=a.cold)
+    if "attn48" in a.what:  # cfg 5 at 1024^2 / cfg 1: the 600M models, hd 48
+        bench_attn(a.rounds, [int(v) for v in a.attn_variants.split(",")], shape=(2, 32, 4096, 48))
+        bench_attn(a.rounds, [int(v) for v in a.attn_variants.split(",")], shape=(2, 32, 256, 48))
     if "attn_vendor" in a.what:
         bench_attn_vendor(a.rounds)
     if "elem" in a.what:

@@ -662,8 +662,8 @@ def test_attention_self(variant, B, H, Hkv, N, hd, fold):
     assert rel_l2(out, ref) < 6e-3, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("hd", [72, 96])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("hd", [72, 96, 48])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_attention_softmax_outlier_keys(variant, hd):
     """forces large running-max jumps mid-sequence, above and below the deferred-rescale threshold (guide 5.4
     rule 26); v1 (rescale every tile), v2 (threshold 8 in log2 units) and v3 (same threshold; hd 72: max folded into the
@@ -777,6 +777,41 @@ def test_attention_v4_is_bit_identical_to_v3(B, H, Hkv, N, outliers):
     ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), scale)
     assert rel_l2(outs[1], ref) < 6e-3
     assert rel_l2(outs[2], ref) < 6e-3
+
+
+@pytest.mark.parametrize("B,H,Hkv,N,outliers", [(2, 32, 32, 4096, False), (1, 8, 2, 1024, True), (1, 4, 4, 64, False), (1, 2, 2, 200 * 64, True), (2, 32, 32, 256, False),
+                                                 # tile counts 2, 3, 5, 6, 7 (mod 4 remainders of the ring-depth unrolled loop), ragged last q-block
+                                                 (1, 4, 4, 128, False), (1, 4, 2, 192, True), (1, 4, 4, 320, True), (2, 2, 2, 384, False), (1, 2, 1, 448, True)])
+@pytest.mark.parametrize("fold", [True, False])
+def test_attention_v4_hd48_against_the_v2_kernel_and_fp32(B, H, Hkv, N, outliers, fold):
+    """attn_fwd_kernel_v4h48 (round 4: the one-wave-per-SIMD structure at head_dim 48 - a fourth, pad-only k-step carries the folded
+    maximum, 64-row O^T with the row of ones, six-gap overhang of the softmax window into the block's own PV segment) against the
+    round-1 kernel (variant 2: fp32 maximum / row sum on the VALU - other rounding on purpose, as between the two hd-96 kernels) and
+    the exact softmax; the 600M models' shapes (32 heads, 256 and 4096 tokens), max moves late in the sequence, GQA, every remainder
+    of the unrolled tile loop, scale folded into K or applied to Q."""
+    hd = 48
+    g = torch.Generator().manual_seed(N + H + hd)
+    q = bf(torch.randn(B, H, N, hd, generator=g))
+    k = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    v = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    if outliers:
+        rep = H // Hkv
+        k[:, :, N // 2 + 3] = q[:, ::rep, 7] * 4.0
+        k[:, :, 5] = q[:, ::rep, N - 9] * 2.0
+        k[:, :, N - 64:] += q[:, ::rep, 40:41] * 1.5   # last tile above everything before it for row 40
+        k[:, :, :64] -= q[:, ::rep, 50:51] * 3.0
+    scale = math.sqrt(math.log(N, 64) / hd) if N > 64 else 1 / math.sqrt(hd)
+    outs = []
+    for variant in (2, 6):  # 6 = 4 with the hd-48 kernel forced (the dispatcher keeps the round-1 kernel below ~200 workgroups)
+        set_option("attention_variant", variant)
+        outs.append(_run_attn(q, k, v, scale, fold_scale=fold).clone())
+    ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), scale)
+    assert not torch.isnan(outs[1].float()).any()
+    assert rel_l2(outs[1], ref) < 6e-3, rel_l2(outs[1], ref)
+    # (measured at 2 x 32 x 4096: v4 3.0e-3, v2 2.4e-3 from the fp32 softmax, 4.1e-3 from each other: the folded maximum is a bf16 pair and
+    #  the row sum adds the bf16-rounded P the PV MFMA multiplies - the hd-72 / hd-96 one-wave kernels do the same)
+    assert rel_l2(outs[1], outs[0]) < 5e-3, rel_l2(outs[1], outs[0])
+    assert rel_l2(outs[1], ref) < 1.5 * rel_l2(outs[0], ref) + 1e-4, (rel_l2(outs[1], ref), rel_l2(outs[0], ref))
 
 
 @pytest.mark.parametrize("B,H,Hkv,N,outliers", [(2, 32, 32, 4160, False), (1, 8, 2, 1024, True), (1, 4, 4, 64, False), (1, 2, 2, 100 * 64, True),

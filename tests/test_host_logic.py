@@ -529,6 +529,7 @@ def test_generated_attention_accessors_are_in_sync_with_their_generator(tmp_path
     REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for gen, rel in (("gen_attn_v4_asm.py", ("lumina-t2x_amd", "csrc", "attention_v4_asm.inc")),
                      ("gen_attn_v4_96_asm.py", ("lumina-t2x_amd", "csrc", "attention_v4_96_asm.inc")),
+                     ("gen_attn_v4_48_asm.py", ("lumina-t2x_amd", "csrc", "attention_v4_48_asm.inc")),
                      ("gen_attn_v5_asm.py", ("lumina-t2x_amd", "csrc", "experimental", "attention_v5_asm.inc"))):
         committed = open(os.path.join(REPO, *rel)).read()
         # run the generator against a scratch copy of the tree layout (it writes next to its own location)
