@@ -276,7 +276,9 @@ def box_probe(lib, torch):
     """Which box did this run draw?  Boxes of this pool differ by up to 10 % under identical code (DESIGN.md status log: 29.2-30.7 vs
     32.97-34.5 ms per step), more than a round usually moves.  A fixed probe - the W1|W3-shaped GEMM (8192 x 12288 x 2304, random bf16
     operands, plain epilogue) run 40 times back to back after the timed regions - gives a number that depends on the box and the
-    library's one GEMM kernel only; `class` compares it with 1270 TFLOP/s (fast boxes read 1320-1340, slow ones 1190-1230)."""
+    library's one GEMM kernel only (it runs on a chip the timed regions have just heated, so it reads lower than a cold op-level
+    benchmark of the same kernel).  `class` compares it with 1170 TFLOP/s - a provisional cut: the calibration points are listed in
+    profiles/r04/NOTES_same_box_numbers.md (1220 on a box whose step took 29.0 ms); read `tflops`, not the label, when in doubt."""
     import ctypes as C
     M, N, K = 8192, 12288, 2304
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -297,7 +299,7 @@ def box_probe(lib, torch):
     e1.record()
     torch.cuda.synchronize()
     tf = 2.0 * M * N * K * 40 / (e0.elapsed_time(e1) * 1e-3) / 1e12
-    return {"probe": "gemm 8192x12288x2304 bf16, 40 launches back to back", "tflops": tf, "class": "fast" if tf >= 1270.0 else "slow", "threshold_tflops": 1270.0}
+    return {"probe": "gemm 8192x12288x2304 bf16, 40 launches back to back", "tflops": tf, "class": "fast" if tf >= 1170.0 else "slow", "threshold_tflops": 1170.0}
 
 
 def gemm_kernel_label(lib, M, d, F, dkv, tokens, hd):
