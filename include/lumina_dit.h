@@ -223,6 +223,13 @@ int lt_op_gemm_qkv(const void* A_dev, const void* W_dev, void* C_dev, void* vt_d
 int lt_op_gemm_qkv_fusable(int32_t M, int32_t N, int32_t K, int32_t split, int32_t tokens, int32_t hd);
 /* name of the kernel lt_op_gemm_bf16(..., variant) would launch for a dense problem (bench.py labels its roofline line with it) */
 int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap);
+/* lt_op_gemm_bf16 on the 64 x 128 small-M tile with the K range split over two workgroups per tile (round 4: how the engine runs the
+ * 512-row O / W2 projections of the 600M models - F.linear of Next-DiT-ImageNet/models/models.py:403, :494).  The caller lends the
+ * workspace: part_f32 [tiles][2][64 * 128] floats and counters_u32 [tiles] (zero before the first launch, left zero by every launch);
+ * tiles >= ceil(M / 64) * ceil(N / 128), K % 512 == 0, K >= 1024, else the call runs unsplit.  Launches sharing a workspace must be
+ * stream-ordered.  Result: bf16(fp32 sum of the two halves' fp32 partial sums) - independent of which half finishes last. */
+int lt_op_gemm_splitk(const void* A_dev, const void* W_dev, void* C_dev, int32_t M, int32_t N, int32_t K, void* part_f32_dev,
+                      void* counters_u32_dev, int32_t tiles, void* stream);
 /* grouped (mixture-of-experts) form of lt_op_gemm_bf16 - replaces the per-expert Python loop `for i, expert in
  * enumerate(self.experts): ... expert(x[batch_idx])` of Next-DiT-MoE/models/models2.py:470-476, :499-505 on expert-sorted
  * rows: rows [256 t, 256 t + 256) of A multiply with W_dev + tile_expert[t] * w_expert_stride (elements); tile_expert[t] < 0

@@ -138,6 +138,10 @@ struct lt_engine {
     // parity hooks (lt_moe_routing_*): [L][2 branches][max rows][2] expert ids, recorded from / forced onto moe_route_kernel
     int *moe_rec = nullptr, *moe_force = nullptr;
     int moe_rec_on = 0, moe_force_rows = 0, moe_rec_rows = 0;
+    // split-K workspace of the 512-row-class GEMMs (GemmArgs::splitk_*): 128 tiles = one round of half the CUs
+    float* splitk_part = nullptr;
+    unsigned* splitk_cnt = nullptr;
+    int splitk_tiles = 0;
     u16 *capb = nullptr, *capn = nullptr, *kvy = nullptr;
     float* txt_bias = nullptr;
     float* rope = nullptr;
@@ -220,6 +224,7 @@ int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.bias_dtype = bias ? 1 : -1;
+    g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;  // (the launcher decides)
     ProfScope ps(e, 0, 2.0 * M * (double)N * K, s, true);
     return launch_gemm_bf16(g, epi, 0, s, ps.ev0(), ps.ev1());
 }
@@ -912,6 +917,14 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         if (dev_alloc(e, &q, P * sizeof(int))) return fail();
         e->moe_src = (int*)q;
     }
+    {   // split-K workspace (zeroed by dev_alloc: the counters must start at 0; every launch leaves them at 0)
+        void* q;
+        e->splitk_tiles = 128;
+        if (dev_alloc(e, &q, (size_t)e->splitk_tiles * 2 * 64 * 128 * sizeof(float))) return fail();
+        e->splitk_part = (float*)q;
+        if (dev_alloc(e, &q, (size_t)e->splitk_tiles * sizeof(unsigned))) return fail();
+        e->splitk_cnt = (unsigned*)q;
+    }
     A16(e->patches, M * e->kpad); A16(e->frows, M * e->nfinal); A16(e->mod, Bm * e->ld_mod);
     A16(e->tfeat, Bm * 256); A16(e->t1, Bm * A); A16(e->temb, Bm * A);
     A16(e->cap_emb, Bm * A); A16(e->adaln_in, Bm * A);
@@ -1357,6 +1370,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }
+    if (strcmp(name, "gemm_splitk") == 0) { lt_set_gemm_splitk(value); return 0; }
     if (strcmp(name, "gemm_w4q_grouped") == 0) { lt_set_gemm_w4q_grouped(value); return 0; }
     if (strcmp(name, "gemm_group") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_group must be 0..64"); lt_set_gemm_group(value); return 0; }
     if (strcmp(name, "gemm_stagger") == 0) { LT_REQUIRE(value >= 0 && value <= 256, "gemm_stagger must be 0..256"); return lt_set_gemm_stagger(value); }
@@ -1412,6 +1426,16 @@ extern "C" int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epil
     g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = -1;
     snprintf(out, (size_t)cap, "%s", lt_gemm_describe(g, epilogue, variant));
     return 0;
+}
+
+extern "C" int lt_op_gemm_splitk(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, void* part_f32, void* counters_u32,
+                                 int32_t tiles, void* stream) {
+    LT_REQUIRE(A && W && C && part_f32 && counters_u32, "lt_op_gemm_splitk: null pointer");
+    LT_REQUIRE(M > 0 && N > 0 && K > 0, "lt_op_gemm_splitk: empty problem");
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.bias_dtype = -1; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+    g.splitk_part = (float*)part_f32; g.splitk_cnt = (unsigned*)counters_u32; g.splitk_tiles = tiles;
+    return launch_gemm_bf16(g, 0, 8, (hipStream_t)stream);  // variant 8 = the 64 x 128 tile, the only one that splits
 }
 
 extern "C" int lt_op_gemm_grouped(const void* A, const void* W, const void* tile_expert, int64_t w_expert_stride, void* C,

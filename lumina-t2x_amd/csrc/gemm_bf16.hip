@@ -124,7 +124,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     else fn = (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
     if (!func_attr_done(device_slot(), fn)) LT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
-    const dim3 grid(TM * TN), block(WM * WN * 64);
+    const dim3 grid(TM * TN * (a.split_k == 2 ? 2 : 1)), block(WM * WN * 64);
     if constexpr (PP) {
         if (ev0) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, 0, MODE, KS>), grid, block, SMEM, stream, ev0, ev1, 0, a);
         else hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, 0, MODE, KS>), grid, block, SMEM, stream, a);
@@ -175,6 +175,11 @@ int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 25
 int g_gemm_stagger = 0;
 int g_gemm_group = 0;
 int g_gemm_w4q = 1;  // 1 (default): large dense GEMMs (>= one tile per CU) run on the persistent 16x16x32 kernel (256 / 288-wide tiles)
+// split-K of the 512-row-class GEMMs (round 4).  A 64 x 128 workgroup of the O / W2 projections at 512 rows stages 0.6 / 1.6 MB through
+// a CU that fills at ~50 GB/s: cutting K in two halves the bytes per workgroup and doubles the busy CUs (96 -> 192).
+// Round 3 priced it with an equivalent-shape probe (O 15.9 -> 10.4 us, W2 30.9 -> 19.0 us) and declined because of the consumer-side
+// partial sums; here the second-arriving half adds the first one's fp32 partial itself (counter per tile), no consumer changes.
+int g_gemm_splitk = 1;
 int g_gemm_w4q_grouped = 1;  // 1 (default): grouped (MoE expert) GEMMs with >= 1.5 tiles per CU as well (round 4; at one tile per CU - the 600M MoE at 256 tokens - the 8-wave tiles are 4 % faster)
 
 // the persistent kernel's grouped mode: expert segments (and gather-on-load) - one descriptor over all of A, lane offsets < 2^31
@@ -251,6 +256,7 @@ int launch_gemm_experimental(const GemmArgs& a, int epilogue, int variant, hipSt
 
 void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
 void lt_set_gemm_w4q(int v) { g_gemm_w4q = v; }
+void lt_set_gemm_splitk(int v) { g_gemm_splitk = v; }
 void lt_set_gemm_w4q_grouped(int v) { g_gemm_w4q_grouped = v; }  // 0 off, 1 from 1.5 tiles per CU (default), 2 from 2 tiles per CU (A/B)
 int lt_set_gemm_stagger(int v) { g_gemm_stagger = v; return 0; }
 void lt_set_gemm_group(int v) { g_gemm_group = v; }
@@ -283,6 +289,13 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
     LT_REQUIRE(epilogue != 1 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
     LT_REQUIRE(variant >= 0 && variant <= 18, "gemm: unknown variant %d", variant);
     const GemmKernel k = choose(a, epilogue, variant);
+    // split-K: dense plain-epilogue problems on the 64 x 128 tiles whose two halves still fit one round of the CUs, K >= 1024
+    a.split_k = 0;
+    if (k == GK_S64 && g_gemm_splitk && (variant == 0 || variant == 8) && a.splitk_part && a.splitk_cnt && !a.tile_expert && !a.a_row_map && a.bias_dtype < 0 &&
+        a.K >= 1024 && a.K % 512 == 0) {
+        const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
+        if ((2 * tiles <= num_cus() || g_gemm_splitk == 2) && tiles <= a.splitk_tiles) a.split_k = 2;
+    }
     if (a.a_row_map) {  // gather-on-load lives in the ping-pong kernels' staging (the grouped SwiGLU GEMM of the MoE layers)
         LT_REQUIRE(k == GK_PP256_SWIGLU || k == GK_PP256 || k == GK_S128 || k == GK_S128_SWIGLU || k == GK_S64 || k == GK_W4Q256_GROUPED ||
                    k == GK_W4Q256_SWIGLU_GROUPED,

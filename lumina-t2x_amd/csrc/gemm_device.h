@@ -329,7 +329,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 
     const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
     int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, TM, TN, tm, tn);
+    // split-K (GemmArgs::split_k == 2): workgroups [0, tiles) take the first half of K, [tiles, 2 tiles) the second half of the same tiles
+    const int ntile = TM * TN;
+    const int ksplit = p.split_k == 2 ? (int)blockIdx.x / ntile : 0;
+    const int bid = p.split_k == 2 ? (int)blockIdx.x - ksplit * ntile : (int)blockIdx.x;
+    tile_coords(bid, p.split_k == 2 ? ntile : (int)gridDim.x, TM, TN, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const long long a_left = (long long)(p.M - m0) * p.lda * 2;
@@ -369,9 +373,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         }
         ldsoff[i] = q * 1024;
     }
+    const int kbase = p.split_k == 2 ? ksplit * p.K : 0;  // byte offset along K of this workgroup's range (K / 2 elements = K bytes)
     auto stage = [&](int slab) {
         char* base = smem + (slab & 3) * SLAB;
-        const int soff = slab * RB;
+        const int soff = kbase + slab * RB;
 #pragma unroll
         for (int i = 0; i < IP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i], LDS_PTR(base + ldsoff[i]), 16, voff[i], soff, 0, 0);
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int ns = p.K / (16 * KS);
+    const int ns = (p.split_k == 2 ? p.K / 2 : p.K) / (16 * KS);
     if constexpr (MODE == 2 && G == 1) stagger_start(p.stagger);  // 4-wave kernel only (variant 10)
     // prologue: slabs 0..2 in flight, slab 0 landed and visible
     stage(0);
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         constexpr int EVERY = HEAD / IP > 0 ? HEAD / IP : 1;
         int issued = 0;
         char* base = smem + ((s + 3) & 3) * SLAB;
-        const int soff = (s + 3) * RB;
+        const int soff = kbase + (s + 3) * RB;
 #pragma unroll
         for (int i = 0; i < HEAD; ++i) {
             one_mfma(i);
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
             // steady state only: slabs k+1 (read) and k+3 (staged) exist
             const char* sb = smem + ((k + 1) & 3) * SLAB;
             char* db = smem + ((k + 3) & 3) * SLAB;
-            const int soff = (k + 3) * RB;
+            const int soff = kbase + (k + 3) * RB;
             auto rd = [&](int r) __attribute__((always_inline)) {  // fragment read r of slab k+1, k-step major
                 const int kk = r / (MT + NT), j = r % (MT + NT);
                 if (j < NT) wn_[kk][j] = *(const bf16x8*)(sb + w_row_off + j * TSTRIDE + coff[kk]);
@@ -721,6 +726,47 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     unsigned long long t_loop_end = 0;
     if constexpr (TRACE) t_loop_end = __builtin_amdgcn_s_memtime();
 
+    if constexpr (MODE == 1 && KS == 4 && !TRACE)  // (the small-M tiles only: keeps the 256-wide instantiations' code as it was)
+    if (p.split_k == 2) {
+        // Both halves park their fp32 partial (register image, [register quad][thread] = coalesced 16-byte accesses); the second
+        // arriver at the tile's counter adds the first one's and stores the tile.  The two workgroups may sit on different XCDs, whose
+        // L2s are not coherent: the partials are stored and loaded SYSTEM-coherent (sc0 sc1: written through to / read from the memory
+        // side) and the counter is a system-scope atomic.  NOT __threadfence(): an agent-scope release / acquire on this part is
+        // buffer_wbl2 + buffer_inv - a write-back and invalidate of the XCD's whole 4 MiB L2 - and made every split GEMM 40 us slower.
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+        constexpr int PART_BYTES = BM * BN * 4, CP = 17;  // aux bits: sc0 | sc1
+        const __amdgpu_buffer_rsrc_t rMine = __builtin_amdgcn_make_buffer_rsrc((void*)(p.splitk_part + ((size_t)bid * 2 + ksplit) * (BM * BN)), 0, PART_BYTES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rOther = __builtin_amdgcn_make_buffer_rsrc((void*)(p.splitk_part + ((size_t)bid * 2 + (1 - ksplit)) * (BM * BN)), 0, PART_BYTES, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rMine, (((mt * NT + nt) * 4 + q) * (NW * 64) + tid) * 16, 0, CP);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's partial has reached the memory side ...
+        __syncthreads();                                   // ... before the workgroup reports in
+        int* flag = (int*)smem;  // (the slab ring is idle: every wave is past its last fragment read)
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.splitk_cnt + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (old == 1u) __hip_atomic_store(p.splitk_cnt + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // both arrived: free for the next launch
+            *flag = (int)old;
+        }
+        __syncthreads();
+        if (*flag == 0) return;  // first arriver (uniform)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rOther, (((mt * NT + nt) * 4 + q) * (NW * 64) + tid) * 16, 0, CP));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mt][nt][4 * q + j] += o[j];
+                }
+    }
     store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
 
     if constexpr (TRACE) {

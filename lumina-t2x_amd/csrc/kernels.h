@@ -29,6 +29,15 @@ struct GemmArgs {
     // the 288-column tile, vt_tokens of the 256-row tile.
     u16* VT = nullptr;
     int vt_split = 0;
+    // split-K (round 4, the 64 x 128 small-M tiles of gemm_bf16_pp only).  The CALLER lends a workspace (per engine = per stream:
+    // launches that share one must be ordered); launch_gemm_bf16 decides (split_k is its output): the K range is cut in two, both
+    // halves of a tile run as separate workgroups, each writes its fp32 partial tile to `splitk_part` and bumps the tile's counter;
+    // the second arriver adds the other half to its accumulators, resets the counter and runs the normal epilogue.  fp32 addition
+    // commutes, so the result does not depend on which half arrives last.
+    float* splitk_part = nullptr;    // [splitk_tiles][2][64 * 128] fp32, or null: never split
+    unsigned* splitk_cnt = nullptr;  // [splitk_tiles], zero between launches
+    int splitk_tiles = 0;
+    int split_k = 0;                 // set by the launcher: 0 off, 2 two halves
     int group_rows = 0;  // experiment knob (lt_set_option "gemm_group"): tile rows per group of the XCD-aware tile order (0 = 4)
     int stagger = 0;  // experiment knob of the 4-wave kernels (lt_set_option "gemm_stagger"), filled by the launcher
 };
@@ -147,6 +156,7 @@ void lt_set_gemm_w4q(int v);           // 1: large dense GEMMs on the persistent
 void lt_set_gemm_w4q_grouped(int v);   // 1: grouped (MoE expert) GEMMs with >= 2 tiles per CU on the persistent kernel too (default 1)
 int device_slot();                     // current HIP device id (0..63)
 bool func_attr_done(int dev, const void* fn);  // first call per (device, kernel) returns false: set the kernel's dynamic-LDS attribute then
+void lt_set_gemm_splitk(int v);        // 1 (default): 512-row-class O / W2 GEMMs split their K range over two workgroups per tile; 2: wherever the shape allows (tests)
 void lt_set_gemm_group(int v);          // tile rows per group in the tile order of the 16x16x32 kernel (experiment; 0 = default 4)
 int lt_set_gemm_stagger(int v);        // 4-wave kernels (variants 10, 13, 14): start-phase spread per XCD, units of ~256 cycles (0 = off)
 bool lt_gemm_has_experimental();       // built with EXPERIMENTAL=1 (variants 4-6, 9-12, trace builds, pipeline knobs)

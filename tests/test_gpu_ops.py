@@ -323,6 +323,43 @@ def test_gemm_grouped_gather_on_load(variant, epilogue):
         assert rel_l2(got[256 * 4: 256 * 4 + 131], y) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K,force", [(512, 1536, 1536, False), (512, 1536, 4096, False), (500, 1530 // 8 * 8, 1024, False), (64, 128, 1024, False),
+                                         (1024, 2304, 2048, True), (512, 1536, 768, False)])
+def test_gemm_splitk_small_m(M, N, K, force):
+    """round 4: the 512-row O / W2 projections of the 600M models with their K range split over two workgroups per 64 x 128 tile
+    (lt_op_gemm_splitk: the second-arriving half adds the first one's fp32 partial, counter per tile).  Against the unsplit kernel on
+    the same tile (equal to fp32 rounding of one addition) and the fp32 reference; ragged M / N; a shape that must NOT split (K = 768:
+    runs unsplit, bit-identical); `force` = more tiles than one round (gemm_splitk 2); the counters are back at zero afterwards and a
+    second launch on the same workspace gives the same bits (the result cannot depend on arrival order)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    tiles = ((M + 63) // 64) * ((N + 127) // 128)
+    part = torch.full((tiles * 2 * 64 * 128,), float("nan"), device="cuda", dtype=torch.float32)
+    cnt = torch.zeros(tiles, device="cuda", dtype=torch.int32)
+    plain = _gemm(A, W, variant=8)
+    if force:
+        set_option("gemm_splitk", 2)
+    try:
+        outs = []
+        for _ in range(2):
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ok(lib().lt_op_gemm_splitk(P(A), P(W), P(out), M, N, K, P(part), P(cnt), tiles, stream()), "gemm_splitk")
+            torch.cuda.synchronize()
+            outs.append(out)
+            assert int(cnt.abs().sum()) == 0, "a tile counter was left non-zero"
+    finally:
+        set_option("gemm_splitk", 1)
+    assert torch.equal(outs[0], outs[1])
+    split_ran = not torch.isnan(part).all()
+    assert split_ran == (K >= 1024 and K % 512 == 0 and (force or 2 * tiles <= 256))
+    if not split_ran:
+        assert torch.equal(outs[0], plain)
+    ref = A.float() @ W.float().t()
+    assert rel_l2(outs[0], ref) < 4e-3, rel_l2(outs[0], ref)
+    assert rel_l2(outs[0], plain) < 2e-3, rel_l2(outs[0], plain)
+
+
 @pytest.mark.parametrize("epilogue", [0, 1])
 @pytest.mark.parametrize("K,N,ntile,gather", [(512, 4096, 44, True), (1536, 640, 9, True), (256, 2048, 40, False), (4096, 1536, 36, False)])
 def test_gemm_grouped_persistent_kernel(K, N, ntile, gather, epilogue):
