@@ -272,13 +272,16 @@ def cpu_baseline(latent, n_tokens):
     return res
 
 
-def box_probe(lib, torch):
-    """Which box did this run draw?  Boxes of this pool differ by up to 10 % under identical code (DESIGN.md status log: 29.2-30.7 vs
-    32.97-34.5 ms per step), more than a round usually moves.  A fixed probe - the W1|W3-shaped GEMM (8192 x 12288 x 2304, random bf16
-    operands, plain epilogue) run 40 times back to back after the timed regions - gives a number that depends on the box and the
-    library's one GEMM kernel only (it runs on a chip the timed regions have just heated, so it reads lower than a cold op-level
-    benchmark of the same kernel).  `class` compares it with 1170 TFLOP/s - a provisional cut: the calibration points are listed in
-    profiles/r04/NOTES_same_box_numbers.md (1220 on a box whose step took 29.0 ms); read `tflops`, not the label, when in doubt."""
+def box_probe(lib, torch, power):
+    """Which box did this run draw?  Boxes of this pool differ by up to 10 % under identical code (29.0-30.2 vs 32.9-34.5 ms per step in
+    round 4's own runs), more than a round usually moves.  Two readings, both independent of the engine's kernels' scheduling:
+      * `avg_w` - socket power averaged over the timed region.  This is what separates the classes: every slow box of round 4 drew
+        1173-1203 W under the step, every fast one ~1285 W (calibration table in profiles/r04/NOTES_same_box_numbers.md) - the slow
+        class runs under a lower power limit, and an MFMA-bound step is power-bound (DESIGN.md 5.6).  `class` cuts at 1240 W;
+        `power_cap_w` is the limit amdsmi reports, when it reports one.
+      * `probe_tflops` - a fixed GEMM (8192 x 12288 x 2304, random bf16, plain epilogue) run 40 times after the timed regions.  It reads
+        1198-1220 on BOTH classes: 15 ms of one kernel do not reach the limit a 30-ms mixed step lives under.  Kept as the evidence
+        that the classes do not differ in what a single kernel can do."""
     import ctypes as C
     M, N, K = 8192, 12288, 2304
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -299,7 +302,19 @@ def box_probe(lib, torch):
     e1.record()
     torch.cuda.synchronize()
     tf = 2.0 * M * N * K * 40 / (e0.elapsed_time(e1) * 1e-3) / 1e12
-    return {"probe": "gemm 8192x12288x2304 bf16, 40 launches back to back", "tflops": tf, "class": "fast" if tf >= 1170.0 else "slow", "threshold_tflops": 1170.0}
+    avg_w = (power or {}).get("avg_w")
+    cap = None
+    try:
+        import amdsmi
+        h = amdsmi.amdsmi_get_processor_handles()[0]
+        info = amdsmi.amdsmi_get_power_cap_info(h)
+        cap = info.get("power_cap")
+        if isinstance(cap, (int, float)) and cap > 10000:
+            cap = cap / 1e6  # microwatts on some amdsmi versions
+    except Exception:
+        pass
+    return {"avg_w": avg_w, "power_cap_w": cap, "class": None if avg_w is None else ("fast" if avg_w >= 1240.0 else "slow"), "class_cut_w": 1240.0,
+            "probe": "gemm 8192x12288x2304 bf16, 40 launches back to back", "probe_tflops": tf}
 
 
 def gemm_kernel_label(lib, M, d, F, dkv, tokens, hd):
@@ -469,7 +484,7 @@ def main():
             "n_gpus": 1 if share else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_repeats": repeats_ms,
-            "box": box_probe(_lib.load(), torch),
+            "box": None,  # filled below (needs the power report)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (wl["desc"] + ", text T=128, CFG=4 (cond+uncond B=2), proportional attention, "
@@ -503,6 +518,7 @@ def main():
                                    "generate.py:212-219, tests/golden/solver_kat.npz); rk4 / dopri5 restate torchdiffeq (absent "
                                    "everywhere) and stay unpinned, DESIGN.md 6",
         }
+        out["box"] = box_probe(_lib.load(), torch, out["power"])
         if share:
             out.update(ranks=world, shared_device=True,
                        note="ranks share GPU 0 over gloo: exercises launcher / rank / shard / relay logic with the real engine; NOT a scaling "
