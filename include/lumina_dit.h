@@ -223,6 +223,16 @@ int lt_op_gemm_qkv(const void* A_dev, const void* W_dev, void* C_dev, void* vt_d
 int lt_op_gemm_qkv_fusable(int32_t M, int32_t N, int32_t K, int32_t split, int32_t tokens, int32_t hd);
 /* name of the kernel lt_op_gemm_bf16(..., variant) would launch for a dense problem (bench.py labels its roofline line with it) */
 int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap);
+/* the routing plan of one mixture-of-experts FFN (what replaces the host loop `for i, expert in enumerate(self.experts): batch_idx, nth =
+ * torch.where(selected == i)` of Next-DiT-MoE/models/models2.py:470-476, :499-505): sel_dev int32 [rows][2] = every row's two experts in
+ * ascending id (lt_op_attention-style callers write it; with sample_logits_dev != null - bf16 [rows / rows_per_sample][E], the time
+ * branch - the kernel routes first and WRITES sel_dev and the bf16 softmax weights wts_dev [rows][2]).  Outputs: pos_dev int32
+ * [rows][2] sorted position of each (row, expert) entry; src_dev int32 [max_tiles * 256] row of each sorted position, -1 = padding;
+ * tile_expert_dev int32 [max_tiles] expert of each 256-row tile, -1 behind the last segment.  Segments are in expert order, each
+ * starts on a tile, entries keep their row order inside a segment.  sel_dev / pos_dev need 4 ints of slack behind the last entry
+ * (16-byte accesses); max_tiles * 256 >= 2 rows + E * 255.  Integer work: bit-exact against oracle/moe_plan_oracle.py. */
+int lt_op_moe_plan(void* sel_dev, const void* sample_logits_dev, void* wts_dev, int32_t rows, int32_t rows_per_sample, int32_t E, void* pos_dev,
+                   void* src_dev, void* tile_expert_dev, int32_t max_tiles, void* stream);
 /* lt_op_gemm_bf16 on the 64 x 128 small-M tile with the K range split over two workgroups per tile (round 4: how the engine runs the
  * 512-row O / W2 projections of the 600M models - F.linear of Next-DiT-ImageNet/models/models.py:403, :494).  The caller lends the
  * workspace: part_f32 [tiles][2][64 * 128] floats and counters_u32 [tiles] (zero before the first launch, left zero by every launch);

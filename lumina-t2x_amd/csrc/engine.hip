@@ -1428,6 +1428,17 @@ extern "C" int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epil
     return 0;
 }
 
+extern "C" int lt_op_moe_plan(void* sel, const void* sample_logits, void* wts, int32_t rows, int32_t rows_per_sample, int32_t E, void* pos,
+                              void* src, void* tile_expert, int32_t max_tiles, void* stream) {
+    LT_REQUIRE(sel && pos && src && tile_expert, "lt_op_moe_plan: null pointer");
+    LT_REQUIRE(sample_logits == nullptr || wts != nullptr, "lt_op_moe_plan: routing from per-sample logits writes the weights too");
+    MoeArgs m;
+    m.x = nullptr; m.gate_w = nullptr; m.sample_logits = (const u16*)sample_logits; m.forced = nullptr;
+    m.rows = rows; m.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : rows; m.d = 8; m.E = E;
+    m.sel = (int*)sel; m.wts = (u16*)wts; m.pos = (int*)pos; m.src = (int*)src; m.tile_expert = (int*)tile_expert; m.max_tiles = max_tiles;
+    return launch_moe_plan(m, (hipStream_t)stream);
+}
+
 extern "C" int lt_op_gemm_splitk(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, void* part_f32, void* counters_u32,
                                  int32_t tiles, void* stream) {
     LT_REQUIRE(A && W && C && part_f32 && counters_u32, "lt_op_gemm_splitk: null pointer");

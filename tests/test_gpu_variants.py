@@ -238,6 +238,27 @@ def test_moe_600m_width_two_layers_vs_oracle():
     assert rel_l2(got, floor) < max(3e-2, 1.5 * f_all), (rel_l2(got, floor), f_all)
 
 
+def test_moe_many_rows_takes_the_generic_plan_walk():
+    """moe_plan holds a thread's entries in registers up to 32 per thread (round 4); beyond 16 384 rows (2 x 8464 tokens here: 33 856
+    (token, expert) entries, 34 per thread) it falls back to the round-3 walk over memory - time branch routed inside the kernel
+    included.  Tiny widths, full routing / grouped-GEMM / combine path, against the oracle at the reference's rounding points."""
+    cfg = synth.TINY_MOE
+    sd = synth.synth_state_dict(cfg, seed=47)
+    z, t, y = synth.synth_inputs(cfg, latent_hw=(184, 184), seed=48)
+    model = models.moe.DiT_Llama(**cfg.ctor_kwargs())
+    model.load_state_dict(sd, strict=True)
+    model = model.eval().to("cuda", torch.bfloat16)
+    zb = z.to("cuda", torch.bfloat16)
+    assert 2 * 2 * (184 // 2) ** 2 > 32 * 1024
+    got = model.forward_with_cfg(zb, t.cuda(), y.cuda(), 4.0)
+    want = V.imagenet_forward_with_cfg(sd, cfg, zb.float().cpu(), t, y, 4.0)
+    floor = V.imagenet_forward_with_cfg(sd, cfg, zb.float().cpu(), t, y, 4.0, bf16=True)
+    f_all = rel_l2(floor, want)
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, want) < max(TOL_CFG4, 1.5 * f_all), (rel_l2(got, want), f_all)
+    assert rel_l2(got, floor) < max(3e-2, 1.5 * f_all), (rel_l2(got, floor), f_all)
+
+
 @pytest.mark.parametrize("name", ["compositional_tiny", "compositional_tiny_1x3"])
 def test_compositional_regional_attention_engine_vs_reference_golden(golden_dir, name):
     """models.compositional.NextDiT (lumina_next_compositional_generation/models/model.py:422-446, :852-955) on the engine:
