@@ -30,7 +30,7 @@ void lt_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lt_last_error(void) { return g_err; }
-extern "C" const char* lt_version(void) { return lt_gemm_has_experimental() ? "lumina_dit gfx950 r3+experimental" : "lumina_dit gfx950 r3"; }
+extern "C" const char* lt_version(void) { return lt_gemm_has_experimental() ? "lumina_dit gfx950 r4+experimental" : "lumina_dit gfx950 r4"; }
 
 namespace {
 
