@@ -276,9 +276,10 @@ def box_probe(lib, torch, power):
     """Which box did this run draw?  Boxes of this pool differ by up to 10 % under identical code (29.0-30.2 vs 32.9-34.5 ms per step in
     round 4's own runs), more than a round usually moves.  Two readings, both independent of the engine's kernels' scheduling:
       * `avg_w` - socket power averaged over the timed region.  This is what separates the classes: every slow box of round 4 drew
-        1173-1203 W under the step, every fast one ~1285 W (calibration table in profiles/r04/NOTES_same_box_numbers.md) - the slow
-        class runs under a lower power limit, and an MFMA-bound step is power-bound (DESIGN.md 5.6).  `class` cuts at 1240 W;
-        `power_cap_w` is the limit amdsmi reports, when it reports one.
+        1173-1203 W under the step, every fast one ~1285 W (calibration table in profiles/r04/NOTES_same_box_numbers.md) - an
+        MFMA-bound step is power-bound, so a box that sustains fewer watts is slower in proportion.  It is a
+        continuum more than two classes (a 30.4 ms box drew 1208 W), and it is not the configured cap: `power_cap_w` (what amdsmi
+        reports) read 1400 W on that box.  `class` cuts at 1240 W.
       * `probe_tflops` - a fixed GEMM (8192 x 12288 x 2304, random bf16, plain epilogue) run 40 times after the timed regions.  It reads
         1198-1220 on BOTH classes: 15 ms of one kernel do not reach the limit a 30-ms mixed step lives under.  Kept as the evidence
         that the classes do not differ in what a single kernel can do."""
