@@ -123,3 +123,33 @@ def test_bench_launches_two_ranks_on_one_gpu():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["ranks"] == 2 and rec["shared_device"] is True and rec["steps"] == 3 and rec["value"] > 0
     assert "NOT a scaling" in rec["note"]
+
+
+def _worker_rccl_one_rank(rank, world, port, out_dir):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    # exactly the call parallel.init_distributed makes for world > 1 (backend "nccl" = RCCL, bound to the rank's device)
+    torch.distributed.init_process_group("nccl", device_id=dev)
+    t = torch.arange(8, device=dev, dtype=torch.float32)
+    torch.distributed.broadcast(t, 0)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    h = torch.ones(3, 4, device=dev, dtype=torch.bfloat16)
+    bufs = [torch.empty_like(h)]
+    torch.distributed.gather(h, bufs, dst=0)
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32)) and torch.equal(bufs[0], h)
+    assert parallel.max_over_ranks(2.5, dev) == 2.5  # world 1: early return, no collective
+    open(os.path.join(out_dir, "ok"), "w").write("1")
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_communicator_and_collectives_with_one_rank(tmp_path):
+    """What a one-GPU lease CAN say about the RCCL path: the `nccl` backend initialises with `device_id` on this stack and the four
+    collectives parallel.py uses (broadcast, all_reduce MAX, gather, barrier) run on device tensors - with ONE rank, i.e. no xGMI
+    traffic and no peer.  It catches a missing RCCL library, an init signature the installed torch rejects, or an IPC-mode
+    environment that breaks communicator creation; it is not a multi-GPU test."""
+    mp.spawn(_worker_rccl_one_rank, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok").exists()
