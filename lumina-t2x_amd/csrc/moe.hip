@@ -257,6 +257,75 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
     }
 }
 
+// Time branch without the parity hook: every token of a sample shares its two experts, so the plan is closed form - expert e's segment
+// holds, sample by sample, the N rows of every sample that selected e - and needs no scan: any number of workgroups, each thread one
+// row (round 4: the single-workgroup kernel took 26 us per TimeMoeLayer at 8192 rows, this one a few).  Every workgroup recomputes the
+// B routings and the E segment offsets (B x E bf16 loads), then writes its rows' sel / wts / pos / src and its slice of the padding
+// positions and of the tile table.  Same outputs as moe_plan_kernel, bit for bit (tests/test_moe_plan.py).
+constexpr int PLAN_T_MAXB = 64;
+__global__ __launch_bounds__(256) void moe_plan_time_kernel(MoeArgs p) {
+    __shared__ int s_sel[PLAN_T_MAXB][2], s_base[PLAN_T_MAXB][2], s_off[MAX_E], s_cnt[MAX_E];
+    __shared__ u16 s_w[PLAN_T_MAXB][2];
+    const int tid = threadIdx.x;
+    const int N = p.rows_per_sample, B = p.rows / N;
+    if (tid < B) {
+        float logit[MAX_E];
+#pragma unroll
+        for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[tid * p.E + e]) : -INFINITY;
+        int a, b;
+        u16 wa, wb;
+        top2_route(logit, nullptr, a, b, wa, wb);
+        s_sel[tid][0] = a; s_sel[tid][1] = b; s_w[tid][0] = wa; s_w[tid][1] = wb;
+    }
+    __syncthreads();
+    if (tid < p.E) {  // samples that selected expert `tid`
+        int c = 0;
+        for (int b = 0; b < B; ++b) c += (s_sel[b][0] == tid) + (s_sel[b][1] == tid);
+        s_cnt[tid] = c * N;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int off = 0;
+        for (int e = 0; e < p.E; ++e) { s_off[e] = off; off += (s_cnt[e] + TILE - 1) / TILE * TILE; }
+    }
+    __syncthreads();
+    if (tid < B) {  // this sample's block inside each of its two experts' segments: behind the blocks of the samples before it
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = s_sel[tid][k];
+            int before = 0;
+            for (int b = 0; b < tid; ++b) before += (s_sel[b][0] == e) + (s_sel[b][1] == e);
+            s_base[tid][k] = s_off[e] + before * N;
+        }
+    }
+    __syncthreads();
+    const int row = blockIdx.x * 256 + tid;
+    if (row < p.rows) {
+        const int b = row / N, j = row - b * N;
+        const int q0 = s_base[b][0] + j, q1 = s_base[b][1] + j;
+        *(int2*)(p.sel + 2 * row) = int2{s_sel[b][0], s_sel[b][1]};
+        *(unsigned*)(p.wts + 2 * row) = (unsigned)s_w[b][0] | ((unsigned)s_w[b][1] << 16);
+        *(int2*)(p.pos + 2 * row) = int2{q0, q1};
+        p.src[q0] = row;
+        p.src[q1] = row;
+    }
+    // padding positions and the tile table, sliced over the grid
+    const int P = p.max_tiles * TILE;
+    for (int q = blockIdx.x * 256 + tid; q < P; q += gridDim.x * 256) {
+        bool real = false;
+        for (int e = 0; e < p.E; ++e) real |= q >= s_off[e] && q < s_off[e] + s_cnt[e];
+        if (!real) p.src[q] = -1;
+    }
+    for (int t = blockIdx.x * 256 + tid; t < p.max_tiles; t += gridDim.x * 256) {
+        int ex = -1;
+        for (int e = 0; e < p.E; ++e) {
+            const int t0 = s_off[e] / TILE, t1 = (s_off[e] + s_cnt[e] + TILE - 1) / TILE;
+            if (t >= t0 && t < t1) ex = e;
+        }
+        p.tile_expert[t] = ex;
+    }
+}
+
 }  // namespace
 
 static int check(const MoeArgs& a) {
@@ -277,6 +346,11 @@ int launch_moe_route(const MoeArgs& a, hipStream_t stream) {
 int launch_moe_plan(const MoeArgs& a, hipStream_t stream) {
     if (check(a)) return 2;
     LT_REQUIRE(2LL * a.rows <= 1024LL * 1023, "moe_plan: %d rows exceed the packed 16-bit counters of the scan (523776 rows)", a.rows);
+    if (a.sample_logits && !a.forced && a.rows % a.rows_per_sample == 0 && a.rows / a.rows_per_sample <= PLAN_T_MAXB) {  // closed form
+        hipLaunchKernelGGL(moe_plan_time_kernel, dim3((a.rows + 255) / 256), dim3(256), 0, stream, a);
+        LT_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     const int per = (2 * a.rows + 1023) / 1024;  // entries per thread; the register forms hold a multiple of 4
     if (per <= 4) hipLaunchKernelGGL(moe_plan_kernel<4>, dim3(1), dim3(1024), 0, stream, a);
     else if (per <= 8) hipLaunchKernelGGL(moe_plan_kernel<8>, dim3(1), dim3(1024), 0, stream, a);
