@@ -225,6 +225,7 @@ int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.bias_dtype = bias ? 1 : -1;
     g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;  // (the launcher decides)
+    if (g_gemm_prefetch == 1 && M <= 1024 && launch_gemm_prefetch_w(g, epi, s)) return 1;
     ProfScope ps(e, 0, 2.0 * M * (double)N * K, s, true);
     return launch_gemm_bf16(g, epi, 0, s, ps.ev0(), ps.ev1());
 }
@@ -1370,6 +1371,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }
+    if (strcmp(name, "gemm_prefetch") == 0) { lt_set_gemm_prefetch(value); return 0; }
     if (strcmp(name, "gemm_splitk") == 0) { lt_set_gemm_splitk(value); return 0; }
     if (strcmp(name, "gemm_w4q_grouped") == 0) { lt_set_gemm_w4q_grouped(value); return 0; }
     if (strcmp(name, "gemm_group") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_group must be 0..64"); lt_set_gemm_group(value); return 0; }

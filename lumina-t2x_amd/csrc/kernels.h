@@ -44,6 +44,9 @@ struct GemmArgs {
 // ev0 / ev1: optional start / stop events carried by the dispatch packet itself (profiling without extra queue packets)
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0 = nullptr,
                      hipEvent_t ev1 = nullptr);
+int launch_gemm_prefetch_w(const GemmArgs& a, int epilogue, hipStream_t stream);  // experiment: W panels of a small-M GEMM -> the L2 of the XCDs that will stage them
+void lt_set_gemm_prefetch(int v);
+extern int g_gemm_prefetch;
 bool gemm_qkv_fusable(const GemmArgs& a);  // epilogue 3 can take this problem (else: one plain launch for Q | K + one V^T launch)
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream);
 

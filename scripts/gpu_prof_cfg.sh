@@ -8,6 +8,6 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$CFG
 rm -rf $OUT /tmp/prof_$CFG; mkdir -p $OUT
 cd $R
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$CFG -o run -- python scripts/bench_configs.py $CFG --nfe 16 > $OUT/run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$CFG -o run -- python scripts/bench_configs.py $CFG --nfe 16 ${PROF_EXTRA:-} > $OUT/run.log 2>&1
 echo "exit $?"; tail -2 $OUT/run.log
 for f in $(find /tmp/prof_$CFG -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; head -24 $f | cut -c1-160; done
