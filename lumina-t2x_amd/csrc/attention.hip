@@ -966,8 +966,17 @@ void lt_set_attention_variant(int v) { g_attn_variant = v; }
 // true when launch_attention() can take the text keys along with the image keys (one kernel instead of two)
 bool attention_fuses_text(int hd) { return g_attn_variant >= 3 && (hd == 72 || hd == 96); }
 
+// the dispatch condition of attn_fwd_kernel_v4<72> (launch_attention below uses the same expression)
+bool attention_takes_raw_q(const AttnArgs& a) {
+    return g_attn_variant >= 4 && g_attn_variant != 5 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 &&
+           (!a.tk || a.Tkpad <= 256);
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
     LT_REQUIRE(a.H % a.Hkv == 0, "attention: H=%d not a multiple of Hkv=%d", a.H, a.Hkv);
+    LT_REQUIRE(a.q_raw == nullptr || (attention_takes_raw_q(a) && a.q_stat && a.q_ln_w && a.q_ln_b && a.rope_cs && a.rope_cs_t && a.rope_grid_w > 0 && a.rope_cs_len > 0),
+               "attention: q_raw (q_norm + RoPE in the prologue) needs the head_dim-72 one-wave kernel's conditions and the LayerNorm / RoPE inputs");
+    LT_REQUIRE(a.q != nullptr || a.q_raw != nullptr, "attention: no query tensor");
     LT_REQUIRE(a.Nkpad % 64 == 0 && a.Nkpad >= a.Nk && a.Nk > 0 && a.N > 0, "attention: bad key counts Nk=%d Nkpad=%d", a.Nk, a.Nkpad);
     LT_REQUIRE(!a.accumulate || a.gate != nullptr, "attention: accumulate mode needs a gate");
     LT_REQUIRE(a.scale > 0.f, "attention: softmax scale must be positive");

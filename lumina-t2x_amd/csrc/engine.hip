@@ -46,6 +46,7 @@ int g_qkv_vt_epilogue = 1;
 int g_qkv_fused_gemm = 1;  // lt_set_option("qkv_fused_gemm"): Q | K | V in one launch of the persistent kernel where the shapes allow it
 // lt_set_option("graph"): 1 = a model evaluation (~250 launches) is captured into a HIP graph per (arguments, shapes) and replayed.
 // Every lt_set_option bumps g_option_gen, which is part of the graph key (kernel selection is baked into a captured graph).
+int g_attn_q_fused = 1;  // lt_set_option("attn_q_fused"): q_norm + RoPE of the queries inside the attention prologue (hd 72 one-wave kernel, fused QKV GEMM)
 int g_qk_post_pair = 1;  // lt_set_option("qk_post_pair"): 1 = q and k post-processing share one persistent launch (large problems)
 int g_graph = 1;
 int g_option_gen = 0;
@@ -138,6 +139,9 @@ struct lt_engine {
     // parity hooks (lt_moe_routing_*): [L][2 branches][max rows][2] expert ids, recorded from / forced onto moe_route_kernel
     int *moe_rec = nullptr, *moe_force = nullptr;
     int moe_rec_on = 0, moe_force_rows = 0, moe_rec_rows = 0;
+    float* qstat = nullptr;  // [rows][32] float2: LayerNorm partial sums of the Q columns, written by the fused QKV GEMM (GemmArgs::qstat)
+    float* qmr = nullptr;    // [rows] float2 (mean, rstd) of the Q rows, reduced from qstat by the K pass of qk_norm_rope (AttnArgs::q_stat)
+    float* rope_tr = nullptr;  // the 2-D rotary table once more as [branch][freq][pos] (AttnArgs::rope_cs_t)
     // split-K workspace of the 512-row-class GEMMs (GemmArgs::splitk_*): 128 tiles = one round of half the CUs
     float* splitk_part = nullptr;
     unsigned* splitk_cnt = nullptr;
@@ -367,11 +371,11 @@ int ensure_rope(lt_engine* e, const lt_step_args* a, hipStream_t s) {
     const float sf = a->scale_factor > 0.f ? a->scale_factor : 1.0f;
     if (e->rope_scale == sf && e->rope_ntk == ntk) return 0;
     if (e->cfg.variant == LT_VARIANT_NEXT_T2I) {
-        if (launch_rope_table_2d(e->rope, e->rope_len, e->hd, 10000.0f, sf, s)) return 1;
+        if (launch_rope_table_2d(e->rope, e->rope_len, e->hd, 10000.0f, sf, s, e->rope_tr)) return 1;
     } else {
         // both branches identical: theta * ntk_factor, positions / rope_scaling_factor (models.py:1001-1005, model.py:948-955)
         const int step = e->v.rope_1d ? 2 : 4;
-        if (launch_rope_table(e->rope, e->rope_len, e->hd, step, 10000.0f * ntk, sf, 10000.0f * ntk, sf, 1, s)) return 1;
+        if (launch_rope_table(e->rope, e->rope_len, e->hd, step, 10000.0f * ntk, sf, 10000.0f * ntk, sf, 1, s, e->rope_tr)) return 1;
     }
     e->rope_scale = sf;
     e->rope_ntk = ntk;
@@ -565,7 +569,25 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         GemmArgs gq;
         gq.A = e->h; gq.W = w.wqkv; gq.C = e->qkv; gq.bias = nullptr; gq.bias_dtype = -1; gq.M = M; gq.N = d + 2 * dkv; gq.K = d;
         gq.lda = d; gq.ldw = d; gq.ldc = e->qkvn; gq.VT = e->vt; gq.vt_split = d + dkv; gq.vt_tokens = N; gq.vt_hd = hd; gq.vt_npad = Npad;
+        // round 4: with the fused launch the Q columns' LayerNorm partial sums leave the GEMM epilogue and the attention kernel's prologue
+        // does q_norm + RoPE itself (AttnArgs::q_raw): qk_norm_rope then runs for K only.  Conditions: the hd-72 one-wave kernel takes
+        // the call (whole tiles, no packed batch), 2-D RoPE, qk_norm on, text keys fused into the launch or absent, not regional.
+        const bool regional = v.text && e->reg_Y > 0;
+        const bool fuse_text = v.text && !regional && attention_fuses_text(hd);
+        AttnArgs at;
+        at.q = e->q; at.k = e->k; at.vt = e->vt; at.bias = nullptr; at.out = e->attn; at.gate = nullptr; at.accumulate = 0;
+        at.B = B; at.H = H; at.Hkv = Hkv; at.N = N; at.Nk = N; at.Nkpad = Npad; at.hd = hd; at.scale = sm_scale;
+        at.k_prescaled = 1;
+        at.nk_batch = ntok_dev;
+        if (fuse_text) {  // zero-init gated text cross-attention (model.py:420-434) inside the same launch
+            at.tk = w.ky; at.tvt = w.vty; at.tbias = e->txt_bias; at.tgate = w.gate; at.Tk = e->prompt_T; at.Tkpad = e->prompt_Tpad;
+        }
+        bool raw_q = false;
         if (vt_epi && g_qkv_fused_gemm && gemm_qkv_fusable(gq)) {
+            const int bn = gemm_qkv_tile_width(gq);
+            raw_q = g_attn_q_fused && c.qk_norm && !v.rope_1d && !pk && !regional && (fuse_text || !v.text) && attention_takes_raw_q(at) &&
+                    bn > 0 && d % bn == 0 && 2 * d / bn <= 32;
+            if (raw_q) { gq.qstat = e->qstat; gq.qstat_cols = d; gq.qstat_slots = 2 * d / bn; }
             ProfScope ps(e, 0, 2.0 * M * (double)(d + 2 * dkv) * d, s, true);
             if (launch_gemm_bf16(gq, 3, 0, s, ps.ev0(), ps.ev1())) return 1;
         } else if (vt_epi) {
@@ -593,7 +615,15 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             pa.k = qa;
             pa.v_src = e->qkv; pa.v_dst = e->vt; pa.v_ld_src = e->qkvn; pa.v_col0 = d + dkv; pa.v_B = B; pa.v_N = N;
             pa.v_Npad = Npad; pa.v_kv_heads = Hkv; pa.v_hd = hd;
-            if (!vt_epi && (g_qkv_post_fused == 1 || (g_qkv_post_fused == 2 && M < 2048))) {
+            if (raw_q) {
+                // K only: the queries are normalised and rotated by the attention prologue; the K pass reduces their LayerNorm partials
+                pa.k.qstat_in = e->qstat; pa.k.qstat_out = e->qmr; pa.k.qstat_slots = gq.qstat_slots; pa.k.qstat_width = d;
+                if (launch_qk_norm_rope(pa.k, s)) return 1;
+                at.q = nullptr; at.q_raw = e->qkv; at.q_ld = e->qkvn; at.q_col0 = 0; at.q_stat = e->qmr;
+                at.q_ln_w = w.q_norm_w; at.q_ln_b = w.q_norm_b;
+                at.rope_cs = e->rope; at.rope_cs_t = e->rope_tr; at.rope_t = t_dev; at.rope_watershed = pa.q.watershed;
+                at.rope_cs_len = e->rope_len; at.rope_grid_w = Wp;
+            } else if (!vt_epi && (g_qkv_post_fused == 1 || (g_qkv_post_fused == 2 && M < 2048))) {
                 if (launch_qkv_post(pa, s)) return 1;  // q, k post-processing and the V transpose in one launch
             } else if (g_qk_post_pair && M >= 2048) {
                 if (launch_qk_norm_rope_pair(pa.q, pa.k, s)) return 1;  // q and k in one persistent launch
@@ -603,16 +633,6 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 if (launch_qk_norm_rope(pa.k, s)) return 1;
                 if (!vt_epi && launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
             }
-        }
-        AttnArgs at;
-        at.q = e->q; at.k = e->k; at.vt = e->vt; at.bias = nullptr; at.out = e->attn; at.gate = nullptr; at.accumulate = 0;
-        at.B = B; at.H = H; at.Hkv = Hkv; at.N = N; at.Nk = N; at.Nkpad = Npad; at.hd = hd; at.scale = sm_scale;
-        at.k_prescaled = 1;
-        at.nk_batch = ntok_dev;
-        const bool regional = v.text && e->reg_Y > 0;
-        const bool fuse_text = v.text && !regional && attention_fuses_text(hd);
-        if (fuse_text) {  // zero-init gated text cross-attention (model.py:420-434) inside the same launch
-            at.tk = w.ky; at.tvt = w.vty; at.tbias = e->txt_bias; at.tgate = w.gate; at.Tk = e->prompt_T; at.Tkpad = e->prompt_Tpad;
         }
         if (attention(e, at, s)) return 1;
         if (regional) {
@@ -918,6 +938,13 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         if (dev_alloc(e, &q, P * sizeof(int))) return fail();
         e->moe_src = (int*)q;
     }
+    {
+        void* q;
+        if (dev_alloc(e, &q, M * 32 * 2 * sizeof(float))) return fail();
+        e->qstat = (float*)q;
+        if (dev_alloc(e, &q, M * 2 * sizeof(float))) return fail();
+        e->qmr = (float*)q;
+    }
     {   // split-K workspace (zeroed by dev_alloc: the counters must start at 0; every launch leaves them at 0)
         void* q;
         e->splitk_tiles = 128;
@@ -936,6 +963,8 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         e->txt_bias = (float*)p;
         if (dev_alloc(e, &p, (size_t)2 * e->rope_len * (hd / 2) * 2 * sizeof(float))) return fail();
         e->rope = (float*)p;
+        if (dev_alloc(e, &p, (size_t)2 * e->rope_len * (hd / 2) * 2 * sizeof(float))) return fail();
+        e->rope_tr = (float*)p;
         const size_t state = Bm * cfg->in_channels * Nm * cfg->patch_size * cfg->patch_size * sizeof(float);
         for (int i = 0; i < 2; ++i) { if (dev_alloc(e, &e->ys[i], state)) return fail(); }
         if (dev_alloc(e, &e->ymid, state)) return fail();
@@ -1369,6 +1398,7 @@ extern "C" int lt_set_option(const char* name, int32_t value) {
     if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
     if (strcmp(name, "qkv_fused_gemm") == 0) { g_qkv_fused_gemm = value != 0; return 0; }
     if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
+    if (strcmp(name, "attn_q_fused") == 0) { g_attn_q_fused = value != 0; return 0; }
     if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
     if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }
     if (strcmp(name, "gemm_prefetch") == 0) { lt_set_gemm_prefetch(value); return 0; }

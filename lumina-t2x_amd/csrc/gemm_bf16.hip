@@ -92,6 +92,7 @@ int gemm_qkv_fused_tile(const GemmArgs& a) {
     return (long long)((a.M + 255) / 256) * (a.N / bn) >= num_cus() ? bn : 0;
 }
 bool gemm_qkv_fusable(const GemmArgs& a) { return gemm_qkv_fused_tile(a) != 0; }
+int gemm_qkv_tile_width(const GemmArgs& a) { return gemm_qkv_fused_tile(a); }
 
 namespace {
 using lt_gemm::gemm_bf16_tn;

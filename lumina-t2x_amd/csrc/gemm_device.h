@@ -820,6 +820,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     constexpr int NM = MT * NT, RD = MT + NT, EVERY = NM / IP, RS = NM / RD;
     constexpr int NST = EPI != 1 ? MT * (NT / 2) + (NT % 2 ? MT : 0) : MT * (NT / 4);  // store instructions per wave and tile
     constexpr int NST_V = (MT / 2) * NT;  // ... of a V^T tile (EPI 3)
+    constexpr int NST_Q = EPI == 3 ? MT : 0;  // EPI 3, plain tiles: + the LayerNorm partial-sum stores (one per row tile and wave, always issued)
     static_assert(NM % IP == 0 && RS >= 1 && (RD - 1) * RS + 4 <= NM, "one LDS-DMA per EVERY MFMAs, one fragment read per RS MFMAs, the last one >= 4 MFMAs before the wait");
     static_assert(EPI != 1 || NT % 4 == 0, "SwiGLU pairs 32-column groups");
     static_assert(PA % NW == 0, "A pieces first: slot i < PA / NW is an A piece for every wave");
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         // between slab g+2's DMAs and them (loads and stores retire in issue order, one counter)
         if constexpr (FIRST) {
             if (GROUPED && after_epilogue == 1 && gather) wait_vmcnt<IP + NST + 1>();  // + the map LDS-DMA issued behind the stores
-            else if (after_epilogue == 1) wait_vmcnt<IP + NST>();
+            else if (after_epilogue == 1) wait_vmcnt<IP + NST + NST_Q>();
             else if (EPI == 3 && after_epilogue == 2) wait_vmcnt<IP + NST_V>();
             else wait_vmcnt<IP>();
             after_epilogue = 0;
@@ -1074,15 +1075,28 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)t.c, 0, t.c_bytes, 0x00020000);
         const int lane_e = lane_now(), l15 = lane_e & 15, q4 = lane_e >> 4;  // shadow the kernel-scope values
         const int nbase = t.n0 + wn * (NT * 16);
+        // EPI 3: LayerNorm partial sums of the Q columns (GemmArgs::qstat) - v_dot2_f32_bf16 of each packed output pair with (1, 1) and
+        // with itself: the sums run over the ROUNDED values, which is what the reference normalises (nn.LayerNorm of the bf16 Linear output)
+        const bool stats = EPI == 3 && p.qstat != nullptr && t.n0 < p.qstat_cols;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+        const bf2_t ones2 = __builtin_bit_cast(bf2_t, 0x3F803F80u);
+        float st1[MT], st2[MT];
+        auto stat_add = [&](int mt, unsigned w) __attribute__((always_inline)) {
+            const bf2_t v = __builtin_bit_cast(bf2_t, w);
+            st1[mt] = __builtin_amdgcn_fdot2_f32_bf16(v, ones2, st1[mt], false);
+            st2[mt] = __builtin_amdgcn_fdot2_f32_bf16(v, v, st2[mt], false);
+        };
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int row_off = (wm * (MT * 16) + mt * 16 + l15) * p.ldc * 2;  // bytes from the tile's first C row (< 2^31: launcher)
+            st1[mt] = 0.f; st2[mt] = 0.f;
             if constexpr (EPI != 1) {
 #pragma unroll
                 for (int np = 0; np < NT / 2; ++np) {
                     const f32x4 a = acc[mt][2 * np], b = acc[mt][2 * np + 1];
                     const unsigned a0 = pack2bf_pk(a[0], a[1]), a1 = pack2bf_pk(a[2], a[3]);
                     const unsigned b0 = pack2bf_pk(b[0], b[1]), b1 = pack2bf_pk(b[2], b[3]);
+                    if constexpr (EPI == 3) { if (stats) { stat_add(mt, a0); stat_add(mt, a1); stat_add(mt, b0); stat_add(mt, b1); } }
                     auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                     auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                     // lane rows 0 / 2 hold tile 2 np, columns 0..7 / 8..15; lane rows 1 / 3 tile 2 np + 1
@@ -1094,6 +1108,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
                 if constexpr (NT % 2 == 1) {  // the unpaired last tile: 8 bytes per lane
                     const f32x4 a = acc[mt][NT - 1];
                     const u32x2_t o = {pack2bf_pk(a[0], a[1]), pack2bf_pk(a[2], a[3])};
+                    if constexpr (EPI == 3) { if (stats) { stat_add(mt, o[0]); stat_add(mt, o[1]); } }
                     const int col = nbase + (NT - 1) * 16 + 4 * q4;
                     const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b64(o, rC, off, 0, 0);
@@ -1119,6 +1134,24 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
                     const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b128(o, rC, off, 0, 0);
                 }
+            }
+        }
+        if constexpr (EPI == 3) {
+            // a row's columns of this wave are spread over the four lanes l15 + 16 q4: add them up, lane q4 == 0 stores the pair.
+            // ALWAYS MT store instructions per wave and plain tile (lanes / tiles that have nothing to say store out of range): the
+            // hand-kept vmcnt of the next tile's first body counts them (NST_Q)
+            const long long q_all = (long long)p.M * p.qstat_slots * 8;
+            const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.qstat, 0, stats ? (int)(q_all > 0x7fffffffLL ? 0x7fffffffLL : q_all) : 0, 0x00020000);
+            const int slot = 2 * (t.n0 / BN) + wn;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float a = st1[mt], b = st2[mt];
+                a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+                a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+                const int row = t.m0 + wm * (MT * 16) + mt * 16 + l15;
+                const u32x2_t o = {__float_as_uint(a), __float_as_uint(b)};
+                const int off = (q4 == 0 && row < p.M) ? (row * p.qstat_slots + slot) * 8 : (int)0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b64(o, rS, off, 0, 0);
             }
         }
     };

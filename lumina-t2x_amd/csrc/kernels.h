@@ -38,6 +38,12 @@ struct GemmArgs {
     unsigned* splitk_cnt = nullptr;  // [splitk_tiles], zero between launches
     int splitk_tiles = 0;
     int split_k = 0;                 // set by the launcher: 0 off, 2 two halves
+    // epilogue 3, round 4: LayerNorm statistics of the Q columns on the way out.  Every plain tile whose first column lies below
+    // qstat_cols (= the Q width) adds, per row and per wave column-half, (sum, sum of squares) of its bf16-ROUNDED outputs to
+    // qstat[row][slot] with slot = 2 * (n0 / BN) + wn  (float2; qstat_slots = 2 * qstat_cols / BN per row).  The attention kernel's
+    // prologue reduces the slots to the row's mean / rstd and applies q_norm + RoPE itself (AttnArgs::q_raw): Q is never re-written.
+    float* qstat = nullptr;
+    int qstat_cols = 0, qstat_slots = 0;
     int group_rows = 0;  // experiment knob (lt_set_option "gemm_group"): tile rows per group of the XCD-aware tile order (0 = 4)
     int stagger = 0;  // experiment knob of the 4-wave kernels (lt_set_option "gemm_stagger"), filled by the launcher
 };
@@ -47,7 +53,8 @@ int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t s
 int launch_gemm_prefetch_w(const GemmArgs& a, int epilogue, hipStream_t stream);  // experiment: W panels of a small-M GEMM -> the L2 of the XCDs that will stage them
 void lt_set_gemm_prefetch(int v);
 extern int g_gemm_prefetch;
-bool gemm_qkv_fusable(const GemmArgs& a);  // epilogue 3 can take this problem (else: one plain launch for Q | K + one V^T launch)
+bool gemm_qkv_fusable(const GemmArgs& a);
+int gemm_qkv_tile_width(const GemmArgs& a);  // 288 / 256 (the fused launch's tile width), 0 = not fusable  // epilogue 3 can take this problem (else: one plain launch for Q | K + one V^T launch)
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream);
 
 // ---- norm / residual kernels (norm.hip) --------------------------------------------------------
@@ -101,6 +108,12 @@ struct QkPostArgs {
     // null); padded positions n >= n_tok_b[b] rotate like the sample's LAST token (item_freqs_cis[-1:] expand, :822-827)
     const int* n_tok_b = nullptr;
     const int* grid_w_b = nullptr;
+    // round 4, the K pass of a layer whose queries are post-processed by the attention prologue (AttnArgs::q_raw): while it walks
+    // row r it also reduces the fused QKV GEMM's LayerNorm partials of the SAME row of Q (GemmArgs::qstat: qstat_slots float2 of
+    // (sum, sum of squares)) to the row's (mean, rstd) -> qstat_out[r] (float2), once per row instead of once per head and lane
+    const float* qstat_in = nullptr;
+    float* qstat_out = nullptr;
+    int qstat_slots = 0, qstat_width = 0;
 };
 int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream);
 int launch_qk_norm_rope_pair(const QkPostArgs& q, const QkPostArgs& k, hipStream_t stream);  // both in one persistent launch
@@ -137,6 +150,21 @@ struct AttnArgs {
     const u16* tgate = nullptr;   // [H] bf16
     int Tk = 0, Tkpad = 0;
     unsigned long long* trace = nullptr;  // diagnostics only (lt_op_attention_trace)
+    // round 4 (attn_fwd_kernel_v4<72> only; attention_takes_raw_q() says whether a call qualifies): q == nullptr and the workgroup
+    // makes its 256 query rows itself from the QKV projection's row-major output - q_norm (full-width affine LayerNorm in fp32; the
+    // row's (mean, rstd) come from q_stat, which the K pass of qk_norm_rope reduced from the fused QKV GEMM's partial sums,
+    // GemmArgs::qstat / QkPostArgs::qstat_in) -> 2-D RoPE in fp32 -> ONE bf16 rounding (model.py:361-371), the arithmetic of
+    // qk_norm_rope.  Saves the Q half of that kernel's round trip (2 x [M, d] bf16 per layer).
+    const u16* q_raw = nullptr;     // [B * N, q_ld] bf16, this head's columns at q_col0 + h * hd
+    int q_ld = 0, q_col0 = 0;
+    const float* q_stat = nullptr;  // [B * N] float2 (mean, rstd)
+    const u16* q_ln_w = nullptr;    // [H * hd] bf16
+    const u16* q_ln_b = nullptr;
+    const float* rope_cs = nullptr;   // (cos, sin) table of QkPostArgs::cs (rope_mode 1): [branch][pos][hd / 4], the ROW factors (one position per 32 lanes)
+    const float* rope_cs_t = nullptr; // the same table as [branch][hd / 4][pos]: the COLUMN factors (32 consecutive positions per load)
+    const float* rope_t = nullptr;    // branch = rope_t[0] < rope_watershed ? 0 : 1
+    float rope_watershed = 0.f;
+    int rope_cs_len = 0, rope_grid_w = 0;
     // packed variable-resolution batches (model.py:789-834): valid keys of sample b = nk_batch[b] <= Nk (device array, or null)
     const int* nk_batch = nullptr;
     // regional (compositional) text attention: key/value/bias/output batch b attends the queries of batch q_batch_map[b]
@@ -152,6 +180,7 @@ int launch_attention_v4(const AttnArgs& a, hipStream_t stream);  // hd 72, 4 wav
 int launch_attention_v4_hd48(const AttnArgs& a, hipStream_t stream);  // hd 48, the same structure, softmax-bound (attention_v4_48.hip)
 int launch_attention_v4_hd96(const AttnArgs& a, hipStream_t stream);  // hd 96, the same structure without pad slots (attention_v4_96.hip)
 int launch_attention_v5(const AttnArgs& a, hipStream_t stream);  // the same with the PV product on 16x16x32 MFMAs (attention_v5.hip)
+bool attention_takes_raw_q(const AttnArgs& a);  // launch_attention would run this call on attn_fwd_kernel_v4<72> (the kernel with the q_raw prologue)
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
 void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
 void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
@@ -221,8 +250,8 @@ int launch_ode_combine(int mode, const void* y0, const void* k1, const void* k2,
 // the 32-row interleaved SwiGLU layout), row stride dst_ld (>= cols; padding left untouched)
 int launch_upload_rows(const void* src, int dtype, u16* dst, int rows, int cols, int dst_ld, int r0, int row_map,
                        hipStream_t stream);
-int launch_rope_table_2d(float* out, int len, int hd, float theta, float scale_factor, hipStream_t stream);
+int launch_rope_table_2d(float* out, int len, int hd, float theta, float scale_factor, hipStream_t stream, float* out_t = nullptr);
 // general (cos,sin) factor table, two branches: out[b][pos][fi], fi < hd / step (step 4 = 2-D RoPE axis table, 2 = 1-D)
 int launch_rope_table(float* out, int len, int hd, int step, float theta0, float lin0, float theta1, float lin1,
-                      int lin_on_pos, hipStream_t stream);
+                      int lin_on_pos, hipStream_t stream, float* out_t = nullptr);  // out_t: the same as [b][fi][pos]
 int launch_fill_rows_bf16(u16* dst, const u16* row, long long rows, int d, hipStream_t stream);

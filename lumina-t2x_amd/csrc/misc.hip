@@ -285,7 +285,9 @@ __global__ void ode_combine_kernel(int mode, const void* y0, const void* k1, con
 //   Next-DiT-ImageNet/models/models.py:977-1012) or 2 (1-D: hd/2 frequencies; lumina_t2i/models/model.py:924-960);
 //   angle = pos * (f / lin_b)   (Next-DiT T2I: the frequency is divided, model.py:952-953)  or
 //           (pos / lin_b) * f   (ImageNet / Flag-DiT: the position is divided, models.py:1003-1005)
-__global__ void rope_table_kernel(float* out, int len, int nf, int step, int hd, float theta0, float lin0, float theta1,
+// out_t (optional): the same factors as [branch][fi][pos] - positions contiguous, for readers whose LANES differ in position
+// (the attention prologue's column lookups, AttnArgs::rope_cs_t)
+__global__ void rope_table_kernel(float* out, float* out_t, int len, int nf, int step, int hd, float theta0, float lin0, float theta1,
                                   float lin1, int lin_on_pos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * len * nf) return;
@@ -294,8 +296,14 @@ __global__ void rope_table_kernel(float* out, int len, int nf, int step, int hd,
     const float th = branch == 0 ? theta0 : theta1;
     const float freq = 1.0f / powf(th, (float)(step * fi) / (float)hd);
     const float ang = lin_on_pos ? ((float)pos / lin) * freq : (float)pos * (freq / lin);
-    out[2 * (size_t)i] = cosf(ang);
-    out[2 * (size_t)i + 1] = sinf(ang);
+    const float c = cosf(ang), sn = sinf(ang);
+    out[2 * (size_t)i] = c;
+    out[2 * (size_t)i + 1] = sn;
+    if (out_t) {
+        const size_t j = ((size_t)branch * nf + fi) * len + pos;
+        out_t[2 * j] = c;
+        out_t[2 * j + 1] = sn;
+    }
 }
 
 __global__ void fill_rows_bf16_kernel(u16* dst, const u16* row, long long rows, int d) {
@@ -475,18 +483,18 @@ int launch_ode_combine(int mode, const void* y0, const void* k1, const void* k2,
     return 0;
 }
 
-int launch_rope_table_2d(float* out, int len, int hd, float theta, float scale_factor, hipStream_t stream) {
+int launch_rope_table_2d(float* out, int len, int hd, float theta, float scale_factor, hipStream_t stream, float* out_t) {
     // Next-DiT T2I: branch 0 = linear interpolation (t < watershed), branch 1 = NTK (model.py:944-949)
-    return launch_rope_table(out, len, hd, 4, theta, scale_factor, theta * scale_factor, 1.0f, 0, stream);
+    return launch_rope_table(out, len, hd, 4, theta, scale_factor, theta * scale_factor, 1.0f, 0, stream, out_t);
 }
 
 int launch_rope_table(float* out, int len, int hd, int step, float theta0, float lin0, float theta1, float lin1,
-                      int lin_on_pos, hipStream_t stream) {
+                      int lin_on_pos, hipStream_t stream, float* out_t) {
     LT_REQUIRE(step == 2 || step == 4, "rope_table: step must be 2 (1-D) or 4 (2-D)");
     LT_REQUIRE(hd % step == 0 && len > 0, "rope_table: hd %% %d != 0", step);
     LT_REQUIRE(lin0 > 0.f && lin1 > 0.f && theta0 > 0.f && theta1 > 0.f, "rope_table: factors must be positive");
     const int nf = hd / step;
-    hipLaunchKernelGGL(rope_table_kernel, dim3(nblk(2LL * len * nf, 256)), dim3(256), 0, stream, out, len, nf, step, hd,
+    hipLaunchKernelGGL(rope_table_kernel, dim3(nblk(2LL * len * nf, 256)), dim3(256), 0, stream, out, out_t, len, nf, step, hd,
                        theta0, lin0, theta1, lin1, lin_on_pos);
     LT_CHECK_HIP(hipGetLastError());
     return 0;

@@ -179,6 +179,7 @@ __device__ __forceinline__ void qk_norm_rope_persistent_body(const QkPostArgs& p
         }
     };
     bf8_t cur[MAXCH], nxt[MAXCH];
+    float2 pv_cur = (p.qstat_in && lane < p.qstat_slots) ? ((const float2*)p.qstat_in)[(size_t)(row < rows ? row : rows - 1) * p.qstat_slots + lane] : float2{0.f, 0.f};
     load_row(row, cur);
     if (p.ln_w) {
         for (int c = tid; c < nch; c += 64 * QK_WAVES) {
@@ -192,7 +193,13 @@ __device__ __forceinline__ void qk_norm_rope_persistent_body(const QkPostArgs& p
     const float* cs = p.rope_mode != 0 ? p.cs + (size_t)branch * p.cs_len * nfreq * 2 : nullptr;
     __syncthreads();  // the only workgroup barrier: weights staged (every wave passes it exactly once)
 
+    // (the Q partials of a row travel like the row itself: fetched one iteration ahead, in FRONT of the row's own loads - vmcnt retires
+    //  in order, a load issued behind them could only be waited for together with them)
+    auto load_stat = [&](int r) __attribute__((always_inline)) {
+        return (p.qstat_in && lane < p.qstat_slots) ? ((const float2*)p.qstat_in)[(size_t)(r < rows ? r : rows - 1) * p.qstat_slots + lane] : float2{0.f, 0.f};
+    };
     for (; row < rows; row += stride) {
+        const float2 pv_nxt = load_stat(row + stride);
         load_row(row + stride, nxt);  // clamped inside; the extra load of the last iteration is discarded
         const int b = row / p.N, n = row - b * p.N;
         if (p.rope_mode != 0 && lane < nslot) {  // this row's rotary factors -> the wave's LDS strip
@@ -205,6 +212,15 @@ __device__ __forceinline__ void qk_norm_rope_persistent_body(const QkPostArgs& p
                 fi = pr >> 1; pos = (pr & 1) ? gc : gr;
             } else { fi = pr; pos = n_rot; }
             st[pr] = *(const float2*)(cs + ((size_t)pos * nfreq + fi) * 2);
+        }
+        if (p.qstat_in) {
+            // the same row of Q: its LayerNorm partials (GemmArgs::qstat) -> (mean, rstd) for the attention prologue (AttnArgs::q_stat).
+            // var = E[x^2] - mean^2 in fp32 over bf16 values of O(1): within an fp32 ulp or two of the two-pass form below
+            const float inv_w = 1.0f / (float)p.qstat_width;
+            const float qm = wave_sum(pv_cur.x) * inv_w;
+            const float qr = rsqrtf(fmaxf(wave_sum(pv_cur.y) * inv_w - qm * qm, 0.f) + p.ln_eps);
+            if (lane == 0) ((float2*)p.qstat_out)[row] = float2{qm, qr};
+            pv_cur = pv_nxt;
         }
         float mean = 0.f, rstd = 1.f;
         if (p.ln_w) {
@@ -355,6 +371,8 @@ static int validate_qk_post(const QkPostArgs& a, const char* who) {
     LT_REQUIRE(a.rope_mode == 0 || a.cs != nullptr, "%s: rotary table missing", who);
     LT_REQUIRE(a.rope_mode != 1 || (a.hd % 4 == 0 && a.grid_w > 0), "%s: 2-D rope needs hd %% 4 == 0 and grid_w > 0 (got hd %d, grid_w %d)", who, a.hd, a.grid_w);
     LT_REQUIRE((a.ln_w == nullptr) == (a.ln_b == nullptr), "%s: LayerNorm weight and bias must come together", who);
+    LT_REQUIRE(a.qstat_in == nullptr || (a.qstat_out && a.qstat_slots > 0 && a.qstat_slots <= 64 && a.qstat_width > 0),
+               "%s: q-stat reduction needs an output, 1..64 slots and the Q width", who);
     return 0;
 }
 
@@ -385,6 +403,7 @@ int launch_qk_norm_rope_pair(const QkPostArgs& q, const QkPostArgs& k, hipStream
     if (int rc = validate_qk_post(k, "qk_norm_rope_pair (k)")) return rc;
     const int wq = q.heads * q.hd, wk = k.heads * k.hd;
     LT_REQUIRE(q.hd == k.hd && wk <= wq, "qk_norm_rope_pair: widths %d / %d unsupported", wq, wk);
+    LT_REQUIRE(!q.qstat_in && !k.qstat_in, "qk_norm_rope_pair: the q-stat reduction rides on the single-stream launch only");
     const int cus = num_cus();
     // QK_WG_PER_CU workgroups per CU in total, split by the bytes of the two streams (GQA: the k stream is a quarter of the q stream)
     const int rows = q.B * q.N;
@@ -424,6 +443,7 @@ int launch_qkv_post(const QkvPostArgs& a0, hipStream_t stream) {
     const int wq = a.q.heads * a.q.hd, wk = a.k.heads * a.k.hd;
     LT_REQUIRE(a.q.hd % 8 == 0 && wq <= 4096 && wk <= wq, "qkv_post: widths %d / %d unsupported", wq, wk);
     LT_REQUIRE(a.v_Npad % 64 == 0 && a.v_Npad >= a.v_N && a.v_hd <= 128, "qkv_post: bad V shape");
+    LT_REQUIRE(!a.q.qstat_in && !a.k.qstat_in, "qkv_post: the q-stat reduction rides on the single-stream launch only");
     a.nq_blocks = (a.q.B * a.q.N + QK_ROWS - 1) / QK_ROWS;
     a.nk_blocks = (a.k.B * a.k.N + QK_ROWS - 1) / QK_ROWS;
     const int nv = (a.v_Npad / 64) * a.v_kv_heads * a.v_B;

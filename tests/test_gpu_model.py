@@ -564,15 +564,17 @@ def test_attention_variants_3_and_4_agree_in_the_model():
     zb, capb = z.to("cuda", torch.bfloat16), cap.to("cuda", torch.bfloat16)
     outs = {}
     try:
+        set_option("attn_q_fused", 0)  # (both kernels on head-major queries from qk_norm_rope: the comparison is about the kernels)
         for v in (4, 3):
             set_option("attention_variant", v)
             outs[v] = model.forward_with_cfg(zb, t.cuda(), capb, mask.cuda(), 4.0, base_seqlen=4096, proportional_attn=True)
     finally:
         set_option("attention_variant", 4)
+        set_option("attn_q_fused", 1)
     assert torch.equal(outs[4], outs[3]), rel_l2(outs[4], outs[3])
 
 
-@pytest.mark.parametrize("opt", ["qk_post_pair", "qkv_vt_epilogue", "qkv_fused_gemm", "gemm_w4q", "norm_specialize"])
+@pytest.mark.parametrize("opt", ["qk_post_pair", "qkv_vt_epilogue", "qkv_fused_gemm", "gemm_w4q", "norm_specialize", "attn_q_fused"])
 def test_engine_path_switches_do_not_change_results(opt):
     """the launch-structure options of the engine (q / k post-processing in one launch, V projection with the V^T epilogue,
     persistent 16x16x32 GEMM, specialised row kernels) on a model wide and long enough to take those paths (d 1152, 4096 tokens,
@@ -588,13 +590,31 @@ def test_engine_path_switches_do_not_change_results(opt):
     zb, capb = z.to("cuda", torch.bfloat16), cap.to("cuda", torch.bfloat16)
     outs = {}
     on, default = 1, 1
+    # the prologue form of q_norm + RoPE exists only behind the fused QKV launch: a switch that takes that launch away would also move the
+    # queries to qk_norm_rope (other summation order of the LayerNorm statistics) - those switches are compared with the prologue off
+    pin_q = opt in ("qkv_vt_epilogue", "qkv_fused_gemm", "gemm_w4q")
     try:
+        if pin_q:
+            set_option("attn_q_fused", 0)
         for v in (on, 0):
             set_option(opt, v)
             outs[1 if v else 0] = model.forward_with_cfg(zb, t.cuda(), capb, mask.cuda(), 4.0, base_seqlen=4096, proportional_attn=True)
     finally:
         set_option(opt, default)
+        set_option("attn_q_fused", 1)
     if opt in ("gemm_w4q", "qkv_fused_gemm"):  # (fused QKV: the V columns move from the 32x32x16 classic kernel to the 16x16x32 one)
         assert rel_l2(outs[1], outs[0]) < 1e-2, rel_l2(outs[1], outs[0])
+    elif opt == "attn_q_fused":
+        # round 4: q_norm + RoPE of the queries in the attention prologue instead of qk_norm_rope - the same arithmetic per element, but
+        # the row's mean / variance come from (sum, sum of squares) partials in another summation order: a few queries land one bf16
+        # ulp away, which the softmax and 2 layers carry to the output at the 1e-3 level
+        assert rel_l2(outs[1], outs[0]) < 6e-3, rel_l2(outs[1], outs[0])
+        # and the other queries' path must really have been taken: with the option off the result equals the kernel-variant test's
+        set_option("qk_post_pair", 0)
+        try:
+            again = model.forward_with_cfg(zb, t.cuda(), capb, mask.cuda(), 4.0, base_seqlen=4096, proportional_attn=True)
+        finally:
+            set_option("qk_post_pair", 1)
+        assert torch.equal(again, outs[1])  # with the prologue path on, how q / k post-processing is launched cannot matter for q
     else:
         assert torch.equal(outs[1], outs[0]), rel_l2(outs[1], outs[0])
