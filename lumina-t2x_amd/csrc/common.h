@@ -80,6 +80,18 @@ __device__ __forceinline__ bf8_t pack8(const float* f) {
 __device__ __forceinline__ unsigned pk_bf(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
 __device__ __forceinline__ f32x2 unpk_bf(unsigned u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
 __device__ __forceinline__ f32x2 bfr2(f32x2 v) { return unpk_bf(pk_bf(v)); }  // round both to bf16, keep as fp32
+// two SwiGLU outputs: per element bfr(silu_f(bfr(x))) * bfr(y) - the reference's rounding points (model.py:497-502 under bf16: w1 x,
+// w3 x, silu, the product is rounded by the caller) - with the multiplies / the add as packed fp32 instructions and one
+// v_cvt_pk_bf16_f32 per rounded pair (the scalar form left 2 of its 5 fp32 ops per element unpacked and a quarter of the converts
+// single: 13.5 -> 12 VALU instructions per output of the SwiGLU epilogue).  Same operations, same order: bit-identical.
+__device__ __forceinline__ f32x2 swiglu2(f32x2 x, f32x2 y) {
+    const f32x2 xr = bfr2(x), yr = bfr2(y);
+    const float nl2e = __uint_as_float(0xbfb8aa3bu);  // -log2(e), the constant __expf(-x) multiplies by
+    const f32x2 t = xr * f32x2{nl2e, nl2e};
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return bfr2(xr * r) * yr;
+}
 
 // host-side error plumbing shared by the launchers
 void lt_set_error(const char* fmt, ...);

@@ -109,16 +109,15 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[MT][NT], const GemmArgs
                 const int obase = (n0 + wn * NT * 32 + np * 64) / 2;
 #pragma unroll
                 for (int qp = 0; qp < 2; ++qp) {
-                    float v[8];
+                    unsigned w[4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 4; ++j) {
                         // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
-                        const float a = bfr(acc[mt][2 * np][8 * qp + j]);
-                        const float b = bfr(acc[mt][2 * np + 1][8 * qp + j]);
-                        v[j] = bfr(silu_f(a)) * b;
+                        const f32x2 a = {acc[mt][2 * np][8 * qp + 2 * j], acc[mt][2 * np][8 * qp + 2 * j + 1]};
+                        const f32x2 b = {acc[mt][2 * np + 1][8 * qp + 2 * j], acc[mt][2 * np + 1][8 * qp + 2 * j + 1]};
+                        w[j] = pk_bf(swiglu2(a, b));
                     }
-                    unsigned ax = pack2bf_pk(v[0], v[1]), ay = pack2bf_pk(v[2], v[3]);
-                    unsigned bx = pack2bf_pk(v[4], v[5]), by = pack2bf_pk(v[6], v[7]);
+                    unsigned ax = w[0], ay = w[1], bx = w[2], by = w[3];
                     auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                     auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
                     const int col = obase + 16 * qp + 8 * hi;
@@ -1120,12 +1119,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const f32x4 x = acc[mt][4 * j + u], y = acc[mt][4 * j + 2 + u];
-                        float vv[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)  // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
-                            vv[r] = bfr(silu_f(bfr(x[r]))) * bfr(y[r]);
-                        pk[u][0] = pack2bf_pk(vv[0], vv[1]);
-                        pk[u][1] = pack2bf_pk(vv[2], vv[3]);
+                        // reference rounding points (model.py:497-502 under bf16): w1 x, w3 x, silu, product
+                        pk[u][0] = pk_bf(swiglu2(f32x2{x[0], x[1]}, f32x2{y[0], y[1]}));
+                        pk[u][1] = pk_bf(swiglu2(f32x2{x[2], x[3]}, f32x2{y[2], y[3]}));
                     }
                     auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
                     auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
