@@ -105,6 +105,11 @@ const char* lt_version(void);
  *   "qkv_post_fused"    2 (default): one launch for q / k post-processing + V transpose below 2048 rows (launch-bound regime), three
  *                       launches above | 1 always one launch | 0 always separate launches
  *   "qk_post_pair"      1 (default): q and k post-processing share one persistent launch (>= 2048 rows) | 0: two launches
+ *   "attn_q_fused"      1 (default): behind the fused QKV launch at head_dim 72 (2-D RoPE, qk_norm, whole 64-key tiles) q_norm + RoPE
+ *                       of the queries happen in the attention kernel's prologue - the QKV GEMM's epilogue leaves per-row LayerNorm
+ *                       partial sums, the K pass reduces them to (mean, rstd) - and q is never written head-major; the row
+ *                       statistics come from (sum, sum of squares) instead of the two-pass form, so a few queries differ by one
+ *                       bf16 ulp from the "0" path | 0: q goes through qk_norm_rope like k
  *   "qkv_vt_epilogue"   1 (default): the V projection is its own GEMM whose epilogue writes the attention kernels' transposed,
  *                       key-permuted V image directly (no V transpose pass; needs tokens per sample % 64 == 0, large M) | 0: off
  *   "norm_specialize"   1 (default): gated_residual_norm runs instantiations with its three mode switches fixed at compile
