@@ -176,6 +176,11 @@ struct lt_engine {
     void *g_x = nullptr, *g_out = nullptr;
     float* g_t = nullptr;
     hipStream_t cap_stream = nullptr;
+    // lt_set_option("gemm_prefetch", 2): weight panels of the next 512-row-class GEMM are read into their XCDs' L2 on a side stream,
+    // beside the row / attention kernel that precedes the GEMM (fork before that kernel, join in front of the GEMM)
+    hipStream_t pf_stream = nullptr;
+    hipEvent_t pf_fork = nullptr, pf_join = nullptr;
+    bool pf_pending = false;
     long long graph_replays = 0;
     // profiling
     int prof_mask = 0;  // bit k: class k launches are bracketed by HIP events
@@ -223,12 +228,49 @@ struct ProfScope {
     }
 };
 
+// "gemm_prefetch" 2: called in front of the kernel that PRECEDES a dense GEMM in the stream, with that GEMM's arguments: its weight
+// panels are read on the side stream while the preceding kernel runs; gemm() joins.  Works the same eagerly and inside a stream
+// capture (the side stream joins the capture through the fork event; every fork is joined by the GEMM it was made for).
+int prefetch_fork(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int ldc, int M, int N, int K, int epi, hipStream_t s) {
+    if (g_gemm_prefetch != 2 || M > 1024 || e->pf_pending) return 0;
+    if (!e->pf_stream) {
+        LT_CHECK_HIP(hipStreamCreateWithFlags(&e->pf_stream, hipStreamNonBlocking));
+        LT_CHECK_HIP(hipEventCreateWithFlags(&e->pf_fork, hipEventDisableTiming));
+        LT_CHECK_HIP(hipEventCreateWithFlags(&e->pf_join, hipEventDisableTiming));
+    }
+    GemmArgs g;
+    g.A = A; g.W = W; g.C = C; g.bias = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
+    g.bias_dtype = -1;
+    g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;
+    LT_CHECK_HIP(hipEventRecord(e->pf_fork, s));
+    LT_CHECK_HIP(hipStreamWaitEvent(e->pf_stream, e->pf_fork, 0));
+    if (launch_gemm_prefetch_w(g, epi, e->pf_stream)) return 1;
+    LT_CHECK_HIP(hipEventRecord(e->pf_join, e->pf_stream));
+    e->pf_pending = true;
+    return 0;
+}
+
+// "gemm_prefetch" 3: the same panels read by rider workgroups inside the row kernel that precedes the GEMM (no second stream, no
+// graph edges - which is what option 2 died of: +37 us per layer of cross-stream dependencies)
+void prefetch_rider(lt_engine* e, PrefetchRider* r, const u16* A, int lda, const u16* W, int ldw, u16* C, int ldc, int M, int N, int K, int epi) {
+    if (g_gemm_prefetch != 3 || M > 1024) return;
+    GemmArgs g;
+    g.A = A; g.W = W; g.C = C; g.bias = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
+    g.bias_dtype = -1;
+    g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;
+    if (!gemm_prefetch_rider(g, epi, r)) *r = PrefetchRider();
+}
+
 int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int ldc, int M, int N, int K,
          const u16* bias, int epi, hipStream_t s) {
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.bias_dtype = bias ? 1 : -1;
     g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;  // (the launcher decides)
+    if (e->pf_pending) {  // the side stream's panel reads for THIS GEMM (prefetch_fork): join
+        e->pf_pending = false;
+        LT_CHECK_HIP(hipStreamWaitEvent(s, e->pf_join, 0));
+    }
     if (g_gemm_prefetch == 1 && M <= 1024 && launch_gemm_prefetch_w(g, epi, s)) return 1;
     ProfScope ps(e, 0, 2.0 * M * (double)N * K, s, true);
     return launch_gemm_bf16(g, epi, 0, s, ps.ev0(), ps.ev1());
@@ -550,6 +592,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
     }
     auto chunk = [&](int layer, int idx) -> const u16* { return idx < 0 ? nullptr : e->mod + (size_t)layer * cd + (size_t)idx * d; };
     // first pre-norm: modulate(attention_norm(x), [shift,] scale) (model.py:599 / models.py:785 / lumina_t2i model.py:600)
+    if (prefetch_fork(e, e->h, d, e->lw[0].wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, 0, s)) return 1;  // (small problems, option gemm_prefetch 2)
     {
         ProfScope ps(e, 2, 0, s);
         NormModArgs n;
@@ -598,6 +641,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             ProfScope ps(e, 0, 2.0 * M * (double)dkv * d, s, true);
             if (launch_gemm_bf16(g, 2, 0, s, ps.ev0(), ps.ev1())) return 1;
         } else if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, nullptr, 0, s)) return 1;
+        if (!regional && (fuse_text || !v.text) && prefetch_fork(e, e->attn, d, w.wo, d, e->o, d, M, d, d, 0, s)) return 1;  // beside q / k post-processing + attention
         {
             ProfScope ps(e, 2, 0, s);
             QkPostArgs qa;
@@ -652,6 +696,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             if (attention(e, at, s)) return 1;
         }
         if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s)) return 1;
+        if (e->E == 0 && prefetch_fork(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, 1, s)) return 1;
         {   // x += gate' * post(attn) ; h = pre_ffn(x) * (1 + scale) [+ shift]
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
@@ -660,6 +705,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             g.next_w = v.pre_w ? w.ffn_norm1 : nullptr; g.next_scale = chunk(l, v.i_scale[1]); g.next_shift = chunk(l, v.i_shift[1]);
             g.next_mode = 1; g.h = e->h;
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
+            if (e->E == 0) prefetch_rider(e, &g.pf, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, 1);
             if (launch_gated_residual_norm(g, s)) return 1;
         }
         const u16 *last_post_w, *last_gate;
@@ -686,6 +732,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             last_post_w = w.norm_space;
             last_gate = chunk(l, 5);
         }
+        if (l + 1 < L && prefetch_fork(e, e->h, d, e->lw[l + 1].wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, 0, s)) return 1;
         {   // x += gate' * post(ffn) ; h = next layer's pre-norm + modulate, or the final layer's LayerNorm + modulate
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
@@ -702,6 +749,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 g.next_shift = v.final_chunks == 2 ? fin : nullptr;
                 g.next_scale = v.final_chunks == 2 ? fin + d : fin;
             }
+            if (l + 1 < L) prefetch_rider(e, &g.pf, e->h, d, e->lw[l + 1].wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, 0);
             if (launch_gated_residual_norm(g, s)) return 1;
         }
     }
@@ -991,6 +1039,9 @@ extern "C" void lt_destroy(lt_engine* e) {
     if (!e) return;
     for (auto& ge : e->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    if (e->pf_stream) (void)hipStreamDestroy(e->pf_stream);
+    if (e->pf_fork) (void)hipEventDestroy(e->pf_fork);
+    if (e->pf_join) (void)hipEventDestroy(e->pf_join);
     for (auto& b : e->allocs) (void)hipFree(b.p);
     if (e->t_dev) (void)hipFree(e->t_dev);
     if (e->t_pinned) (void)hipHostFree(e->t_pinned);

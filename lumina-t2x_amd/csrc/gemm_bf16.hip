@@ -339,45 +339,36 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
 // (scripts/ubench/fill_rate.hip).  This kernel walks the SAME workgroup -> tile map as the GEMM that follows (same grid, same
 // tile_coords, i.e. same XCD per tile) and reads each tile's W panel - every workgroup of a tile column takes its share of the rows -
 // so that the panel is resident in the L2 of the XCD whose workgroups will stage it.  Loads only, results discarded.
-__global__ __launch_bounds__(256) void gemm_prefetch_w_kernel(const u16* __restrict__ W, int N, int K, int ldw, int BN, int TM, int TN, int split) {
-    const int ntile = TM * TN;
-    const int ks = split == 2 ? (int)blockIdx.x / ntile : 0;
-    const int bid = (int)blockIdx.x - ks * ntile;
-    int tm, tn;
-    tile_coords(bid, ntile, TM, TN, tm, tn);
-    const int first_m = (tm / 4) * 4, gsz = min(4, TM - first_m), part = tm - first_m;  // the workgroups of this column in this tile-row group
-    const int n0 = tn * BN, n1 = min(N, n0 + BN);
-    const int k0 = split == 2 ? ks * (K / 2) : 0, kw = split == 2 ? K / 2 : K;  // elements
-    const int cpr = kw / 8;                                                     // 16-byte chunks per row
-    const int rows = n1 - n0;
-    const long long total = (long long)rows * cpr;
-    unsigned acc = 0;
-    for (long long i = (long long)part * 256 + threadIdx.x; i < total; i += (long long)gsz * 256) {
-        const int r = (int)(i / cpr), c = (int)(i - (long long)r * cpr);
-        const uint4 v = *(const uint4*)(W + (size_t)(n0 + r) * ldw + k0 + c * 8);
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
-    }
-    if (acc == 0x9e3779b9u) asm volatile("s_nop 0");  // keep the loads
-}
+__global__ __launch_bounds__(256) void gemm_prefetch_w_kernel(PrefetchRider r) { prefetch_w_block(r, (int)blockIdx.x); }
 
-int g_gemm_prefetch = 0;  // experiment knob (lt_set_option "gemm_prefetch"): 1 = launch the prefetch right in front of every small-M GEMM (same stream)
+int g_gemm_prefetch = 0;  // experiment knob (lt_set_option "gemm_prefetch"): 1 = a prefetch launch right in front of every small-M GEMM (same
+                          // stream: the upper bound), 2 = on a side stream beside the preceding kernel, 3 = as riders in the preceding row kernel
 void lt_set_gemm_prefetch(int v) { g_gemm_prefetch = v; }
 
-int launch_gemm_prefetch_w(const GemmArgs& a0, int epilogue, hipStream_t stream) {
+bool gemm_prefetch_rider(const GemmArgs& a0, int epilogue, PrefetchRider* r) {
     GemmArgs a = a0;
     const GemmKernel k = choose(a, epilogue, 0);
-    int BM = 0, BN = 128;
+    int BM = 0;
     if (k == GK_S64) BM = 64;
     else if (k == GK_S128 || k == GK_S128_SWIGLU) BM = 128;
-    else return 0;  // not a small-M launch: nothing to do
-    if (a.tile_expert || a.a_row_map) return 0;
+    else return false;  // not a small-M launch: nothing to do
+    if (a.tile_expert || a.a_row_map) return false;
     int split = 0;
     if (k == GK_S64 && g_gemm_splitk && a.splitk_part && a.bias_dtype < 0 && a.K >= 1024 && a.K % 512 == 0) {
         const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
         if (2 * tiles <= num_cus() && tiles <= a.splitk_tiles) split = 2;
     }
-    const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL(gemm_prefetch_w_kernel, dim3(TM * TN * (split == 2 ? 2 : 1)), dim3(256), 0, stream, a.W, a.N, a.K, a.ldw, BN, TM, TN, split);
+    r->W = a.W; r->N = a.N; r->K = a.K; r->ldw = a.ldw; r->BN = 128;
+    r->TM = (a.M + BM - 1) / BM; r->TN = (a.N + 127) / 128; r->split = split;
+    r->blocks = r->TM * r->TN * (split == 2 ? 2 : 1);
+    r->first = 0;
+    return true;
+}
+
+int launch_gemm_prefetch_w(const GemmArgs& a, int epilogue, hipStream_t stream) {
+    PrefetchRider r;
+    if (!gemm_prefetch_rider(a, epilogue, &r)) return 0;
+    hipLaunchKernelGGL(gemm_prefetch_w_kernel, dim3(r.blocks), dim3(256), 0, stream, r);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

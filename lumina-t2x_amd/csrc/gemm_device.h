@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "kernels.h"
+#include "tile_order.h"
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <type_traits>
@@ -10,20 +11,6 @@
 namespace {
 
 constexpr int BK = 64;
-
-__device__ __forceinline__ void tile_coords(int bid, int nwg, int TM, int TN, int& tm, int& tn, int G = 4) {
-    const int NX = 8;
-    const int xcd = bid % NX, idx = bid / NX;
-    const int q = nwg / NX, r = nwg % NX;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int per_group = G * TN;
-    const int g = L / per_group;
-    const int first_m = g * G;
-    const int gsz = min(G, TM - first_m);
-    const int in = L - g * per_group;
-    tm = first_m + in % gsz;
-    tn = in / gsz;
-}
 
 __device__ __forceinline__ float load_bias(const void* bias, int dt, int n) {
     return dt == 0 ? ((const float*)bias)[n] : bf2f(((const u16*)bias)[n]);

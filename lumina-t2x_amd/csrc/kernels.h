@@ -50,6 +50,15 @@ struct GemmArgs {
 // ev0 / ev1: optional start / stop events carried by the dispatch packet itself (profiling without extra queue packets)
 int launch_gemm_bf16(const GemmArgs& a, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0 = nullptr,
                      hipEvent_t ev1 = nullptr);
+// weight-panel prefetch of a small-M GEMM as a RIDER in the grid of the kernel that precedes it (option "gemm_prefetch" 3): blocks
+// [first, first + blocks) of the host kernel run prefetch_w_block (tile_order.h) instead of the host's work.  first % 8 == 0, so that
+// rider i runs on the XCD GEMM workgroup i will run on.  Filled by gemm_prefetch_rider (false: the GEMM is not a small-M launch).
+struct PrefetchRider {
+    const u16* W = nullptr;
+    int N = 0, K = 0, ldw = 0, BN = 0, TM = 0, TN = 0, split = 0;
+    int first = 0x7fffffff, blocks = 0;
+};
+bool gemm_prefetch_rider(const GemmArgs& a, int epilogue, PrefetchRider* r);
 int launch_gemm_prefetch_w(const GemmArgs& a, int epilogue, hipStream_t stream);  // experiment: W panels of a small-M GEMM -> the L2 of the XCDs that will stage them
 void lt_set_gemm_prefetch(int v);
 extern int g_gemm_prefetch;
@@ -88,6 +97,7 @@ struct GatedResArgs {
     const u16* moe_ys = nullptr;
     const int* moe_pos = nullptr;
     const u16* moe_wts = nullptr;
+    PrefetchRider pf;  // weight panels of the GEMM that follows, read by extra workgroups of this launch (512-row-class problems)
 };
 int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream);
 void lt_set_norm_specialize(int v);  // 1: mode-specialised gated_residual_norm instantiations (experiment, default 0)

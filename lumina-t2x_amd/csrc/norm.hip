@@ -10,6 +10,7 @@
 // lane per chunk; wave shuffles for the reductions; no LDS, no barrier).
 #include "common.h"
 #include "kernels.h"
+#include "tile_order.h"
 
 namespace {
 
@@ -102,6 +103,10 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(NormModArgs p) {
 template <int MAXCH, int PM = -1, int GM = -1, int NM = -1, bool MOE = false>
 __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p) {
     const int post_mode = PM >= 0 ? PM : p.post_mode, gate_mode = GM >= 0 ? GM : p.gate_mode, next_mode = NM >= 0 ? NM : p.next_mode;
+    if ((int)blockIdx.x >= p.pf.first) {  // rider workgroups (GatedResArgs::pf): the next GEMM's weight panels -> their XCDs' L2
+        prefetch_w_block(p.pf, (int)blockIdx.x - p.pf.first);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
@@ -230,14 +235,22 @@ int launch_rmsnorm_mod(const NormModArgs& a, hipStream_t stream) {
     return 0;
 }
 
-int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream) {
+int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
+    GatedResArgs a = a_in;
     LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH_LIMIT, "gated_residual_norm: d=%d must be a multiple of 8 and <= 4096", a.d);
     LT_REQUIRE(a.rows_per_batch > 0 && a.rows > 0, "gated_residual_norm: empty input");
     LT_REQUIRE(a.gate_mode == 2 || a.gate != nullptr, "gated_residual_norm: gate pointer missing");
     LT_REQUIRE(a.y != nullptr || a.moe_pos != nullptr, "gated_residual_norm: branch output missing");
     LT_REQUIRE(a.post_mode == 0 || a.post_w != nullptr, "gated_residual_norm: post-norm weight missing");
     LT_REQUIRE(a.next_mode == 0 || a.h != nullptr, "gated_residual_norm: h output missing");
-    const dim3 grid((a.rows + 3) / 4);
+    int nblk = (a.rows + 3) / 4;
+    if (a.pf.blocks > 0) {  // riders behind the row blocks, from a multiple of 8 on (block index mod 8 = XCD)
+        a.pf.first = (nblk + 7) / 8 * 8;
+        nblk = a.pf.first + a.pf.blocks;
+    } else {
+        a.pf.first = 0x7fffffff;
+    }
+    const dim3 grid(nblk);
     if (a.moe_pos) {  // y = top-2 combine of the experts' outputs (MoE families: d = 1536 ... 4096)
         LT_REQUIRE(a.moe_ys && a.moe_wts, "gated_residual_norm: incomplete MoE combine arguments");
         switch (((a.d >> 3) + 63) / 64) {
