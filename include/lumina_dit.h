@@ -114,6 +114,9 @@ const char* lt_version(void);
  *                       key-permuted V image directly (no V transpose pass; needs tokens per sample % 64 == 0, large M) | 0: off
  *   "norm_specialize"   1 (default): gated_residual_norm runs instantiations with its three mode switches fixed at compile
  *                       time (the engine's combinations at d = 1536 / 2304 / 3072; bit-identical, 34.4 -> 31.6 us) | 0: generic
+ *   "gemm_prefetch"     3 (default): at <= 1024 rows the weight panels of the QKV / O / W1|W3 projections are read into the L2 of the
+ *                       XCDs that will stage them by extra workgroups of the row kernel in front of the GEMM | 0 off | 1 / 2: the
+ *                       measurement forms (serial launch = upper bound; side stream = loses), DESIGN.md 5.8
  *   "graph"             1 (default): one model evaluation is captured into a HIP graph per (shape, arguments) and replayed | 0: eager
  * (the round-1 knobs gemm_pipeline / gemm_pp_tail / gemm_persist selected study kernels that now live in
  *  csrc/experimental/ - build with `make EXPERIMENTAL=1` and use the explicit lt_op_gemm_bf16 variants) */

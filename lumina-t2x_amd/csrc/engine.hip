@@ -668,6 +668,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 at.rope_cs = e->rope; at.rope_cs_t = e->rope_tr; at.rope_t = t_dev; at.rope_watershed = pa.q.watershed;
                 at.rope_cs_len = e->rope_len; at.rope_grid_w = Wp;
             } else if (!vt_epi && (g_qkv_post_fused == 1 || (g_qkv_post_fused == 2 && M < 2048))) {
+                if (!regional && (fuse_text || !v.text)) prefetch_rider(e, &pa.pf, e->attn, d, w.wo, d, e->o, d, M, d, d, 0);
                 if (launch_qkv_post(pa, s)) return 1;  // q, k post-processing and the V transpose in one launch
             } else if (g_qk_post_pair && M >= 2048) {
                 if (launch_qk_norm_rope_pair(pa.q, pa.k, s)) return 1;  // q and k in one persistent launch

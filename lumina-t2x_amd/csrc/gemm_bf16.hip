@@ -341,8 +341,10 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
 // so that the panel is resident in the L2 of the XCD whose workgroups will stage it.  Loads only, results discarded.
 __global__ __launch_bounds__(256) void gemm_prefetch_w_kernel(PrefetchRider r) { prefetch_w_block(r, (int)blockIdx.x); }
 
-int g_gemm_prefetch = 0;  // experiment knob (lt_set_option "gemm_prefetch"): 1 = a prefetch launch right in front of every small-M GEMM (same
-                          // stream: the upper bound), 2 = on a side stream beside the preceding kernel, 3 = as riders in the preceding row kernel
+// lt_set_option "gemm_prefetch": 3 (default) = the W panels of the 512-row-class GEMMs are read by rider workgroups of the row kernel
+// that precedes the GEMM (cfg 1 -1.6 %, cfg 5 -1..3 % on a fast-class box, -6.5 % on a slow one); 0 = off; 1 = a prefetch launch right in
+// front of every small-M GEMM (same stream: the upper bound experiment); 2 = on a side stream beside the preceding kernel (loses 33 %)
+int g_gemm_prefetch = 3;
 void lt_set_gemm_prefetch(int v) { g_gemm_prefetch = v; }
 
 bool gemm_prefetch_rider(const GemmArgs& a0, int epilogue, PrefetchRider* r) {

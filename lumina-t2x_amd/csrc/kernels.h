@@ -136,6 +136,7 @@ struct QkvPostArgs {
     u16* v_dst;
     int v_ld_src, v_col0, v_B, v_N, v_Npad, v_kv_heads, v_hd;
     int nq_blocks = 0, nk_blocks = 0;  // filled by the launcher
+    PrefetchRider pf;  // weight panels of a later small-M GEMM (the O projection), read by extra workgroups of this launch
 };
 int launch_qkv_post(const QkvPostArgs& a, hipStream_t stream);
 

@@ -13,6 +13,7 @@
 //                 values, so the PV MFMA needs no cross-lane exchange (see attention.hip).
 #include "common.h"
 #include "kernels.h"
+#include "tile_order.h"
 #include <algorithm>
 
 namespace {
@@ -346,6 +347,10 @@ template <int MAXCH>
 __global__ __launch_bounds__(64 * QK_WAVES) void qkv_post_kernel(QkvPostArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int bid = blockIdx.x;
+    if (bid >= p.pf.first) {  // rider workgroups (QkvPostArgs::pf)
+        prefetch_w_block(p.pf, bid - p.pf.first);
+        return;
+    }
     if (bid < p.nq_blocks) {
         qk_norm_rope_block<MAXCH>(p.q, bid, smem_raw);
         return;
@@ -357,6 +362,7 @@ __global__ __launch_bounds__(64 * QK_WAVES) void qkv_post_kernel(QkvPostArgs p) 
     }
     bid -= p.nk_blocks;
     const int nx = p.v_Npad / 64;
+    if (bid >= nx * p.v_kv_heads * p.v_B) return;  // (padding blocks in front of rider workgroups)
     v_transpose_tile(p.v_src, p.v_ld_src, p.v_col0, p.v_dst, p.v_N, p.v_Npad, p.v_kv_heads, p.v_hd, bid % nx,
                      (bid / nx) % p.v_kv_heads, bid / (nx * p.v_kv_heads), smem_raw);
 }
@@ -447,7 +453,14 @@ int launch_qkv_post(const QkvPostArgs& a0, hipStream_t stream) {
     a.nq_blocks = (a.q.B * a.q.N + QK_ROWS - 1) / QK_ROWS;
     a.nk_blocks = (a.k.B * a.k.N + QK_ROWS - 1) / QK_ROWS;
     const int nv = (a.v_Npad / 64) * a.v_kv_heads * a.v_B;
-    const dim3 grid(a.nq_blocks + a.nk_blocks + nv);
+    int nblk = a.nq_blocks + a.nk_blocks + nv;
+    if (a.pf.blocks > 0) {  // riders behind the working blocks, from a multiple of 8 on (block index mod 8 = XCD); the blocks in between exit
+        a.pf.first = (nblk + 7) / 8 * 8;
+        nblk = a.pf.first + a.pf.blocks;
+    } else {
+        a.pf.first = 0x7fffffff;
+    }
+    const dim3 grid(nblk);
     const size_t smem = std::max<size_t>((size_t)a.v_hd * 72 * 2, (size_t)wq * 4 + (size_t)QK_ROWS * (a.q.hd >> 1) * 8);
     switch (((wq >> 3) + 63) / 64) {
         case 1: hipLaunchKernelGGL(qkv_post_kernel<1>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;

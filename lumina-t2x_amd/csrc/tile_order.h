@@ -32,13 +32,26 @@ __device__ __forceinline__ void prefetch_w_block(const PrefetchRider& r, int blk
     const int first_m = (tm / 4) * 4, gsz = min(4, r.TM - first_m), part = tm - first_m;
     const int n0 = tn * r.BN, n1 = min(r.N, n0 + r.BN);
     const int k0 = r.split == 2 ? ks * (r.K / 2) : 0, kw = r.split == 2 ? r.K / 2 : r.K;  // elements
-    const int cpr = kw / 8;                                                               // 16-byte chunks per row
-    const long long total = (long long)(n1 - n0) * cpr;
+    // ONE 4-byte load per 128-byte line and lane: a wave instruction touches 64 lines (8 KB of panel), so a 128 x 1536 panel is three
+    // instructions for each of the 16 waves that share it, all in flight at once - one memory round trip.  (First form: a linear
+    // 16-byte-chunk index per thread, one dependent load and one integer division at a time - 12.5 us for a 14-25 MB panel set, longer
+    // than the 7 us row kernel it rides in; second form, 16-byte loads with two rows in flight per wave: 9 us, four round trips.)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nrow = n1 - n0;
+    const int lpr = (kw + 63) / 64;  // lines per row
+    const int total = nrow * lpr, step = gsz * 4 * 64;
+    const char* base = (const char*)(r.W + (size_t)n0 * r.ldw + k0);
     unsigned acc = 0;
-    for (long long i = (long long)part * 256 + threadIdx.x; i < total; i += (long long)gsz * 256) {
-        const int row = (int)(i / cpr), c = (int)(i - (long long)row * cpr);
-        const uint4 v = *(const uint4*)(r.W + (size_t)(n0 + row) * r.ldw + k0 + c * 8);
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    for (int i0 = (part * 4 + wave) * 64 + lane; i0 - lane < total; i0 += 8 * step) {
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * step;
+            const int row = i / lpr, c = i - row * lpr;
+            v[u] = i < total ? *(const unsigned*)(base + (size_t)row * r.ldw * 2 + (size_t)c * 128) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u];
     }
     if (acc == 0x9e3779b9u) asm volatile("s_nop 0");  // keep the loads
 }
