@@ -97,6 +97,16 @@ def test_imagenet_600m_full_width_vs_oracle():
         assert torch.equal(model.forward_with_cfg(zb, t.cuda(), y.cuda(), 4.0), got)
     finally:
         set_option("qkv_post_fused", 2)
+    # round 4: the weight-panel prefetch of the 512-row GEMMs only READS (rider workgroups inside the row kernels = the default 3, a
+    # side stream forked / joined inside the captured graph = 2, a serial launch = 1, off = 0): every form must return the same bits,
+    # eagerly (first call of an option generation) and from the replayed graph (third call)
+    try:
+        for form in (0, 1, 2, 3):
+            set_option("gemm_prefetch", form)
+            for _ in range(3):
+                assert torch.equal(model.forward_with_cfg(zb, t.cuda(), y.cuda(), 4.0), got), form
+    finally:
+        set_option("gemm_prefetch", 3)
 
 
 def test_flag_engine_matches_reference_golden(golden_dir):
