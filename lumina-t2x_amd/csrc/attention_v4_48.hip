@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v4h48(AttnArgs p) {
     // fragment read is `lane address + immediate`, whatever the ring slot (the tile loop is unrolled by the ring depth)
     constexpr int K_BASE = 0, V_BASE = 4 * KTILE, CONST_OFF = V_BASE + 4 * VTILE;
     constexpr int NKP = 6, NVP = 6, IP = (NKP + NVP) / 4;  // 1-KiB staging pieces per (K, V^T) tile pair; per wave and tile
+    constexpr int STG_OFF = CONST_OFF + 3 * KTILE + 32 * HD * 2 + 512 + 16 + 16;  // four wave-private strips of 64 rows x HD for the output rows
     constexpr int ZERO_CHUNK = 512;  // behind the 32 pad chunks of every (slot, sub-tile) block: 16 bytes of zeros (the pad step's lo half)
     constexpr int W_PV = 4 * DT, W_END = 4 * DT + 2 * KS + 6;  // softmax window: gaps [0, W_PV) under the other block's PV, [W_PV, W_PV + 2 KS) under its QK^T, then six gaps into the block's own PV
     constexpr float THR = 8.0f;
@@ -432,18 +433,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v4h48(AttnArgs p) {
         }
     }
 
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-        if (q_ok[blk]) {
-            u16* orow = p.out + ((size_t)b * p.N + qrow[blk]) * ((size_t)p.H * HD) + (size_t)h * HD;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int d0 = 32 * dt + 8 * q4 + 4 * hi;
-                    if (d0 < HD) *(u32x2*)(orow + d0) = res[blk][dt][q4];
-                }
-        }
+    // ---- output: through a wave-private LDS strip to row-contiguous 16-byte stores (store_rows_via_lds, common.h) ---------------------
+    {
+        const int row0 = qb * 256 + wave * 64;
+        store_rows_via_lds<HD, DT>(smem + STG_OFF + wave * (64 * HD * 2), res, lane,
+                                   p.out + ((size_t)b * p.N + row0) * ((size_t)p.H * HD) + (size_t)h * HD, (size_t)p.H * HD, p.N - row0);
     }
     if (p.trace && tid == 0) {  // per workgroup: s_memrealtime (100 MHz) at entry | loop start | loop end | exit, shader clocks of the loop
         unsigned long long* o = p.trace + (size_t)blockIdx.x * 8;
@@ -457,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v4h48(AttnArgs p) {
 
 int launch_attention_v4_hd48(const AttnArgs& a, hipStream_t stream) {
     // V^T ring | K ring | pad-chunk blocks at the K ring's (slot, sub-tile) strides: the last block ends 3 KTILE + 32 hd 2 + 512 + 16 in
-    constexpr int SMEM = 4 * (48 * 128 + 256) + 4 * (64 * 48 * 2) + 3 * (64 * 48 * 2) + 32 * 48 * 2 + 512 + 16 + 16;
+    constexpr int SMEM = 4 * (48 * 128 + 256) + 4 * (64 * 48 * 2) + 3 * (64 * 48 * 2) + 32 * 48 * 2 + 512 + 16 + 16 + 4 * (64 * 48 * 2);  // (+ the waves' output strips)
     LT_REQUIRE(a.hd == 48 && !a.bias && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && !a.tk,
                "attention v4 (hd 48): whole 64-key tiles, no per-sample key counts, no fused text keys (the inherited text phase is untested)");
     if (!func_attr_done(device_slot(), (const void*)lt_attn48::attn_fwd_kernel_v4h48))  // per (device, kernel)

@@ -93,6 +93,36 @@ __device__ __forceinline__ f32x2 swiglu2(f32x2 x, f32x2 y) {
     return bfr2(xr * r) * yr;
 }
 
+// Output rows of the one-wave-per-SIMD attention kernels: a lane holds, per (dt, q4), 8 bytes of ITS query row (d = 32 dt + 8 q4 +
+// 4 hi ..+3).  Stored from there, every instruction touched 64 different lines (rows of the [B, N, H * hd] output lie H * hd * 2 bytes
+// apart): 18 instructions x 64 partial-line writes per wave at head_dim 72, ~2 us of the texture addresser per workgroup.  Instead the
+// wave parks its 64 rows x HD in a private LDS strip (`tb`, 64 * HD * 2 bytes, touched by this wave only: LDS operations of one wave
+// stay in order) and stores them as HD / 8 instructions of 64 consecutive 16-byte chunks - ~7 row segments = ~16 lines each.
+// obase = the output address of the wave's first row (this head's columns); rows_valid = rows of the 64 that exist.
+template <int HD, int DT>
+__device__ __forceinline__ void store_rows_via_lds(char* tb, const u32x2 (&res)[2][DT][4], int lane, u16* obase, size_t row_stride, int rows_valid) {
+    const int hi = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int d0 = 32 * dt + 8 * q4 + 4 * hi;
+                if (d0 < HD) *(u32x2*)(tb + (blk * 32 + l31) * (HD * 2) + d0 * 2) = res[blk][dt][q4];
+            }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int CPR = HD / 8;  // 16-byte chunks per row
+#pragma unroll
+    for (int i = 0; i < CPR; ++i) {
+        const int c = lane + 64 * i;
+        const int r = c / CPR, ch = c - r * CPR;
+        if (r < rows_valid) *(u32x4*)(obase + (size_t)r * row_stride + ch * 8) = *(const u32x4*)(tb + r * (HD * 2) + ch * 16);
+    }
+}
+
 // host-side error plumbing shared by the launchers
 void lt_set_error(const char* fmt, ...);
 // compute units of the CURRENT device (cached per device id; defined in gemm_bf16.hip)
