@@ -336,6 +336,25 @@ int lt_op_linear_small_m(const void* a_dev, const void* w_dev, const void* b_dev
  * branch 0 = linear-interpolation (t < watershed), branch 1 = NTK. */
 int lt_op_rope_table_2d(void* out_dev, int32_t len, int32_t hd, float theta, float scale_factor,
                         void* stream);
+/* the same table in both layouts the engine keeps (round 4): out float2 [2][len][hd/4] and out_t float2 [2][hd/4][len] (the column
+ * factors of the attention prologue: 32 consecutive positions per load) */
+int lt_op_rope_table_2d_pair(void* out_dev, void* out_t_dev, int32_t len, int32_t hd, float theta, float scale_factor, void* stream);
+/* Round 4, the attn_q_fused path of the engine as two stand-alone steps (model.py:355-371: wq | wk | wv, q_norm, k_norm, RoPE).
+ * lt_op_qkv_qstat = lt_op_gemm_qkv (same layouts and conditions; q_cols a multiple of the launch's tile width) whose epilogue also leaves
+ * per-row partial (sum, sum of squares) of the bf16-rounded Q columns in qstat_ws (float2 [M][32], scratch), followed by the K pass of
+ * lt_op_qk_norm_rope (LayerNorm over the K columns [q_cols, split), 2-D RoPE from cs_table = ONE branch's [len][hd/4] table, out_scale folded in,
+ * head-major k_out [B, (split - q_cols) / hd, tokens, hd]) which reduces the partials to q_mean_rstd float2 [M] = (mean, rsqrt(var + 1e-5))
+ * of each row's Q columns.
+ * lt_op_attention_qraw = lt_op_attention (k prescaled, no bias, head_dim 72, N % 64 == 0) with q == NULL: the kernel builds its query
+ * fragments from qkv [B * N, ld] (this head's columns at q_col0 + h * hd) as RoPE(LayerNorm(x; q_mean_rstd, q_ln_w, q_ln_b)) with ONE
+ * bf16 rounding - cs_table / cs_table_t from lt_op_rope_table_2d_pair (branch 1), token n at grid position (n / grid_w, n % grid_w). */
+int lt_op_qkv_qstat(const void* A_dev, const void* W_dev, void* C_dev, void* vt_dev, int32_t M, int32_t N, int32_t K, int32_t split,
+                    int32_t tokens, int32_t hd, int32_t q_cols, const void* k_ln_w_dev, const void* k_ln_b_dev, const void* cs_table_dev,
+                    int32_t grid_w, float k_out_scale, void* k_out_dev, void* qstat_ws_dev, void* q_mean_rstd_dev, void* stream);
+int lt_op_attention_qraw(const void* qkv_dev, int32_t ld, int32_t q_col0, const void* q_mean_rstd_dev, const void* q_ln_w_dev,
+                         const void* q_ln_b_dev, const void* cs_table_dev, const void* cs_table_t_dev, int32_t table_len, int32_t grid_w,
+                         const void* k_dev, const void* vt_dev, void* out_dev, int32_t B, int32_t H, int32_t Hkv, int32_t N, int32_t Nkpad,
+                         int32_t hd, void* stream);
 
 #ifdef __cplusplus
 }

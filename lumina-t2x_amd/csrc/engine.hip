@@ -1496,6 +1496,29 @@ extern "C" int lt_op_gemm_qkv(const void* A, const void* W, void* C, void* vt, i
     return launch_gemm_bf16(g, 3, 0, (hipStream_t)stream);
 }
 
+// The fused QKV launch with the Q columns' LayerNorm partials (GemmArgs::qstat) followed by the K pass of qk_norm_rope that reduces
+// them (QkPostArgs::qstat_in): exactly the two launches the engine makes per layer on the attn_q_fused path.
+extern "C" int lt_op_qkv_qstat(const void* A, const void* W, void* C, void* vt, int32_t M, int32_t N, int32_t K, int32_t split, int32_t tokens,
+                               int32_t hd, int32_t q_cols, const void* k_ln_w, const void* k_ln_b, const void* cs_table, int32_t grid_w,
+                               float k_out_scale, void* k_out, void* qstat_ws, void* q_mean_rstd, void* stream) {
+    LT_REQUIRE(A && W && C && vt && k_ln_w && k_ln_b && cs_table && k_out && qstat_ws && q_mean_rstd, "lt_op_qkv_qstat: null pointer");
+    LT_REQUIRE(hd > 0 && q_cols > 0 && q_cols % hd == 0 && split > q_cols && (split - q_cols) % hd == 0 && M % tokens == 0,
+               "lt_op_qkv_qstat: bad column split (q %d | k | v at %d, head_dim %d)", q_cols, split, hd);
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.bias_dtype = -1; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = N; g.VT = (u16*)vt; g.vt_split = split; g.vt_tokens = tokens; g.vt_hd = hd; g.vt_npad = tokens;
+    const int bn = gemm_qkv_tile_width(g);
+    LT_REQUIRE(bn > 0 && q_cols % bn == 0 && 2 * q_cols / bn <= 32, "lt_op_qkv_qstat: the problem does not take the fused QKV launch with whole Q tiles");
+    g.qstat = (float*)qstat_ws; g.qstat_cols = q_cols; g.qstat_slots = 2 * q_cols / bn;  // qstat_ws: [M][qstat_slots] float2, <= [M][32]
+    if (int rc = launch_gemm_bf16(g, 3, 0, (hipStream_t)stream)) return rc;
+    QkPostArgs q;
+    q.src = (const u16*)C; q.ld_src = N; q.col0 = q_cols; q.ln_w = (const u16*)k_ln_w; q.ln_b = (const u16*)k_ln_b; q.ln_eps = 1e-5f;
+    q.dst = (u16*)k_out; q.B = M / tokens; q.N = tokens; q.heads = (split - q_cols) / hd; q.hd = hd; q.rope_mode = 1;
+    q.cs = (const float*)cs_table; q.t = nullptr; q.grid_w = grid_w; q.cs_len = 0; q.watershed = 0.f; q.out_scale = k_out_scale;  // (one branch's table, as lt_op_qk_norm_rope)
+    q.qstat_in = (const float*)qstat_ws; q.qstat_out = (float*)q_mean_rstd; q.qstat_slots = g.qstat_slots; q.qstat_width = q_cols;
+    return launch_qk_norm_rope(q, (hipStream_t)stream);
+}
+
 extern "C" int lt_op_gemm_qkv_fusable(int32_t M, int32_t N, int32_t K, int32_t split, int32_t tokens, int32_t hd) {
     GemmArgs g;
     g.A = nullptr; g.W = nullptr; g.C = nullptr; g.bias = nullptr; g.bias_dtype = -1; g.M = M; g.N = N; g.K = K;
@@ -1633,6 +1656,22 @@ extern "C" int lt_op_attention(const void* q, const void* k, const void* vt, con
     return launch_attention(a, (hipStream_t)stream);
 }
 
+// self-attention whose queries come straight from the QKV projection (AttnArgs::q_raw): q_norm + 2-D RoPE in the kernel's prologue
+extern "C" int lt_op_attention_qraw(const void* qkv, int32_t ld, int32_t q_col0, const void* q_mean_rstd, const void* q_ln_w, const void* q_ln_b,
+                                    const void* cs_table, const void* cs_table_t, int32_t table_len, int32_t grid_w, const void* k,
+                                    const void* vt, void* out, int32_t B, int32_t H, int32_t Hkv, int32_t N, int32_t Nkpad, int32_t hd,
+                                    void* stream) {
+    LT_REQUIRE(qkv && q_mean_rstd && q_ln_w && q_ln_b && cs_table && cs_table_t && k && vt && out, "lt_op_attention_qraw: null pointer");
+    AttnArgs a;
+    a.q = nullptr; a.k = (const u16*)k; a.vt = (const u16*)vt; a.bias = nullptr; a.out = (u16*)out; a.gate = nullptr; a.accumulate = 0;
+    a.B = B; a.H = H; a.Hkv = Hkv; a.N = N; a.Nk = N; a.Nkpad = Nkpad; a.hd = hd; a.scale = 1.f; a.k_prescaled = 1;
+    a.q_raw = (const u16*)qkv; a.q_ld = ld; a.q_col0 = q_col0; a.q_stat = (const float*)q_mean_rstd;
+    a.q_ln_w = (const u16*)q_ln_w; a.q_ln_b = (const u16*)q_ln_b;
+    a.rope_cs = (const float*)cs_table; a.rope_cs_t = (const float*)cs_table_t; a.rope_t = nullptr; a.rope_watershed = 0.f;  // branch 1
+    a.rope_cs_len = table_len; a.rope_grid_w = grid_w;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
 extern "C" int lt_op_attention_fused(const void* q, const void* k, const void* vt, const void* tk, const void* tvt,
                                      const float* tbias, const void* tgate, void* out, int32_t B, int32_t H, int32_t Hkv, int32_t N,
                                      int32_t Nk, int32_t Nkpad, int32_t Tk, int32_t Tkpad, int32_t hd, void* stream) {
@@ -1660,6 +1699,11 @@ extern "C" int lt_op_linear_small_m(const void* a, const void* w, const void* b,
                                     int32_t act_in, void* stream) {
     LT_REQUIRE(a && w && y, "lt_op_linear_small_m: null pointer");
     return launch_linear_small_m((const u16*)a, (const u16*)w, (const u16*)b, (u16*)y, M, N, K, act_in, (hipStream_t)stream);
+}
+
+extern "C" int lt_op_rope_table_2d_pair(void* out, void* out_t, int32_t len, int32_t hd, float theta, float scale_factor, void* stream) {
+    LT_REQUIRE(out && out_t, "lt_op_rope_table_2d_pair: null pointer");
+    return launch_rope_table_2d((float*)out, len, hd, theta, scale_factor, (hipStream_t)stream, (float*)out_t);
 }
 
 extern "C" int lt_op_rope_table_2d(void* out, int32_t len, int32_t hd, float theta, float scale_factor, void* stream) {

@@ -943,3 +943,75 @@ def test_linear_small_m(M, N, K, act):
         af = r16(F.silu(af))
     ref = af @ w.float().cpu().t() + b.float().cpu()
     assert rel_l2(y, ref) < 4e-3
+
+
+@pytest.mark.parametrize("B,tokens,H,Hkv,grid_w", [(2, 4096, 32, 32, 64), (2, 4096, 32, 8, 128)])
+def test_qkv_qstat_then_attention_qraw_equal_the_separate_passes(B, tokens, H, Hkv, grid_w):
+    """round 4, the attn_q_fused path of the engine at the op level (model.py:355-371 + :392-405), head_dim 72:
+    (1) lt_op_qkv_qstat: the fused QKV launch leaves C / V^T bit-identical to lt_op_gemm_qkv, its K pass equals lt_op_qk_norm_rope on the K
+        columns bit for bit, and the per-row (mean, rstd) reduced from the epilogue's partial sums equal torch's statistics of the
+        bf16-rounded Q columns to fp32 accuracy (the variance comes from E[x^2] - mean^2: a few 1e-6 relative);
+    (2) lt_op_attention_qraw with exactly those statistics equals lt_op_attention on the queries lt_op_qk_norm_rope makes, up to the
+        bf16 ulps that the two forms of the row variance move (two-pass there, sums here): <= 2e-3 of the output norm; fed the two-pass
+        statistics instead, the prologue is qk_norm_rope's arithmetic and the outputs agree to <= 1e-3."""
+    hd = 72
+    d, dkv = H * hd, Hkv * hd
+    M, Nall, K = B * tokens, d + 2 * dkv, d
+    if not lib().lt_op_gemm_qkv_fusable(M, Nall, K, d + dkv, tokens, hd):
+        pytest.skip("this box does not take the fused QKV launch for the shape")
+    g = torch.Generator().manual_seed(H * 7 + Hkv)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(Nall, K, generator=g) / math.sqrt(K))
+    W[:d] += bf(0.02 * torch.ones(1, K))  # a row mean that is not negligible beside the spread: exercises E[x^2] - mean^2
+    qw, qb = bf(1 + 0.1 * torch.randn(d, generator=g)), bf(0.1 * torch.randn(d, generator=g))
+    kw, kb = bf(1 + 0.1 * torch.randn(dkv, generator=g)), bf(0.1 * torch.randn(dkv, generator=g))
+    table = torch.empty(2, 384, hd // 4, 2, device="cuda", dtype=torch.float32)
+    table_t = torch.empty(2, hd // 4, 384, 2, device="cuda", dtype=torch.float32)
+    ok(lib().lt_op_rope_table_2d_pair(P(table), P(table_t), 384, hd, 10000.0, 1.0, stream()))
+    ref_table = torch.empty_like(table)
+    ok(lib().lt_op_rope_table_2d(P(ref_table), 384, hd, 10000.0, 1.0, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(table, ref_table) and torch.equal(table_t, table.permute(0, 2, 1, 3).contiguous())
+    scale = math.sqrt(math.log(tokens, 4096) / hd) if tokens > 4096 else 1 / math.sqrt(hd)
+    kscale = scale * 1.4426950408889634
+    # the separate passes
+    C0 = torch.empty(M, Nall, device="cuda", dtype=torch.bfloat16)
+    vt0 = torch.empty(B, Hkv, hd, tokens, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_gemm_qkv(P(A), P(W), P(C0), P(vt0), M, Nall, K, d + dkv, tokens, hd, stream()))
+    q0 = torch.empty(B, H, tokens, hd, device="cuda", dtype=torch.bfloat16)
+    k0 = torch.empty(B, Hkv, tokens, hd, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_qk_norm_rope(P(C0), Nall, 0, P(qw), P(qb), 1e-5, P(q0), B, tokens, H, hd, 1, P(table[1]), grid_w, 1.0, stream()))
+    ok(lib().lt_op_qk_norm_rope(P(C0), Nall, d, P(kw), P(kb), 1e-5, P(k0), B, tokens, Hkv, hd, 1, P(table[1]), grid_w, kscale, stream()))
+    out0 = torch.full((B, tokens, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_attention(P(q0), P(k0), P(vt0), None, P(out0), None, 0, B, H, Hkv, tokens, tokens, tokens, hd, scale, 1, stream()))
+    # the fused path
+    C1, vt1, k1 = torch.empty_like(C0), torch.empty_like(vt0), torch.empty_like(k0)
+    ws = torch.empty(M, 32, 2, device="cuda", dtype=torch.float32)
+    qmr = torch.empty(M, 2, device="cuda", dtype=torch.float32)
+    ok(lib().lt_op_qkv_qstat(P(A), P(W), P(C1), P(vt1), M, Nall, K, d + dkv, tokens, hd, d, P(kw), P(kb), P(table[1]), grid_w, kscale,
+                             P(k1), P(ws), P(qmr), stream()), "qkv_qstat")
+    out1 = torch.full_like(out0, float("nan"))
+    ok(lib().lt_op_attention_qraw(P(C1), Nall, 0, P(qmr), P(qw), P(qb), P(table), P(table_t), 384, grid_w, P(k1), P(vt1), P(out1),
+                                  B, H, Hkv, tokens, tokens, hd, stream()), "attention_qraw")
+    torch.cuda.synchronize()
+    assert torch.equal(C1[:, :d + dkv], C0[:, :d + dkv]) and torch.equal(vt1, vt0)  # (the V columns of C are not written: V leaves as vt)
+    if not torch.equal(k1, k0):
+        bad = (k1.view(torch.int16) != k0.view(torch.int16))
+        idx = bad.nonzero()
+        raise AssertionError(f"k differs: rel {rel_l2(k1, k0):.3e}, {int(bad.sum())} of {bad.numel()} elements; first {idx[:6].tolist()} last {idx[-3:].tolist()}; "
+                             f"rows hit {sorted(set(idx[:, 2].tolist()))[:20]}")
+    x = C0[:, :d].float()
+    mean, var = x.mean(-1), x.var(-1, unbiased=False)
+    assert (mean.abs() > 0.2 * var.sqrt()).float().mean() > 0.5  # (the draw really has rows with a sizeable mean)
+    assert ((qmr[:, 0] - mean).abs() / var.sqrt()).max() < 1e-5
+    assert (qmr[:, 1] * torch.sqrt(var + 1e-5) - 1).abs().max() < 2e-5
+    assert not torch.isnan(out1.float()).any()
+    assert rel_l2(out1, out0) < 2e-3, rel_l2(out1, out0)
+    # and with the statistics of the separate pass's form (two-pass variance, computed here) the prologue is the same arithmetic:
+    # whatever still differs is fp32 contraction inside two differently compiled kernels, far below a bf16 ulp of q on average
+    qmr2 = torch.stack([mean, torch.rsqrt(var + 1e-5)], -1).contiguous()
+    out2 = torch.full_like(out0, float("nan"))
+    ok(lib().lt_op_attention_qraw(P(C1), Nall, 0, P(qmr2), P(qw), P(qb), P(table), P(table_t), 384, grid_w, P(k1), P(vt1), P(out2),
+                                  B, H, Hkv, tokens, tokens, hd, stream()), "attention_qraw (two-pass statistics)")
+    torch.cuda.synchronize()
+    assert rel_l2(out2, out0) < 1e-3, rel_l2(out2, out0)
