@@ -99,6 +99,11 @@ const char* lt_version(void);
  *                       kernel with PV on 16x16x32 MFMAs (EXPERIMENTAL=1 builds)
  *   "gemm_variant"      0 auto tile shape (default) | 1 256x256 | 2 256x288
  *   "gemm_w4q"          1 (default): large dense GEMMs run on the persistent 4-wave 16x16x32 kernel | 0: classic / ping-pong tiles
+ *   "gemm_w4q_grouped"  1 (default): the grouped (mixture-of-experts) GEMMs run on the persistent kernel's grouped mode from 1.5 tiles of
+ *                       256 x 256 per CU on | 2: from 2 tiles per CU on (A/B) | 0: always the 8-wave ping-pong / classic tiles
+ *   "gemm_splitk"       1 (default): the 64 x 128 small-M tile splits K over two workgroups per tile when both halves fit one round of the
+ *                       CUs (the 512-row O / W2 projections) | 2: whenever the workspace allows | 0: off
+ *   "gemm_group"        0 (default = 4) .. 64: tile rows per group of the XCD-aware tile order (experiment knob, no measured effect)
  *   "gemm_stagger"      0 (default) .. 256: the persistent 4-wave GEMM kernels spread the start of the workgroups of an XCD over
  *                       eight phases, n * ~256 cycles apart (experiment knob: de-synchronises the tile-end store bursts; measured
  *                       -0.5 % .. 0 depending on the box)

@@ -139,3 +139,18 @@ def test_missing_library_fails_loudly(tmp_path):
     )
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert "LOUD" in out.stdout and "no CPU/PyTorch fallback" in out.stdout, out.stdout + out.stderr
+
+
+def test_every_option_lt_set_option_accepts_is_documented_in_the_header():
+    """the knobs of lt_set_option live in engine.hip's strcmp chain; include/lumina_dit.h is where an integrator reads what they do
+    (gemm_group / gemm_persist are round-1 experiment knobs the header mentions as retired)"""
+    src = open(os.path.join(REPO, "lumina-t2x_amd", "csrc", "engine.hip")).read()
+    body = src[src.index('extern "C" int lt_set_option('):]
+    body = body[:body.index("\n}\n")]
+    names = set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', body))
+    assert {"attn_q_fused", "gemm_prefetch", "graph", "attention_variant"} <= names, names
+    header = open(os.path.join(REPO, "include", "lumina_dit.h")).read()
+    retired = {"gemm_pipeline", "gemm_pp_tail", "gemm_persist"}  # accepted with value 0 only; the header names them as removed
+    missing = sorted(n for n in names - retired if f'"{n}"' not in header)
+    assert not missing, missing
+    assert all(n in header for n in retired)
