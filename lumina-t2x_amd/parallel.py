@@ -121,6 +121,34 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
+def comm_report(per_rank_value: float, device: torch.device) -> dict:
+    """What a multi-rank bench line records so that the JSON itself proves the collective layer saw every rank:
+    the backend in use, the RCCL version torch was built against, `ranks_seen` = an all-reduce SUM of ones (== world only if every
+    rank took part in a real collective), every rank's own value of `per_rank_value` (all-gather, rank order) and device name."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return {"backend": None, "world": 1, "ranks_seen": 1, "per_rank": [float(per_rank_value)],
+                "devices": [torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu"]}
+    world, host = dist.get_world_size(), _host_hop()
+    cdev = torch.device("cpu") if host else device
+    ones = torch.ones(1, dtype=torch.int64, device=cdev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([per_rank_value], dtype=torch.float64, device=cdev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    name = torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu"
+    idx = device.index if device.type == "cuda" and device.index is not None else -1
+    names = [None] * world
+    dist.all_gather_object(names, f"{name} (cuda:{idx})" if device.type == "cuda" else name)
+    rccl = None
+    try:
+        if dist.get_backend() == "nccl":
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rccl = None
+    return {"backend": dist.get_backend(), "rccl_version": rccl, "world": world, "ranks_seen": int(ones.item()),
+            "per_rank": [float(v.item()) for v in every], "devices": names}
+
+
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -17,18 +17,31 @@ def available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "lumina_next_t2i", "models"))
 
 
-def load_reference(package: str = "lumina_next_t2i"):
+def copy_root():
+    """``oracle/_ref`` when it holds a verified byte-identical copy of the files the timing leg imports (oracle/build_ref.py), else None"""
+    from oracle import build_ref
+    return build_ref.REF_DST if build_ref.verify() else None
+
+
+def timing_root():
+    """where bench.cpu_baseline() imports the UNMODIFIED reference from: the checkout in the authoring container, the travelling copy
+    on the GPU box, None when neither exists (the baseline then falls back to the restatement and says ``kind: "port"``)"""
+    return REFERENCE_ROOT if available() else copy_root()
+
+
+def load_reference(package: str = "lumina_next_t2i", root: str = None):
     """Returns (models module, transport module) of the given reference sub-project."""
-    if not available():
-        raise RuntimeError(f"reference checkout not found under {REFERENCE_ROOT}")
-    for p in (_REPO, _STUBS, os.path.join(REFERENCE_ROOT, package)):
+    root = root or REFERENCE_ROOT
+    if not os.path.isdir(os.path.join(root, package, "models")):
+        raise RuntimeError(f"reference sub-project {package} not found under {root}")
+    for p in (_REPO, _STUBS, os.path.join(root, package)):
         if p not in sys.path:
             sys.path.insert(0, p)
     # model.py:952 hard-codes .cuda(); on the CPU harness make it a no-op
     if not torch.cuda.is_available():
         torch.Tensor.cuda = lambda self, *a, **k: self
     for name in ("models", "transport"):
-        if name in sys.modules and not getattr(sys.modules[name], "__file__", "").startswith(REFERENCE_ROOT):
+        if name in sys.modules and not getattr(sys.modules[name], "__file__", "").startswith(root):
             del sys.modules[name]
     import warnings
     with warnings.catch_warnings():

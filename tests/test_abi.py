@@ -123,7 +123,30 @@ def test_product_path_never_imports_the_oracle():
                 text = open(os.path.join(root, f)).read()
                 if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "import_module(\"oracle" in text:
                     bad.append(os.path.join(root, f))
+                # ... nor the travelling copy of the reference modules (oracle/_ref, the CPU-baseline leg of bench.py) or the checkout
+                if "_ref" in text and re.search(r"oracle[/.\\]_ref", text):
+                    bad.append(os.path.join(root, f))
+                if "/root/reference" in text and f.endswith(".py"):
+                    bad.append(os.path.join(root, f))
     assert not bad, bad
+
+
+def test_reference_copy_for_the_cpu_baseline_is_byte_identical_or_absent():
+    """oracle/_ref (git-ignored, filled by oracle/build_ref.py from __graft_entry__.build()): when present every file must still carry the
+    sha256 recorded when it was copied from the reference; in the authoring container the sources are compared directly"""
+    import hashlib
+    import json
+    from oracle import build_ref
+    man_path = os.path.join(build_ref.REF_DST, "MANIFEST.json")
+    if not os.path.exists(man_path):
+        pytest.skip("oracle/_ref not built (no reference checkout was present when build() ran)")
+    assert build_ref.verify()
+    man = json.load(open(man_path))["sha256"]
+    if os.path.isdir(os.path.join(build_ref.REF_SRC, "lumina_next_t2i")):
+        for rel, h in man.items():
+            assert hashlib.sha256(open(os.path.join(build_ref.REF_SRC, rel), "rb").read()).hexdigest() == h, rel
+    tracked = subprocess.run(["git", "-C", REPO, "ls-files", "oracle/_ref"], capture_output=True, text=True).stdout.strip()
+    assert tracked == "", "reference sources must never enter git history: " + tracked
 
 
 def test_missing_library_fails_loudly(tmp_path):

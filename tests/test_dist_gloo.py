@@ -39,6 +39,9 @@ def _worker(rank, world, port, out_dir):
     full = parallel.gather_latents(local, n_img, dst=0)
     slow = parallel.max_over_ranks(1.0 + rank, torch.device("cpu"))
     assert slow == float(world)
+    rep = parallel.comm_report(10.0 + rank, torch.device("cpu"))  # what bench.py records for N > 1
+    assert rep["backend"] == "gloo" and rep["world"] == world and rep["ranks_seen"] == world
+    assert rep["per_rank"] == [10.0 + r for r in range(world)] and rep["devices"] == ["cpu"] * world
     parallel.barrier()
     if rank == 0:
         expect = torch.stack([want[i, 0].float().mean().expand(4, 2, 2) + i for i in range(n_img)])
