@@ -89,43 +89,23 @@ typedef struct lt_step_args {
 } lt_step_args;
 
 const char* lt_last_error(void);
-/* library / build identification: "lumina_dit gfx950 r3", with "+experimental" appended by EXPERIMENTAL=1 builds */
+/* library / build identification: "lumina_dit gfx950 r5" */
 const char* lt_version(void);
 
-/* process-wide kernel selection knobs (A/B measurements, tests; defaults are the measured-best settings):
- *   "qkv_fused_gemm" 1 (default): Q | K | V projection in one launch where the shapes are whole 256 x 288 tiles
- *   "attention_variant" 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (hd 72 / 96) | 4 (default) one wave per SIMD x 64 query rows,
- *                       asm-owned AGPRs (hd 72 and, since round 3, hd 96, with whole 64-key tiles; variant 3 otherwise) | 5 the hd-72
- *                       kernel with PV on 16x16x32 MFMAs (EXPERIMENTAL=1 builds)
- *   "gemm_variant"      0 auto tile shape (default) | 1 256x256 | 2 256x288
- *   "gemm_w4q"          1 (default): large dense GEMMs run on the persistent 4-wave 16x16x32 kernel | 0: classic / ping-pong tiles
- *   "gemm_w4q_grouped"  1 (default): the grouped (mixture-of-experts) GEMMs run on the persistent kernel's grouped mode from 1.5 tiles of
- *                       256 x 256 per CU on | 2: from 2 tiles per CU on (A/B) | 0: always the 8-wave ping-pong / classic tiles
- *   "gemm_splitk"       1 (default): the 64 x 128 small-M tile splits K over two workgroups per tile when both halves fit one round of the
- *                       CUs (the 512-row O / W2 projections) | 2: whenever the workspace allows | 0: off
- *   "gemm_group"        0 (default = 4) .. 64: tile rows per group of the XCD-aware tile order (experiment knob, no measured effect)
- *   "gemm_stagger"      0 (default) .. 256: the persistent 4-wave GEMM kernels spread the start of the workgroups of an XCD over
- *                       eight phases, n * ~256 cycles apart (experiment knob: de-synchronises the tile-end store bursts; measured
- *                       -0.5 % .. 0 depending on the box)
- *   "qkv_post_fused"    2 (default): one launch for q / k post-processing + V transpose below 2048 rows (launch-bound regime), three
- *                       launches above | 1 always one launch | 0 always separate launches
- *   "qk_post_pair"      1 (default): q and k post-processing share one persistent launch (>= 2048 rows) | 0: two launches
- *   "attn_q_fused"      1 (default): behind the fused QKV launch at head_dim 72 (2-D RoPE, qk_norm, whole 64-key tiles) q_norm + RoPE
- *                       of the queries happen in the attention kernel's prologue - the QKV GEMM's epilogue leaves per-row LayerNorm
- *                       partial sums, the K pass reduces them to (mean, rstd) - and q is never written head-major; the row
- *                       statistics come from (sum, sum of squares) instead of the two-pass form, so a few queries differ by one
- *                       bf16 ulp from the "0" path | 0: q goes through qk_norm_rope like k
- *   "qkv_vt_epilogue"   1 (default): the V projection is its own GEMM whose epilogue writes the attention kernels' transposed,
- *                       key-permuted V image directly (no V transpose pass; needs tokens per sample % 64 == 0, large M) | 0: off
- *   "norm_specialize"   1 (default): gated_residual_norm runs instantiations with its three mode switches fixed at compile
- *                       time (the engine's combinations at d = 1536 / 2304 / 3072; bit-identical, 34.4 -> 31.6 us) | 0: generic
- *   "gemm_prefetch"     3 (default): at <= 1024 rows the weight panels of the QKV / O / W1|W3 projections are read into the L2 of the
- *                       XCDs that will stage them by extra workgroups of the row kernel in front of the GEMM | 0 off | 1 / 2: the
- *                       measurement forms (serial launch = upper bound; side stream = loses), DESIGN.md 5.8
- *   "graph"             1 (default): one model evaluation is captured into a HIP graph per (shape, arguments) and replayed | 0: eager
- * (the round-1 knobs gemm_pipeline / gemm_pp_tail / gemm_persist selected study kernels that now live in
- *  csrc/experimental/ - build with `make EXPERIMENTAL=1` and use the explicit lt_op_gemm_bf16 variants) */
+/* ---- options ----------------------------------------------------------------------------------
+ * The engine picks its kernels by problem shape; a handful of A/B and diagnostic options can override the choice.  They are NOT part
+ * of the drop-in surface - an integrator never has to touch them - and are documented, one by one, in include/lumina_dit_debug.h.
+ *   lt_set_option          sets the PROCESS DEFAULT of an option: what engines without an override of their own, and the lt_op_*
+ *                          operator entry points, use
+ *   lt_engine_set_option   overrides an option for ONE engine (every later call on that engine, from any thread; nothing else).
+ *                          value LT_OPTION_INHERIT drops the override again
+ *   lt_engine_get_option   the value in effect for an engine (e == NULL: the process default)
+ * Unknown names and out-of-range values are errors (lt_last_error names the range).  There is no other mutable state outside an
+ * lt_engine. */
+#define LT_OPTION_INHERIT INT32_MIN
 int lt_set_option(const char* name, int32_t value);
+int lt_engine_set_option(lt_engine* e, const char* name, int32_t value);
+int lt_engine_get_option(lt_engine* e, const char* name, int32_t* value);
 
 /* ---- engine lifetime ------------------------------------------------------------------------- */
 int  lt_create(const lt_config* cfg, lt_engine** out);
@@ -262,19 +242,10 @@ int lt_op_gemm_grouped(const void* A_dev, const void* W_dev, const void* tile_ex
 /* the same with gather-on-load (round 3: how the engine runs the experts' W1 | W3 GEMM - no gather pass, no expert-sorted copy of
  * the FFN input): row m of the problem is row row_map_dev[m] (int32 [M]) of A_dev [a_rows, K]; -1 = a padding row that reads as
  * zero.  Ping-pong tile kernels (explicit 3 / 7 / 8) and the grouped mode of the persistent 16x16x32 kernel (explicit 15; K >= 256, all of A
- * below 2^30 bytes, at most 1024 row segments); variant 0 picks the persistent kernel from two 256 x 256 tiles per CU on. */
+ * below 2^30 bytes, at most 1024 row segments); variant 0 picks the persistent kernel from 1.5 tiles of 256 x 256 per CU on (option gemm_w4q_grouped: 2 = from two tiles per CU, 0 = never). */
 int lt_op_gemm_grouped_gather(const void* A_dev, int32_t a_rows, const void* row_map_dev, const void* W_dev, const void* tile_expert_dev,
                               int64_t w_expert_stride, void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
                               void* stream);
-/* diagnostics (EXPERIMENTAL=1 builds only): a GEMM built with s_memtime stamps (variant 3 | 4 ping-pong, 5 rendezvous, 10 four-wave LDS-DMA, 12 four-wave
- * VGPR-staged; plain epilogue); trace_dev (>= 64 * waves * 8 uint64, zeroed by the caller) receives, for every 64th workgroup
- * and each of its waves, 8 x uint64: six per-wave tick totals - variant 3 / 4 / 5: {fragment-read issue, vmcnt wait, lgkmcnt
- * wait, pre-MFMA barrier, MFMA segment, post-MFMA barrier}; 10: {MFMA / read / DMA stream, vmcnt wait, lgkmcnt wait, barrier,
- * 0, 0} over the steady-state slabs; 12: {8 MFMA + reads, vmcnt wait, 8 MFMA + ds_write, lgkmcnt wait, barrier, second
- * half} - then (slab count << 32 | prologue ticks) and (main-loop ticks << 20 | epilogue ticks).  Readers:
- * scripts/gemm_trace.py, scripts/ubench/gemm_trace_native.cpp. */
-int lt_op_gemm_trace(const void* A_dev, const void* W_dev, void* C_dev, int32_t M, int32_t N, int32_t K,
-                     int32_t variant, void* trace_dev, void* stream);
 /* interleave w1[F,K], w3[F,K] into the packed [2F,K] layout epilogue 1 expects */
 int lt_op_pack_w13(const void* w1_dev, const void* w3_dev, void* out_dev, int32_t F, int32_t K,
                    void* stream);
@@ -327,12 +298,6 @@ int lt_op_attention_fused(const void* q_dev, const void* k_dev, const void* vt_d
                           const void* tvt_dev, const float* tbias_dev, const void* tgate_dev, void* out_dev, int32_t B,
                           int32_t H, int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t Tk, int32_t Tkpad,
                           int32_t hd, void* stream);
-/* diagnostics: the hd-72 self-attention kernel (variant 3) built with s_memtime stamps; trace_dev receives, for every
- * 64th workgroup and each of its 8 waves, 8 x uint64: cycle totals of {X phase (MFMA), DMA wait, barrier, Y phase
- * (softmax + DMA issue), barrier}, the tile count. */
-int lt_op_attention_trace(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int32_t B,
-                          int32_t H, int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t hd, float scale,
-                          void* trace_dev, void* stream);
 /* y[m,n] = sum_k act(a[m,k]) w[n,k] + b[n], m < M <= 8 (GEMV-style; adaLN / embedders).
  * act_in 0 none, 1 SiLU.  a bf16 [M,K], w bf16 [N,K], b bf16 [N] or NULL, y bf16 [M,N]. */
 int lt_op_linear_small_m(const void* a_dev, const void* w_dev, const void* b_dev, void* y_dev,

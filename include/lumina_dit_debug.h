@@ -1,0 +1,69 @@
+/* lumina_dit_debug.h - A/B options and diagnostics of the MI355X (gfx950) Next-DiT denoising engine.
+ *
+ * NOT part of the drop-in boundary (include/lumina_dit.h): nothing here is needed to run the reference's path.  This header names
+ * the options lt_set_option / lt_engine_set_option accept (A/B measurements, tests; every default is the measured-best setting) and
+ * declares the one instrumented-kernel entry point.  The option table itself lives in lumina-t2x_amd/csrc/options.hip;
+ * tests/test_abi.py keeps this text and the table in step (every name, its range and default).
+ */
+#ifndef LUMINA_DIT_DEBUG_H
+#define LUMINA_DIT_DEBUG_H
+
+#include "lumina_dit.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Options - name (range, default): meaning.
+ *   "graph"             (0..1, 1): one model evaluation is captured into a HIP graph per (shape, arguments, option generation) and
+ *                       replayed | 0: eager launches
+ *   "attention_variant" (1..6, 4): 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (hd 72 / 96) | 4 one wave per SIMD x 64 query
+ *                       rows, asm-owned AGPRs (hd 72, 96 and 48 with whole 64-key tiles; variant 3 otherwise) | 6 = 4 with the hd-48
+ *                       one-wave kernel forced at every size | 5 is refused (the PV-on-16x16x32 study kernel, removed in round 5)
+ *   "qkv_post_fused"    (0..2, 2): 2 one launch for q / k post-processing + V transpose below 2048 rows (launch-bound regime), three
+ *                       launches above | 1 always one launch | 0 always separate launches
+ *   "qkv_vt_epilogue"   (0..1, 1): the V projection's epilogue writes the attention kernels' transposed, key-permuted V image directly
+ *                       (no V transpose pass; needs tokens per sample % 64 == 0, large M) | 0: off
+ *   "qkv_fused_gemm"    (0..1, 1): Q | K | V projection in one launch where the shapes are whole 256 x 288 (or 256 x 256) tiles
+ *   "qk_post_pair"      (0..1, 1): q and k post-processing share one persistent launch (>= 2048 rows) | 0: two launches
+ *   "attn_q_fused"      (0..1, 1): behind the fused QKV launch at head_dim 72 (2-D RoPE, qk_norm, whole 64-key tiles) q_norm + RoPE of
+ *                       the queries happen in the attention kernel's prologue - the QKV GEMM's epilogue leaves per-row LayerNorm partial
+ *                       sums, the K pass reduces them to (mean, rstd) - and q is never written head-major; the row statistics come from
+ *                       (sum, sum of squares) instead of the two-pass form, so a few queries differ by one bf16 ulp from the "0" path
+ *   "norm_specialize"   (0..1, 1): gated_residual_norm runs instantiations with its three mode switches fixed at compile time (the
+ *                       engine's combinations at d = 1536 / 2304 / 3072; bit-identical, 34.4 -> 31.6 us) | 0: generic kernel
+ *   "gemm_w4q"          (0..1, 1): large dense GEMMs run on the persistent 4-wave 16x16x32 kernel | 0: classic / ping-pong tiles
+ *   "gemm_prefetch"     (0..3, 3): 3 at <= 1024 rows the weight panels of the QKV / O / W1|W3 projections are read into the L2 of the
+ *                       XCDs that will stage them by extra workgroups of the row kernel in front of the GEMM | 0 off | 1 a serial
+ *                       prefetch launch in front of every small-M GEMM (the upper-bound measurement form) | 2 is refused (the
+ *                       side-stream form lost 33 % and was removed in round 5)
+ *   "gemm_splitk"       (0..2, 1): 1 the 64 x 128 small-M tile splits K over two workgroups per tile when both halves fit one round of
+ *                       the CUs (the 512-row O / W2 projections) | 2 whenever the workspace allows | 0 off
+ *   "gemm_w4q_grouped"  (0..2, 1): 1 the grouped (mixture-of-experts) GEMMs run on the persistent kernel's grouped mode from 1.5 tiles
+ *                       of 256 x 256 per CU on | 2 from 2 tiles per CU on (A/B) | 0 always the 8-wave ping-pong / classic tiles
+ *   "gemm_group"        (0..64, 0): tile rows per group of the XCD-aware tile order, 0 = the built-in 4 (experiment, no measured effect)
+ *   "gemm_stagger"      (0..256, 0): the persistent 4-wave GEMM kernels spread the start of the workgroups of an XCD over eight phases,
+ *                       n * ~256 cycles apart (experiment: de-synchronises the tile-end store bursts; measured -0.5 % .. 0 by box)
+ *   "gemm_variant"      (0..2, 0): tile shape of the classic kernels when the caller passes variant 0: 0 auto | 1 256x256 | 2 256x288
+ *   "rmsnorm_apex"      (0..1, 0): rounding order of the weighted RMSNorms.  0 = the reference's vanilla class
+ *                       (lumina_next_t2i/models/components.py:11-54): bf16(x * rstd) * w, two roundings.  1 = apex.FusedRMSNorm, which
+ *                       the reference uses when apex is importable (components.py:6-9): bf16(x * rstd * w), the weight applied in fp32
+ *                       before the one rounding - as SURVEY.md 8c describes it; DESIGN.md 6 explains why the default order is expected to
+ *                       match an apex box too.  Meant for the text-conditional families (Next-DiT T2I, Flag-DiT: the only ones whose
+ *                       reference imports apex) - set it per engine (lt_engine_set_option) and before lt_prepare_prompt, whose hoisted
+ *                       text K / V go through the same norm
+ * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
+ *  deleted with csrc/experimental/ in round 5) */
+
+/* diagnostics: the hd-72 self-attention kernels built with clock stamps.  Variant 3 (ping-pong): trace_dev receives, for every 64th
+ * workgroup and each of its 8 waves, 8 x uint64: cycle totals of {X phase (MFMA), DMA wait, barrier, Y phase (softmax + DMA issue),
+ * barrier}, the tile count.  Variant 4 (one wave per SIMD): per workgroup 8 x uint64 = s_memrealtime (100 MHz) at entry | loop start |
+ * loop end | exit, shader clocks of the loop.  Readers: scripts/attn_trace.py, scripts/attn_trace_v4.py. */
+int lt_op_attention_trace(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int32_t B,
+                          int32_t H, int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t hd, float scale,
+                          void* trace_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI declared in ``include/lumina_dit.h``.
+"""ctypes binding of the C ABI declared in ``include/lumina_dit.h`` (+ the diagnostics of ``include/lumina_dit_debug.h``).
 
 The shared library is built in-tree by ``__graft_entry__.build()`` (``make -C lumina-t2x_amd/csrc``).
 There is NO fallback: if the library is missing or a symbol cannot be resolved the import of the
@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LUMINA_DIT_LIB: an alternate build of the same C ABI (A/B measurements of two kernel versions on one box); still no fallback
 LIB_PATH = os.environ.get("LUMINA_DIT_LIB") or os.path.join(_HERE, "lib", "liblumina_dit.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lumina_dit.h")
+DEBUG_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lumina_dit_debug.h")  # options' documentation + one trace entry point
+LT_OPTION_INHERIT = -2 ** 31
 
 LT_F32, LT_BF16, LT_F16 = 0, 1, 2
 LT_VARIANT_NEXT_T2I, LT_VARIANT_NEXT_IMAGENET, LT_VARIANT_FLAG_T2I, LT_VARIANT_NEXT_MOE = 0, 1, 2, 3
@@ -47,21 +49,29 @@ class LuminaLibError(RuntimeError):
     pass
 
 
-def declared_symbols(header_path: str = HEADER_PATH) -> List[str]:
-    """Names of every function the public header declares (used by the ABI-export test)."""
-    with open(header_path) as f:
-        text = f.read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(", text)))
+def header_text(strip_comments: bool = True) -> str:
+    """both headers concatenated (the drop-in boundary, then the debug header)"""
+    text = ""
+    for path in (HEADER_PATH, DEBUG_HEADER_PATH):
+        with open(path) as f:
+            text += f.read() + "\n"
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S) if strip_comments else text
+
+
+def declared_symbols() -> List[str]:
+    """Names of every function the two headers declare (used by the ABI-export test)."""
+    return sorted(set(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(", header_text())))
 
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
-# name -> (restype, argtypes); mirrors include/lumina_dit.h one to one
+# name -> (restype, argtypes); mirrors include/lumina_dit.h + lumina_dit_debug.h one to one
 _SIGNATURES: Dict[str, tuple] = {
     "lt_last_error": (C.c_char_p, []),
     "lt_version": (C.c_char_p, []),
     "lt_set_option": (_i32, [C.c_char_p, _i32]),
+    "lt_engine_set_option": (_i32, [_vp, C.c_char_p, _i32]),
+    "lt_engine_get_option": (_i32, [_vp, C.c_char_p, C.POINTER(_i32)]),
     "lt_create": (_i32, [C.POINTER(LtConfig), C.POINTER(_vp)]),
     "lt_destroy": (None, [_vp]),
     "lt_set_weight": (_i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32, _vp]),
@@ -93,7 +103,6 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_op_gemm_splitk": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "lt_op_gemm_grouped": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_grouped_gather": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "lt_op_gemm_trace": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "lt_op_pack_w13": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "lt_op_rmsnorm_mod": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lt_op_gated_residual_norm": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),

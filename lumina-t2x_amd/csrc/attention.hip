@@ -17,6 +17,7 @@
 //  * workgroup -> (head, q-block) map keeps all q-blocks of a head on one XCD (private L2) in order.
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
 #include <type_traits>
 
 namespace {
@@ -960,19 +961,20 @@ template __global__ void attn_fwd_kernel_v3<96, false>(AttnArgs);
 
 using lt_attn::attn_fwd_kernel_v3;
 
-static int g_attn_variant = 4;  // 4: one wave per SIMD x 64 query rows where it applies (hd 72, whole tiles), else 3: ping-pong kernel (hd 72 / 96), v2 elsewhere
-void lt_set_attention_variant(int v) { g_attn_variant = v; }
+// option attention_variant (options.h): 4 (default) = one wave per SIMD x 64 query rows where it applies (hd 72 / 96 / 48, whole tiles), else 3 =
+// ping-pong kernel (hd 72 / 96), v2 elsewhere; 6 = 4 with the hd-48 one-wave kernel forced at every size
 
 // true when launch_attention() can take the text keys along with the image keys (one kernel instead of two)
-bool attention_fuses_text(int hd) { return g_attn_variant >= 3 && (hd == 72 || hd == 96); }
+bool attention_fuses_text(int hd) { return lt_opt(OPT_ATTENTION_VARIANT) >= 3 && (hd == 72 || hd == 96); }
 
 // the dispatch condition of attn_fwd_kernel_v4<72> (launch_attention below uses the same expression)
 bool attention_takes_raw_q(const AttnArgs& a) {
-    return g_attn_variant >= 4 && g_attn_variant != 5 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 &&
+    return lt_opt(OPT_ATTENTION_VARIANT) >= 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 &&
            (!a.tk || a.Tkpad <= 256);
 }
 
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
+    const int g_attn_variant = lt_opt(OPT_ATTENTION_VARIANT);
     LT_REQUIRE(a.H % a.Hkv == 0, "attention: H=%d not a multiple of Hkv=%d", a.H, a.Hkv);
     LT_REQUIRE(a.q_raw == nullptr || (attention_takes_raw_q(a) && a.q_stat && a.q_ln_w && a.q_ln_b && a.rope_cs && a.rope_cs_t && a.rope_grid_w > 0 && a.rope_cs_len > 0),
                "attention: q_raw (q_norm + RoPE in the prologue) needs the head_dim-72 one-wave kernel's conditions and the LayerNorm / RoPE inputs");
@@ -990,10 +992,6 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
                    "attention: incomplete fused text arguments");
     }
     // variant 4: one wave per SIMD, 64 query rows per wave (attention_v4.hip); whole 64-key tiles and <= 256 text keys, else the ping-pong kernel
-#ifdef LT_EXPERIMENTAL
-    if (g_attn_variant == 5 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && (!a.tk || a.Tkpad <= 256))
-        return launch_attention_v5(a, stream);  // PV on 16x16x32 MFMAs (csrc/experimental/attention_v5.hip)
-#endif
     if (g_attn_variant >= 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && (!a.tk || a.Tkpad <= 256))
         return launch_attention_v4(a, stream);
     // ... its head_dim 48 form (attention_v4_48.hip, round 4: the 600M ImageNet / MoE models)
@@ -1009,10 +1007,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
         return launch_attention_v4_hd96(a, stream);
     if (g_attn_variant >= 3 && (a.hd == 72 || a.hd == 96) && a.bias == nullptr && !a.accumulate) {
         constexpr int SMEM72 = 4 * (72 * 128 + 128) + 4 * (64 * 72 * 2) + 16, SMEM96 = 4 * (96 * 128) + 4 * (64 * 96 * 2) + 16;
-        if (!func_attr_done(device_slot(), (const void*)attn_fwd_kernel_v3<72>)) {  // per (device, kernel)
-            LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<72>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM72));
-            LT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v3<96>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM96));
-        }
+        if (ensure_dynamic_lds((const void*)attn_fwd_kernel_v3<72>, SMEM72) || ensure_dynamic_lds((const void*)attn_fwd_kernel_v3<96>, SMEM96)) return 1;
         const int nqb3 = (a.N + 255) / 256;
         if (a.trace) {
             LT_REQUIRE(a.hd == 72, "attention trace: the hd 72 kernel is the instrumented one");

@@ -454,8 +454,7 @@ int launch_attention_v4_hd48(const AttnArgs& a, hipStream_t stream) {
     constexpr int SMEM = 4 * (48 * 128 + 256) + 4 * (64 * 48 * 2) + 3 * (64 * 48 * 2) + 32 * 48 * 2 + 512 + 16 + 16 + 4 * (64 * 48 * 2);  // (+ the waves' output strips)
     LT_REQUIRE(a.hd == 48 && !a.bias && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && !a.tk,
                "attention v4 (hd 48): whole 64-key tiles, no per-sample key counts, no fused text keys (the inherited text phase is untested)");
-    if (!func_attr_done(device_slot(), (const void*)lt_attn48::attn_fwd_kernel_v4h48))  // per (device, kernel)
-        LT_CHECK_HIP(hipFuncSetAttribute((const void*)lt_attn48::attn_fwd_kernel_v4h48, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    if (ensure_dynamic_lds((const void*)lt_attn48::attn_fwd_kernel_v4h48, SMEM)) return 1;  // per (device, kernel)
     const int nqb = (a.N + 255) / 256;
     hipLaunchKernelGGL(lt_attn48::attn_fwd_kernel_v4h48, dim3(a.B * a.H * nqb), dim3(256), SMEM, stream, a);
     LT_CHECK_HIP(hipGetLastError());

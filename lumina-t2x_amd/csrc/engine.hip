@@ -20,6 +20,7 @@
 #include "../../include/lumina_dit.h"
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -30,26 +31,23 @@ void lt_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lt_last_error(void) { return g_err; }
-extern "C" const char* lt_version(void) { return lt_gemm_has_experimental() ? "lumina_dit gfx950 r4+experimental" : "lumina_dit gfx950 r4"; }
+extern "C" const char* lt_version(void) { return "lumina_dit gfx950 r5"; }
 
 namespace {
 
 constexpr float LOG2E = 1.44269504088896340736f;
-// lt_set_option("qkv_post_fused"): 1 = one launch for q / k post-processing + V transpose, 0 = three launches, 2 (default) = one
-// launch where the problem is launch-bound (fewer than 2048 rows: the three passes are 5 us each at 512 rows, i.e. pure launch
-// latency - profiles/r02/rocprofv3_kernel_stats_cfg1_r02.csv), three where it is bandwidth-bound (in-situ A/B at cfg 2 with the
-// LDS-staged row kernels, profiles/r01/bench_ab_qkv_post_fused.log: three launches 0.1-0.2 ms / NFE faster).
-int g_qkv_post_fused = 2;
-// lt_set_option("qkv_vt_epilogue"): 1 = the V projection is its own GEMM launch whose epilogue writes the attention kernels' V^T
-// image (no v_transpose pass: 15.6 us per layer at cfg 2, and the 37.7 MB V slice is never written row-major / re-read)
-int g_qkv_vt_epilogue = 1;
-int g_qkv_fused_gemm = 1;  // lt_set_option("qkv_fused_gemm"): Q | K | V in one launch of the persistent kernel where the shapes allow it
-// lt_set_option("graph"): 1 = a model evaluation (~250 launches) is captured into a HIP graph per (arguments, shapes) and replayed.
-// Every lt_set_option bumps g_option_gen, which is part of the graph key (kernel selection is baked into a captured graph).
-int g_attn_q_fused = 1;  // lt_set_option("attn_q_fused"): q_norm + RoPE of the queries inside the attention prologue (hd 72 one-wave kernel, fused QKV GEMM)
-int g_qk_post_pair = 1;  // lt_set_option("qk_post_pair"): 1 = q and k post-processing share one persistent launch (large problems)
-int g_graph = 1;
-int g_option_gen = 0;
+// Kernel-selection options (options.h; lt_set_option = process default, lt_engine_set_option = per-engine override):
+//   qkv_post_fused   1 = one launch for q / k post-processing + V transpose, 0 = three launches, 2 (default) = one launch where the
+//                    problem is launch-bound (fewer than 2048 rows: the three passes are 5 us each at 512 rows, i.e. pure launch latency -
+//                    profiles/r02/rocprofv3_kernel_stats_cfg1_r02.csv), three where it is bandwidth-bound (in-situ A/B at cfg 2 with the
+//                    LDS-staged row kernels, profiles/r01/bench_ab_qkv_post_fused.log: three launches 0.1-0.2 ms / NFE faster)
+//   qkv_vt_epilogue  1 = the V projection is its own GEMM launch whose epilogue writes the attention kernels' V^T image (no v_transpose
+//                    pass: 15.6 us per layer at cfg 2, and the 37.7 MB V slice is never written row-major / re-read)
+//   qkv_fused_gemm   Q | K | V in one launch of the persistent kernel where the shapes allow it
+//   attn_q_fused     q_norm + RoPE of the queries inside the attention prologue (hd 72 one-wave kernel, fused QKV GEMM)
+//   qk_post_pair     1 = q and k post-processing share one persistent launch (large problems)
+//   graph            1 = a model evaluation (~250 launches) is captured into a HIP graph per (arguments, shapes) and replayed.  Every option
+//                    change moves lt_opt_generation(), which is part of the graph key (kernel selection is baked into a captured graph).
 
 struct DevBuf {
     void* p = nullptr;
@@ -114,6 +112,7 @@ static VariantDesc variant_desc(int variant) {
 
 struct lt_engine {
     lt_config cfg;
+    LtEngineOptions opts;  // per-engine option overrides (lt_engine_set_option); LT_OPT_INHERIT slots follow the process defaults
     VariantDesc v;
     int d, L, H, Hkv, hd, F, dkv, qkvn, A, cap, nfinal, kpad, chunks, ld_mod;
     std::vector<DevBuf> allocs;
@@ -176,11 +175,6 @@ struct lt_engine {
     void *g_x = nullptr, *g_out = nullptr;
     float* g_t = nullptr;
     hipStream_t cap_stream = nullptr;
-    // lt_set_option("gemm_prefetch", 2): weight panels of the next 512-row-class GEMM are read into their XCDs' L2 on a side stream,
-    // beside the row / attention kernel that precedes the GEMM (fork before that kernel, join in front of the GEMM)
-    hipStream_t pf_stream = nullptr;
-    hipEvent_t pf_fork = nullptr, pf_join = nullptr;
-    bool pf_pending = false;
     long long graph_replays = 0;
     // profiling
     int prof_mask = 0;  // bit k: class k launches are bracketed by HIP events
@@ -228,32 +222,11 @@ struct ProfScope {
     }
 };
 
-// "gemm_prefetch" 2: called in front of the kernel that PRECEDES a dense GEMM in the stream, with that GEMM's arguments: its weight
-// panels are read on the side stream while the preceding kernel runs; gemm() joins.  Works the same eagerly and inside a stream
-// capture (the side stream joins the capture through the fork event; every fork is joined by the GEMM it was made for).
-int prefetch_fork(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int ldc, int M, int N, int K, int epi, hipStream_t s) {
-    if (g_gemm_prefetch != 2 || M > 1024 || e->pf_pending) return 0;
-    if (!e->pf_stream) {
-        LT_CHECK_HIP(hipStreamCreateWithFlags(&e->pf_stream, hipStreamNonBlocking));
-        LT_CHECK_HIP(hipEventCreateWithFlags(&e->pf_fork, hipEventDisableTiming));
-        LT_CHECK_HIP(hipEventCreateWithFlags(&e->pf_join, hipEventDisableTiming));
-    }
-    GemmArgs g;
-    g.A = A; g.W = W; g.C = C; g.bias = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
-    g.bias_dtype = -1;
-    g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;
-    LT_CHECK_HIP(hipEventRecord(e->pf_fork, s));
-    LT_CHECK_HIP(hipStreamWaitEvent(e->pf_stream, e->pf_fork, 0));
-    if (launch_gemm_prefetch_w(g, epi, e->pf_stream)) return 1;
-    LT_CHECK_HIP(hipEventRecord(e->pf_join, e->pf_stream));
-    e->pf_pending = true;
-    return 0;
-}
-
-// "gemm_prefetch" 3: the same panels read by rider workgroups inside the row kernel that precedes the GEMM (no second stream, no
-// graph edges - which is what option 2 died of: +37 us per layer of cross-stream dependencies)
+// "gemm_prefetch" 3: the weight panels of the next 512-row-class GEMM are read by rider workgroups inside the row kernel that precedes it.
+// (Option 2 - the same reads on a side stream beside the preceding kernel - lost 33 % to +37 us per layer of cross-stream dependencies
+//  and was removed in round 5 together with its fork / join state)
 void prefetch_rider(lt_engine* e, PrefetchRider* r, const u16* A, int lda, const u16* W, int ldw, u16* C, int ldc, int M, int N, int K, int epi) {
-    if (g_gemm_prefetch != 3 || M > 1024) return;
+    if (lt_opt(OPT_GEMM_PREFETCH) != 3 || M > 1024) return;
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.bias = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.bias_dtype = -1;
@@ -267,11 +240,7 @@ int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.bias_dtype = bias ? 1 : -1;
     g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;  // (the launcher decides)
-    if (e->pf_pending) {  // the side stream's panel reads for THIS GEMM (prefetch_fork): join
-        e->pf_pending = false;
-        LT_CHECK_HIP(hipStreamWaitEvent(s, e->pf_join, 0));
-    }
-    if (g_gemm_prefetch == 1 && M <= 1024 && launch_gemm_prefetch_w(g, epi, s)) return 1;
+    if (lt_opt(OPT_GEMM_PREFETCH) == 1 && M <= 1024 && launch_gemm_prefetch_w(g, epi, s)) return 1;
     ProfScope ps(e, 0, 2.0 * M * (double)N * K, s, true);
     return launch_gemm_bf16(g, epi, 0, s, ps.ev0(), ps.ev1());
 }
@@ -592,7 +561,6 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
     }
     auto chunk = [&](int layer, int idx) -> const u16* { return idx < 0 ? nullptr : e->mod + (size_t)layer * cd + (size_t)idx * d; };
     // first pre-norm: modulate(attention_norm(x), [shift,] scale) (model.py:599 / models.py:785 / lumina_t2i model.py:600)
-    if (prefetch_fork(e, e->h, d, e->lw[0].wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, 0, s)) return 1;  // (small problems, option gemm_prefetch 2)
     {
         ProfScope ps(e, 2, 0, s);
         NormModArgs n;
@@ -606,7 +574,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         // V^T epilogue path: q | k columns in one GEMM, the V columns in a second one that writes e->vt directly.  Large problems
         // only (a second launch of a latency-bound 512-row GEMM costs more than the transpose), whole 64-key tiles per sample
         // (no key padding to zero), and not for packed batches (their padded rows must read as zero keys)
-        const bool vt_epi = g_qkv_vt_epilogue && !pk && N % 64 == 0 && (long long)((M + 255) / 256) * ((dkv + 255) / 256) >= 128;
+        const bool vt_epi = lt_opt(OPT_QKV_VT_EPILOGUE) && !pk && N % 64 == 0 && (long long)((M + 255) / 256) * ((dkv + 255) / 256) >= 128;
         // ... and ONE launch for all three when the shapes are whole tiles of the persistent 256 x 288 kernel (lt_set_option
         // "qkv_fused_gemm"): Q | K tiles with the plain epilogue, V tiles with swapped MFMA operands and the V^T epilogue
         GemmArgs gq;
@@ -626,9 +594,9 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             at.tk = w.ky; at.tvt = w.vty; at.tbias = e->txt_bias; at.tgate = w.gate; at.Tk = e->prompt_T; at.Tkpad = e->prompt_Tpad;
         }
         bool raw_q = false;
-        if (vt_epi && g_qkv_fused_gemm && gemm_qkv_fusable(gq)) {
+        if (vt_epi && lt_opt(OPT_QKV_FUSED_GEMM) && gemm_qkv_fusable(gq)) {
             const int bn = gemm_qkv_tile_width(gq);
-            raw_q = g_attn_q_fused && c.qk_norm && !v.rope_1d && !pk && !regional && (fuse_text || !v.text) && attention_takes_raw_q(at) &&
+            raw_q = lt_opt(OPT_ATTN_Q_FUSED) && c.qk_norm && !v.rope_1d && !pk && !regional && (fuse_text || !v.text) && attention_takes_raw_q(at) &&
                     bn > 0 && d % bn == 0 && 2 * d / bn <= 32;
             if (raw_q) { gq.qstat = e->qstat; gq.qstat_cols = d; gq.qstat_slots = 2 * d / bn; }
             ProfScope ps(e, 0, 2.0 * M * (double)(d + 2 * dkv) * d, s, true);
@@ -641,7 +609,6 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             ProfScope ps(e, 0, 2.0 * M * (double)dkv * d, s, true);
             if (launch_gemm_bf16(g, 2, 0, s, ps.ev0(), ps.ev1())) return 1;
         } else if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, nullptr, 0, s)) return 1;
-        if (!regional && (fuse_text || !v.text) && prefetch_fork(e, e->attn, d, w.wo, d, e->o, d, M, d, d, 0, s)) return 1;  // beside q / k post-processing + attention
         {
             ProfScope ps(e, 2, 0, s);
             QkPostArgs qa;
@@ -667,10 +634,10 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 at.q_ln_w = w.q_norm_w; at.q_ln_b = w.q_norm_b;
                 at.rope_cs = e->rope; at.rope_cs_t = e->rope_tr; at.rope_t = t_dev; at.rope_watershed = pa.q.watershed;
                 at.rope_cs_len = e->rope_len; at.rope_grid_w = Wp;
-            } else if (!vt_epi && (g_qkv_post_fused == 1 || (g_qkv_post_fused == 2 && M < 2048))) {
+            } else if (!vt_epi && (lt_opt(OPT_QKV_POST_FUSED) == 1 || (lt_opt(OPT_QKV_POST_FUSED) == 2 && M < 2048))) {
                 if (!regional && (fuse_text || !v.text)) prefetch_rider(e, &pa.pf, e->attn, d, w.wo, d, e->o, d, M, d, d, 0);
                 if (launch_qkv_post(pa, s)) return 1;  // q, k post-processing and the V transpose in one launch
-            } else if (g_qk_post_pair && M >= 2048) {
+            } else if (lt_opt(OPT_QK_POST_PAIR) && M >= 2048) {
                 if (launch_qk_norm_rope_pair(pa.q, pa.k, s)) return 1;  // q and k in one persistent launch
                 if (!vt_epi && launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
             } else {
@@ -697,7 +664,6 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             if (attention(e, at, s)) return 1;
         }
         if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s)) return 1;
-        if (e->E == 0 && prefetch_fork(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, 1, s)) return 1;
         {   // x += gate' * post(attn) ; h = pre_ffn(x) * (1 + scale) [+ shift]
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
@@ -733,7 +699,6 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             last_post_w = w.norm_space;
             last_gate = chunk(l, 5);
         }
-        if (l + 1 < L && prefetch_fork(e, e->h, d, e->lw[l + 1].wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, 0, s)) return 1;
         {   // x += gate' * post(ffn) ; h = next layer's pre-norm + modulate, or the final layer's LayerNorm + modulate
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
@@ -789,14 +754,14 @@ bool profiling_wants_events(const lt_engine* e) {
 }
 
 int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* out, const lt_step_args* a, int use_cfg, hipStream_t s) {
-    if (!g_graph || profiling_wants_events(e) || e->moe_rec_on || e->moe_force_rows) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+    if (!lt_opt(OPT_GRAPH) || profiling_wants_events(e) || e->moe_rec_on || e->moe_force_rows) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
     const int B = a->batch;
     if (B < 1 || B > e->cfg.max_batch || a->latent_h <= 0 || a->latent_w <= 0 || (a->io_dtype != LT_BF16 && a->io_dtype != LT_F32))
         return run_forward(e, x_in, t_dev, out, a, use_cfg, s);  // let the eager path produce the error message
     const size_t sbytes = (size_t)B * e->cfg.in_channels * a->latent_h * a->latent_w * (a->io_dtype == LT_BF16 ? 2 : 4);
     const size_t cap_bytes = (size_t)e->cfg.max_batch * e->cfg.in_channels * e->cfg.max_tokens * e->cfg.patch_size * e->cfg.patch_size * 4;
     if (sbytes > cap_bytes) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
-    const int extra[8] = {use_cfg, e->prompt_B, e->prompt_T, e->prompt_Tpad, e->reg_Y, e->reg_h, e->reg_w, g_option_gen};
+    const int extra[8] = {use_cfg, e->prompt_B, e->prompt_T, e->prompt_Tpad, e->reg_Y, e->reg_h, e->reg_w, lt_opt_generation()};
     std::vector<char> key(sizeof(lt_step_args) + sizeof(extra));
     memcpy(key.data(), a, sizeof(lt_step_args));
     memcpy(key.data() + sizeof(lt_step_args), extra, sizeof(extra));
@@ -1040,9 +1005,6 @@ extern "C" void lt_destroy(lt_engine* e) {
     if (!e) return;
     for (auto& ge : e->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-    if (e->pf_stream) (void)hipStreamDestroy(e->pf_stream);
-    if (e->pf_fork) (void)hipEventDestroy(e->pf_fork);
-    if (e->pf_join) (void)hipEventDestroy(e->pf_join);
     for (auto& b : e->allocs) (void)hipFree(b.p);
     if (e->t_dev) (void)hipFree(e->t_dev);
     if (e->t_pinned) (void)hipHostFree(e->t_pinned);
@@ -1113,6 +1075,7 @@ static int prepare_caption_kv(lt_engine* e, int Bc, int T, int Tpad, hipStream_t
 extern "C" int lt_prepare_prompt(lt_engine* e, const void* cap_feats_dev, int32_t cap_dtype, const int32_t* cap_mask_dev,
                                  int32_t B, int32_t T, void* stream) {
     LT_REQUIRE(e && cap_feats_dev && cap_mask_dev, "lt_prepare_prompt: null argument");
+    LtOptScope opt_scope(&e->opts);
     LT_REQUIRE(e->v.text, "lt_prepare_prompt: this variant is class-conditional (use lt_prepare_labels)");
     hipStream_t s = (hipStream_t)stream;
     const lt_config& c = e->cfg;
@@ -1137,6 +1100,7 @@ extern "C" int lt_prepare_prompt_regional(lt_engine* e, const void* cap_feats_de
                                           int32_t Y, int32_t T, const void* global_feats_dev, const int32_t* global_mask_dev,
                                           int32_t Tg, int32_t h_split, int32_t w_split, void* stream) {
     LT_REQUIRE(e && cap_feats_dev && cap_mask_dev && global_feats_dev && global_mask_dev, "lt_prepare_prompt_regional: null argument");
+    LtOptScope opt_scope(&e->opts);
     LT_REQUIRE(e->cfg.variant == LT_VARIANT_NEXT_T2I, "lt_prepare_prompt_regional: text-conditional Next-DiT only");
     hipStream_t s = (hipStream_t)stream;
     const lt_config& c = e->cfg;
@@ -1179,6 +1143,7 @@ extern "C" int lt_prepare_prompt_regional(lt_engine* e, const void* cap_feats_de
 
 extern "C" int lt_prepare_labels(lt_engine* e, const int32_t* labels_dev, int32_t B, void* stream) {
     LT_REQUIRE(e && labels_dev, "lt_prepare_labels: null argument");
+    LtOptScope opt_scope(&e->opts);
     LT_REQUIRE(e->v.labels, "lt_prepare_labels: this variant is text-conditional (use lt_prepare_prompt)");
     LT_REQUIRE(B >= 1 && B <= e->cfg.max_batch, "label batch %d exceeds max_batch %d", B, e->cfg.max_batch);
     if (lt_weights_ready(e)) return 2;
@@ -1191,12 +1156,14 @@ extern "C" int lt_prepare_labels(lt_engine* e, const int32_t* labels_dev, int32_
 
 extern "C" int lt_forward(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev, const lt_step_args* a, void* stream) {
     LT_REQUIRE(e && x_dev && t_dev && out_dev && a, "lt_forward: null argument");
+    LtOptScope opt_scope(&e->opts);
     return forward_graphed(e, x_dev, t_dev, out_dev, a, 0, (hipStream_t)stream);
 }
 
 extern "C" int lt_forward_packed(lt_engine* e, const void* const* x_ptrs, const int32_t* hw_host, const float* t_dev,
                                  void* const* out_ptrs, const lt_step_args* a, void* stream) {
     LT_REQUIRE(e && x_ptrs && hw_host && t_dev && out_ptrs && a, "lt_forward_packed: null argument");
+    LtOptScope opt_scope(&e->opts);
     LT_REQUIRE(a->batch >= 1 && a->batch <= e->cfg.max_batch, "lt_forward_packed: batch %d outside 1..max_batch %d", a->batch, e->cfg.max_batch);
     for (int b = 0; b < a->batch; ++b) LT_REQUIRE(x_ptrs[b] && out_ptrs[b], "lt_forward_packed: null sample pointer %d", b);
     if (!e->pk_dev) LT_CHECK_HIP(hipMalloc((void**)&e->pk_dev, 128 * sizeof(int)));
@@ -1206,6 +1173,7 @@ extern "C" int lt_forward_packed(lt_engine* e, const void* const* x_ptrs, const 
 
 extern "C" int lt_forward_cfg(lt_engine* e, const void* x_dev, const float* t_dev, void* out_dev, const lt_step_args* a, void* stream) {
     LT_REQUIRE(e && x_dev && t_dev && out_dev && a, "lt_forward_cfg: null argument");
+    LtOptScope opt_scope(&e->opts);
     return forward_graphed(e, x_dev, t_dev, out_dev, a, 1, (hipStream_t)stream);
 }
 
@@ -1213,6 +1181,7 @@ extern "C" int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, vo
                              int32_t n_grid, int32_t method, int32_t use_cfg, int32_t t_round, const lt_step_args* a,
                              void* stream) {
     LT_REQUIRE(e && z_dev && tgrid_host && a, "lt_sample_ode: null argument");
+    LtOptScope opt_scope(&e->opts);
     LT_REQUIRE(n_grid >= 2, "lt_sample_ode: need at least 2 grid points");
     LT_REQUIRE(method >= LT_ODE_EULER && method <= LT_ODE_RK4, "lt_sample_ode: unknown method %d", method);
     hipStream_t s = (hipStream_t)stream;
@@ -1441,31 +1410,61 @@ extern "C" int lt_profile_read(lt_engine* e, int32_t klass, double* ms, int64_t*
     return 0;
 }
 
-extern "C" int lt_set_option(const char* name, int32_t value) {
-    LT_REQUIRE(name, "lt_set_option: null name");
-    ++g_option_gen;  // captured graphs bake the kernel selection: every option change starts new graph keys
-    if (strcmp(name, "graph") == 0) { g_graph = value != 0; return 0; }
-    if (strcmp(name, "attention_variant") == 0) { LT_REQUIRE(value >= 1 && value <= 6, "attention_variant must be 1 .. 6 (6 = 4 with the hd-48 one-wave kernel forced at every size)"); lt_set_attention_variant(value); return 0; }
-    if (strcmp(name, "qkv_post_fused") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "qkv_post_fused must be 0, 1 or 2 (auto)"); g_qkv_post_fused = value; return 0; }
-    if (strcmp(name, "qkv_vt_epilogue") == 0) { g_qkv_vt_epilogue = value != 0; return 0; }
-    if (strcmp(name, "qkv_fused_gemm") == 0) { g_qkv_fused_gemm = value != 0; return 0; }
-    if (strcmp(name, "qk_post_pair") == 0) { g_qk_post_pair = value != 0; return 0; }
-    if (strcmp(name, "attn_q_fused") == 0) { g_attn_q_fused = value != 0; return 0; }
-    if (strcmp(name, "norm_specialize") == 0) { lt_set_norm_specialize(value != 0); return 0; }
-    if (strcmp(name, "gemm_w4q") == 0) { lt_set_gemm_w4q(value != 0); return 0; }
-    if (strcmp(name, "gemm_prefetch") == 0) { lt_set_gemm_prefetch(value); return 0; }
-    if (strcmp(name, "gemm_splitk") == 0) { lt_set_gemm_splitk(value); return 0; }
-    if (strcmp(name, "gemm_w4q_grouped") == 0) { lt_set_gemm_w4q_grouped(value); return 0; }
-    if (strcmp(name, "gemm_group") == 0) { LT_REQUIRE(value >= 0 && value <= 64, "gemm_group must be 0..64"); lt_set_gemm_group(value); return 0; }
-    if (strcmp(name, "gemm_stagger") == 0) { LT_REQUIRE(value >= 0 && value <= 256, "gemm_stagger must be 0..256"); return lt_set_gemm_stagger(value); }
-    if (strcmp(name, "gemm_variant") == 0) { LT_REQUIRE(value >= 0 && value <= 2, "gemm_variant must be 0, 1 or 2"); lt_set_gemm_variant(value); return 0; }
+// Options (options.h).  lt_set_option: the process default - what every engine without its own override, and every lt_op_* operator
+// call, sees.  lt_engine_set_option: an override for one engine (value LT_OPTION_INHERIT drops it again); it applies to every later call
+// on that engine, from any thread, and to nothing else.  Both validate against the option table (gemm_prefetch, gemm_splitk
+// and gemm_w4q_grouped used to accept any integer).
+// returns the option's index, -1 for a retired name given its only accepted value (nothing to do), -2 after lt_set_error
+static int option_lookup(const char* name, int32_t* value, const char* who) {
+    if (!name) { lt_set_error("%s: null name", who); return -2; }
     if (strcmp(name, "gemm_pipeline") == 0 || strcmp(name, "gemm_pp_tail") == 0 || strcmp(name, "gemm_persist") == 0) {
-        // round-1 study knobs: the kernels they selected moved to csrc/experimental/ (explicit lt_op_gemm_bf16 variants there)
-        LT_REQUIRE(value == 0, "lt_set_option(%s): removed - the round-1 study kernels are explicit variants of EXPERIMENTAL=1 builds", name);
-        return 0;
+        // round-1 study knobs: the kernels they selected were deleted with csrc/experimental/ in round 5
+        if (*value != 0) { lt_set_error("%s(%s): removed - the round-1 study kernels are gone (git history keeps them)", who, name); return -2; }
+        return -1;
     }
-    lt_set_error("lt_set_option: unknown option '%s'", name);
-    return 2;
+    const int id = lt_opt_find(name);
+    if (id < 0) {
+        lt_set_error("%s: unknown option '%s'", who, name);
+        return -2;
+    }
+    int v = *value;
+    if (lt_opt_validate(id, &v)) return -2;
+    *value = v;
+    return id;
+}
+
+extern "C" int lt_set_option(const char* name, int32_t value) {
+    const int id = option_lookup(name, &value, "lt_set_option");
+    if (id == -2) return 2;
+    if (id >= 0) lt_opt_set_process(id, value);
+    return 0;
+}
+
+extern "C" int lt_engine_set_option(lt_engine* e, const char* name, int32_t value) {
+    LT_REQUIRE(e, "lt_engine_set_option: null engine");
+    const bool inherit = value == LT_OPTION_INHERIT;
+    int32_t v = inherit ? 0 : value;
+    int id;
+    if (inherit) {
+        id = lt_opt_find(name);
+        LT_REQUIRE(id >= 0, "lt_engine_set_option: unknown option '%s'", name ? name : "(null)");
+    } else {
+        id = option_lookup(name, &v, "lt_engine_set_option");
+        if (id == -2) return 2;
+        if (id < 0) return 0;
+    }
+    e->opts.v[id] = inherit ? LT_OPT_INHERIT : v;
+    ++e->opts.gen;  // new HIP-graph keys: kernel selection is baked into a captured graph
+    return 0;
+}
+
+extern "C" int lt_engine_get_option(lt_engine* e, const char* name, int32_t* value) {
+    LT_REQUIRE(name && value, "lt_engine_get_option: null argument");
+    const int id = lt_opt_find(name);
+    LT_REQUIRE(id >= 0, "lt_engine_get_option: unknown option '%s'", name);
+    LtOptScope opt_scope(e ? &e->opts : nullptr);  // e == NULL: the process default
+    *value = lt_opt(id);
+    return 0;
 }
 
 // ---- operator-level entry points ---------------------------------------------------------------------------
@@ -1523,7 +1522,7 @@ extern "C" int lt_op_gemm_qkv_fusable(int32_t M, int32_t N, int32_t K, int32_t s
     GemmArgs g;
     g.A = nullptr; g.W = nullptr; g.C = nullptr; g.bias = nullptr; g.bias_dtype = -1; g.M = M; g.N = N; g.K = K;
     g.lda = K; g.ldw = K; g.ldc = N; g.VT = (u16*)1; g.vt_split = split; g.vt_tokens = tokens; g.vt_hd = hd; g.vt_npad = tokens;
-    return g_qkv_fused_gemm && g_qkv_vt_epilogue && gemm_qkv_fusable(g) ? 1 : 0;
+    return lt_opt(OPT_QKV_FUSED_GEMM) && lt_opt(OPT_QKV_VT_EPILOGUE) && gemm_qkv_fusable(g) ? 1 : 0;
 }
 
 extern "C" int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap) {
@@ -1578,19 +1577,6 @@ extern "C" int lt_op_gemm_grouped_gather(const void* A, int32_t a_rows, const vo
     g.tile_expert = (const int*)tile_expert; g.w_expert_stride = w_expert_stride;
     g.a_row_map = (const int*)row_map; g.a_map_rows = a_rows;
     return launch_gemm_bf16(g, epilogue, variant, (hipStream_t)stream);
-}
-
-extern "C" int lt_op_gemm_trace(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t variant,
-                                void* trace_dev, void* stream) {
-    LT_REQUIRE(A && W && C && trace_dev, "lt_op_gemm_trace: null pointer");
-    GemmArgs g;
-    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
-    g.lda = K; g.ldw = K; g.ldc = N; g.bias_dtype = -1; g.trace = (unsigned long long*)trace_dev;
-    if (variant >= 100) {  // 100 + v: the SwiGLU form of variant v (W = w1 / w3 interleaved, C is [M, N / 2])
-        g.ldc = N / 2;
-        return launch_gemm_bf16(g, 1, variant - 100, (hipStream_t)stream);
-    }
-    return launch_gemm_bf16(g, 0, variant, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_pack_w13(const void* w1, const void* w3, void* out, int32_t F, int32_t K, void* stream) {

@@ -21,6 +21,7 @@
 //    grouped (4 tile-rows, column-major) order so neighbouring tiles share A/W panels in one L2.
 
 #include "gemm_device.h"
+#include "options.h"
 #include <mutex>
 #include <set>
 #include <utility>
@@ -61,18 +62,19 @@ int num_cus() {
 }
 
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per (device, function): a process that drives several devices must set it on each
-// (VERDICT r3 / ADVICE r3: the function-local `static bool attr_done` guards were per process).  Returns true if (slot, fn) was seen.
-int device_slot() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
-    return dev;
-}
-bool func_attr_done(int dev, const void* fn) {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per (device, function): a process that drives several devices must set it on each.
+// The (device, function) pair is recorded only AFTER the call succeeded (a failed first attempt used to mark the pair as done,
+// every later launch then died with too little dynamic LDS and the original error was lost), keyed by the real device id.
+int ensure_dynamic_lds(const void* fn, int bytes) {
     static std::mutex mu;
-    static std::set<std::pair<int, const void*>> seen;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    LT_CHECK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    return !seen.insert({dev, fn}).second;
+    if (done.count({dev, fn})) return 0;
+    LT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({dev, fn});
+    return 0;
 }
 
 // the fused QKV projection (epilogue 3) runs on the persistent kernel only: whole 288- or 256-wide tiles on both sides of the split,
@@ -123,7 +125,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     const void* fn;
     if constexpr (PP) fn = (const void*)gemm_bf16_pp<WM, WN, MT, NT, EPI, false, 0, MODE, KS>;
     else fn = (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
-    if (!func_attr_done(device_slot(), fn)) LT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    if (ensure_dynamic_lds(fn, SMEM)) return 1;
     const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
     const dim3 grid(TM * TN * (a.split_k == 2 ? 2 : 1)), block(WM * WN * 64);
     if constexpr (PP) {
@@ -142,8 +144,7 @@ template <int EPI, int NW16, bool GROUPED = false>
 int launch_w4q(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     // GROUPED: + two 1-KiB gather-map slots, the list of valid row tiles (<= 1024) and its count behind the slab ring
     constexpr int BN = 32 * NW16, SMEM = 4 * (256 + BN) * 64 + (GROUPED ? 2048 + 4096 + 16 : 0);
-    if (!func_attr_done(device_slot(), (const void*)gemm_bf16_w4q<EPI, NW16, false, GROUPED>))
-        LT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4q<EPI, NW16, false, GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    if (ensure_dynamic_lds((const void*)gemm_bf16_w4q<EPI, NW16, false, GROUPED>, SMEM)) return 1;
     const int tiles = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN);
     const int cus = num_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(256);
@@ -157,7 +158,7 @@ int launch_w4q(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
 enum GemmKernel {
     GK_TN256, GK_TN288, GK_TN256_VT, GK_TN288_VT, GK_TN256_SWIGLU, GK_PP256, GK_PP256_SWIGLU,
     GK_S128, GK_S128_SWIGLU, GK_S64, GK_W4Q256, GK_W4Q288, GK_W4Q256_SWIGLU, GK_W4Q288_QKV, GK_W4Q256_QKV, GK_W4Q256_GROUPED,
-    GK_W4Q256_SWIGLU_GROUPED, GK_EXPERIMENTAL, GK_NONE
+    GK_W4Q256_SWIGLU_GROUPED, GK_REMOVED, GK_NONE
 };
 const char* const kGemmKernelName[] = {
     "gemm_bf16_tn<2,4,4,2,0> (256x256, 8 waves)", "gemm_bf16_tn<4,3,2,3,0> (256x288, 12 waves)",
@@ -170,18 +171,16 @@ const char* const kGemmKernelName[] = {
     "gemm_bf16_w4q<3,9> (persistent 4 waves, 16x16x32 MFMA, 256x288, fused QKV: plain Q|K tiles + V^T tiles)",
     "gemm_bf16_w4q<3,8> (persistent 4 waves, 16x16x32 MFMA, 256x256, fused QKV: plain Q|K tiles + V^T tiles)",
     "gemm_bf16_w4q<0,8,grouped> (persistent 4 waves, 16x16x32 MFMA, 256x256, expert segments)",
-    "gemm_bf16_w4q<1,8,grouped> (persistent 4 waves, 16x16x32 MFMA, 256x256, expert segments, gather-on-load, SwiGLU)", "experimental", "none"};
+    "gemm_bf16_w4q<1,8,grouped> (persistent 4 waves, 16x16x32 MFMA, 256x256, expert segments, gather-on-load, SwiGLU)", "removed study kernel", "none"};
 
-int g_gemm_variant = 0;   // tile shape when the caller passes 0: 0 auto, 1 = 256x256, 2 = 256x288
-int g_gemm_stagger = 0;
-int g_gemm_group = 0;
-int g_gemm_w4q = 1;  // 1 (default): large dense GEMMs (>= one tile per CU) run on the persistent 16x16x32 kernel (256 / 288-wide tiles)
-// split-K of the 512-row-class GEMMs (round 4).  A 64 x 128 workgroup of the O / W2 projections at 512 rows stages 0.6 / 1.6 MB through
-// a CU that fills at ~50 GB/s: cutting K in two halves the bytes per workgroup and doubles the busy CUs (96 -> 192).
-// Round 3 priced it with an equivalent-shape probe (O 15.9 -> 10.4 us, W2 30.9 -> 19.0 us) and declined because of the consumer-side
-// partial sums; here the second-arriving half adds the first one's fp32 partial itself (counter per tile), no consumer changes.
-int g_gemm_splitk = 1;
-int g_gemm_w4q_grouped = 1;  // 1 (default): grouped (MoE expert) GEMMs with >= 1.5 tiles per CU as well (round 4; at one tile per CU - the 600M MoE at 256 tokens - the 8-wave tiles are 4 % faster)
+// Options (options.h; lt_set_option / lt_engine_set_option):
+//   gemm_variant      tile shape when the caller passes 0: 0 auto, 1 = 256x256, 2 = 256x288
+//   gemm_w4q          1 (default): large dense GEMMs (>= one tile per CU) run on the persistent 16x16x32 kernel (256 / 288-wide tiles)
+//   gemm_splitk       split-K of the 512-row-class GEMMs (round 4).  A 64 x 128 workgroup of the O / W2 projections at 512 rows stages
+//                     0.6 / 1.6 MB through a CU that fills at ~50 GB/s: cutting K in two halves the bytes per workgroup and
+//                     doubles the busy CUs (96 -> 192); the second-arriving half adds the first one's fp32 partial itself (counter per tile)
+//   gemm_w4q_grouped  1 (default): grouped (MoE expert) GEMMs with >= 1.5 tiles per CU as well (round 4; at one tile per CU - the 600M MoE
+//                     at 256 tokens - the 8-wave tiles are 4 % faster); 2: from 2 tiles per CU on
 
 // the persistent kernel's grouped mode: expert segments (and gather-on-load) - one descriptor over all of A, lane offsets < 2^31
 // (gather: < 2^30, the out-of-range offset of a padding row is 2^30), <= 1024 row tiles in the LDS list, K >= 256 (the map of the
@@ -194,16 +193,14 @@ bool w4q_grouped_ok(const GemmArgs& a, int epilogue) {
 }
 
 // variant: 0 = auto; 1 / 2 = 256x256 / 256x288 classic loop; 3 = 256x256 8-wave ping-pong; 7 / 8 = 128x128 / 64x128 small-M tiles;
-//          13 / 14 = persistent 4 waves x (128 x 128) (14: a tile's epilogue rides in the next tile's first slab);
 //          15 / 16 = persistent 4 waves on 16x16x32 MFMAs, 256x256 / 256x288 tiles;
-//          4, 5, 6, 9, 10, 11, 12 = experimental builds only
+//          4, 5, 6, 9 .. 14, 17, 18 = study kernels of rounds 1-3, removed (git history)
 GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     const bool w4p_ok = !a.tile_expert && !a.trace && a.bias_dtype < 0 && a.K % 64 == 0 && a.K >= 128 &&
                         255LL * a.ldc * 2 + (long long)a.N * 2 < 0x7fffffffLL && epilogue != 2;
     if (epilogue == 3) { const int bn = gemm_qkv_fused_tile(a); return bn == 288 ? GK_W4Q288_QKV : bn == 256 ? GK_W4Q256_QKV : GK_NONE; }
-    if (a.trace) return GK_EXPERIMENTAL;
-    if (a.tile_expert && (variant == 15 || (variant == 0 && g_gemm_variant == 0 && g_gemm_w4q && g_gemm_w4q_grouped &&
-                                             2LL * ((a.M + 255) / 256) * ((a.N + 255) / 256) >= (g_gemm_w4q_grouped == 2 ? 4LL : 3LL) * num_cus()))) {
+    if (a.tile_expert && (variant == 15 || (variant == 0 && lt_opt(OPT_GEMM_VARIANT) == 0 && lt_opt(OPT_GEMM_W4Q) && lt_opt(OPT_GEMM_W4Q_GROUPED) &&
+                                             2LL * ((a.M + 255) / 256) * ((a.N + 255) / 256) >= (lt_opt(OPT_GEMM_W4Q_GROUPED) == 2 ? 4LL : 3LL) * num_cus()))) {
         if (w4q_grouped_ok(a, epilogue)) return epilogue == 1 ? GK_W4Q256_SWIGLU_GROUPED : GK_W4Q256_GROUPED;
         if (variant == 15) return GK_NONE;
     }
@@ -211,12 +208,12 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
         if (!w4p_ok || (epilogue == 1 && variant == 16)) return GK_NONE;
         return epilogue == 1 ? GK_W4Q256_SWIGLU : (variant == 15 ? GK_W4Q256 : GK_W4Q288);
     }
-    if (a.trace || variant == 4 || variant == 5 || variant == 6 || (variant >= 9 && variant <= 14) || variant == 17 || variant == 18) return GK_EXPERIMENTAL;
+    if (variant == 4 || variant == 5 || variant == 6 || (variant >= 9 && variant <= 14) || variant == 17 || variant == 18) return GK_REMOVED;
     const int cus = num_cus();
     const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (epilogue == 2) {  // V^T epilogue: the two classic tile shapes
-        int v = variant == 0 ? g_gemm_variant : variant;
+        int v = variant == 0 ? lt_opt(OPT_GEMM_VARIANT) : variant;
         if (v != 1 && v != 2) {
             const long long t288 = (long long)((a.M + 255) / 256) * ((a.N + 287) / 288);
             v = ((t288 + cus - 1) / cus) * 288 < ((t256 + cus - 1) / cus) * 256 ? 2 : 1;
@@ -226,12 +223,12 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     // small-M problems (cfg 1 / cfg 5: 512 rows): 256-wide tiles leave most CUs idle and every workgroup is a long serial
     // K loop that streams weights nobody else re-uses; 128 x 128 (or 64 x 128) tiles give 4-8x the workgroups, each with
     // its own 3-slab prefetch window, single-barrier rendezvous loop over 64-deep slabs (profiles/r01/opbench_small_m.log)
-    const bool small = variant == 7 || variant == 8 || (variant == 0 && g_gemm_variant == 0 && 2 * t256 <= cus);
+    const bool small = variant == 7 || variant == 8 || (variant == 0 && lt_opt(OPT_GEMM_VARIANT) == 0 && 2 * t256 <= cus);
     if (small) {
         if (epilogue == 1) return GK_S128_SWIGLU;
         return (variant == 8 || (variant == 0 && 2 * t128 <= cus)) ? GK_S64 : GK_S128;
     }
-    if (variant == 0 && g_gemm_variant == 0 && g_gemm_w4q && w4p_ok && t256 >= cus) {
+    if (variant == 0 && lt_opt(OPT_GEMM_VARIANT) == 0 && lt_opt(OPT_GEMM_W4Q) && w4p_ok && t256 >= cus) {
         if (epilogue == 1) return GK_W4Q256_SWIGLU;
         const long long t288 = (long long)((a.M + 255) / 256) * ((a.N + 287) / 288);
         return ((t288 + cus - 1) / cus) * 288 < ((t256 + cus - 1) / cus) * 256 ? GK_W4Q288 : GK_W4Q256;
@@ -241,7 +238,7 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
         return GK_PP256_SWIGLU;
     }
     if (variant == 3) return GK_PP256;
-    if (variant == 0) variant = g_gemm_variant;
+    if (variant == 0) variant = lt_opt(OPT_GEMM_VARIANT);
     if (variant == 0) {
         const long long t288 = (long long)((a.M + 255) / 256) * ((a.N + 287) / 288);
         const long long c256 = ((t256 + cus - 1) / cus) * 256, c288 = ((t288 + cus - 1) / cus) * 288;
@@ -251,30 +248,12 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
 }
 }  // namespace
 
-#ifdef LT_EXPERIMENTAL
-int launch_gemm_experimental(const GemmArgs& a, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
-#endif
-
-void lt_set_gemm_variant(int v) { g_gemm_variant = v; }
-void lt_set_gemm_w4q(int v) { g_gemm_w4q = v; }
-void lt_set_gemm_splitk(int v) { g_gemm_splitk = v; }
-void lt_set_gemm_w4q_grouped(int v) { g_gemm_w4q_grouped = v; }  // 0 off, 1 from 1.5 tiles per CU (default), 2 from 2 tiles per CU (A/B)
-int lt_set_gemm_stagger(int v) { g_gemm_stagger = v; return 0; }
-void lt_set_gemm_group(int v) { g_gemm_group = v; }
-bool lt_gemm_has_experimental() {
-#ifdef LT_EXPERIMENTAL
-    return true;
-#else
-    return false;
-#endif
-}
-
 const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant) { return kGemmKernelName[choose(a, epilogue, variant)]; }
 
 int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     GemmArgs a = a0;
-    a.stagger = g_gemm_stagger;
-    a.group_rows = g_gemm_group;
+    a.stagger = lt_opt(OPT_GEMM_STAGGER);
+    a.group_rows = lt_opt(OPT_GEMM_GROUP);
     LT_REQUIRE(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
     LT_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
     LT_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm: unknown epilogue %d", epilogue);
@@ -292,10 +271,10 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
     const GemmKernel k = choose(a, epilogue, variant);
     // split-K: dense plain-epilogue problems on the 64 x 128 tiles whose two halves still fit one round of the CUs, K >= 1024
     a.split_k = 0;
-    if (k == GK_S64 && g_gemm_splitk && (variant == 0 || variant == 8) && a.splitk_part && a.splitk_cnt && !a.tile_expert && !a.a_row_map && a.bias_dtype < 0 &&
+    if (k == GK_S64 && lt_opt(OPT_GEMM_SPLITK) && (variant == 0 || variant == 8) && a.splitk_part && a.splitk_cnt && !a.tile_expert && !a.a_row_map && a.bias_dtype < 0 &&
         a.K >= 1024 && a.K % 512 == 0) {
         const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
-        if ((2 * tiles <= num_cus() || g_gemm_splitk == 2) && tiles <= a.splitk_tiles) a.split_k = 2;
+        if ((2 * tiles <= num_cus() || lt_opt(OPT_GEMM_SPLITK) == 2) && tiles <= a.splitk_tiles) a.split_k = 2;
     }
     if (a.a_row_map) {  // gather-on-load lives in the ping-pong kernels' staging (the grouped SwiGLU GEMM of the MoE layers)
         LT_REQUIRE(k == GK_PP256_SWIGLU || k == GK_PP256 || k == GK_S128 || k == GK_S128_SWIGLU || k == GK_S64 || k == GK_W4Q256_GROUPED ||
@@ -321,13 +300,9 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         case GK_W4Q256_QKV: return launch_w4q<3, 8>(a, stream, ev0, ev1);
         case GK_W4Q256_GROUPED: return launch_w4q<0, 8, true>(a, stream, ev0, ev1);
         case GK_W4Q256_SWIGLU_GROUPED: return launch_w4q<1, 8, true>(a, stream, ev0, ev1);
-        case GK_EXPERIMENTAL:
-#ifdef LT_EXPERIMENTAL
-            return launch_gemm_experimental(a, epilogue, variant, stream, ev0, ev1);
-#else
-            lt_set_error("gemm: variant %d%s is an experimental kernel - rebuild with `make EXPERIMENTAL=1`", variant, a.trace ? " (trace build)" : "");
+        case GK_REMOVED:
+            lt_set_error("gemm: variant %d was a study kernel of csrc/experimental/ (rounds 1-3), removed in round 5; product variants: 0 auto, 1, 2, 3, 7, 8, 15, 16", variant);
             return 2;
-#endif
         default:
             lt_set_error("gemm: variant %d cannot run this problem (persistent 4-wave kernels: dense, no bias, K %% 64 == 0, K >= 128)", variant);
             return 2;
@@ -344,8 +319,6 @@ __global__ __launch_bounds__(256) void gemm_prefetch_w_kernel(PrefetchRider r) {
 // lt_set_option "gemm_prefetch": 3 (default) = the W panels of the 512-row-class GEMMs are read by rider workgroups of the row kernel
 // that precedes the GEMM (cfg 1 -1.6 %, cfg 5 -1..3 % on a fast-class box, -6.5 % on a slow one); 0 = off; 1 = a prefetch launch right in
 // front of every small-M GEMM (same stream: the upper bound experiment); 2 = on a side stream beside the preceding kernel (loses 33 %)
-int g_gemm_prefetch = 3;
-void lt_set_gemm_prefetch(int v) { g_gemm_prefetch = v; }
 
 bool gemm_prefetch_rider(const GemmArgs& a0, int epilogue, PrefetchRider* r) {
     GemmArgs a = a0;
@@ -356,7 +329,7 @@ bool gemm_prefetch_rider(const GemmArgs& a0, int epilogue, PrefetchRider* r) {
     else return false;  // not a small-M launch: nothing to do
     if (a.tile_expert || a.a_row_map) return false;
     int split = 0;
-    if (k == GK_S64 && g_gemm_splitk && a.splitk_part && a.bias_dtype < 0 && a.K >= 1024 && a.K % 512 == 0) {
+    if (k == GK_S64 && lt_opt(OPT_GEMM_SPLITK) && a.splitk_part && a.bias_dtype < 0 && a.K >= 1024 && a.K % 512 == 0) {
         const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
         if (2 * tiles <= num_cus() && tiles <= a.splitk_tiles) split = 2;
     }

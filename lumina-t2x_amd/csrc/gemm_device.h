@@ -719,6 +719,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         // L2s are not coherent: the partials are stored and loaded SYSTEM-coherent (sc0 sc1: written through to / read from the memory
         // side) and the counter is a system-scope atomic.  NOT __threadfence(): an agent-scope release / acquire on this part is
         // buffer_wbl2 + buffer_inv - a write-back and invalidate of the XCD's whole 4 MiB L2 - and made every split GEMM 40 us slower.
+        // What the hand-off relies on: an sc0 sc1 store is written THROUGH the L2 and its vmcnt credit returns only with the
+        // memory side's acknowledgement, so after `s_waitcnt vmcnt(0)` (inline asm: the compiler cannot drop or move it) + the
+        // workgroup barrier every lane's partial is visible device-wide BEFORE lane 0 touches the counter; the reader's sc0 sc1 loads
+        // miss its own L2 by definition and are issued after the counter's returning atomic has told it that it is second.  This is the
+        // "drained sc1 payload -> asm vmcnt(0) -> sc1 flag" form of /opt/skills/guides/MI355X_MICROARCH.md (price list, row
+        // handoff-flag; the failure it warns about - the flag overtaking the write-back - needs a compiler-visible fence to be dropped,
+        // which the asm wait is not).  tests/test_gpu_ops.py::test_gemm_splitk_handoff_stress runs 3000 split launches against a
+        // concurrent L2-thrashing stream and checks every output word of every launch.
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
         constexpr int PART_BYTES = BM * BN * 4, CP = 17;  // aux bits: sc0 | sc1
         const __amdgpu_buffer_rsrc_t rMine = __builtin_amdgcn_make_buffer_rsrc((void*)(p.splitk_part + ((size_t)bid * 2 + ksplit) * (BM * BN)), 0, PART_BYTES, 0x00020000);

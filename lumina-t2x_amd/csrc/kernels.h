@@ -60,8 +60,6 @@ struct PrefetchRider {
 };
 bool gemm_prefetch_rider(const GemmArgs& a, int epilogue, PrefetchRider* r);
 int launch_gemm_prefetch_w(const GemmArgs& a, int epilogue, hipStream_t stream);  // experiment: W panels of a small-M GEMM -> the L2 of the XCDs that will stage them
-void lt_set_gemm_prefetch(int v);
-extern int g_gemm_prefetch;
 bool gemm_qkv_fusable(const GemmArgs& a);
 int gemm_qkv_tile_width(const GemmArgs& a);  // 288 / 256 (the fused launch's tile width), 0 = not fusable  // epilogue 3 can take this problem (else: one plain launch for Q | K + one V^T launch)
 int launch_pack_w13(const u16* w1, const u16* w3, u16* out, int F, int K, hipStream_t stream);
@@ -76,6 +74,7 @@ struct NormModArgs {
     int rows, rows_per_batch, d, ld_mod;
     float eps;
     int scale_pre = 0;  // 1: `scale` already holds bf16(1 + scale) (engine: prepared once per NFE by launch_prep_mod)
+    int apex = 0;       // set by the launcher from option rmsnorm_apex: the weight multiplies in fp32 before the one rounding
 };
 int launch_rmsnorm_mod(const NormModArgs& a, hipStream_t stream);
 
@@ -92,6 +91,7 @@ struct GatedResArgs {
     int post_mode, gate_mode, next_mode;
     float eps, eps_next;
     int scale_pre = 0;  // 1: next_scale already holds bf16(1 + scale)
+    int apex = 0;       // set by the launcher from option rmsnorm_apex (generic kernel only; the specialised instantiations are bypassed)
     // MoE layers: y is the top-2 combine of the experts' outputs, formed on the way in (y may then be null):
     // ys [sorted rows, d], pos [rows, 2] sorted row of each (token, expert) pair, wts [rows, 2] bf16 routing weights (MoeArgs)
     const u16* moe_ys = nullptr;
@@ -100,7 +100,6 @@ struct GatedResArgs {
     PrefetchRider pf;  // weight panels of the GEMM that follows, read by extra workgroups of this launch (512-row-class problems)
 };
 int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream);
-void lt_set_norm_specialize(int v);  // 1: mode-specialised gated_residual_norm instantiations (experiment, default 0)
 
 // ---- q/k/v post-processing (qkv_post.hip) ------------------------------------------------------
 struct QkPostArgs {
@@ -190,19 +189,9 @@ int launch_attention(const AttnArgs& a, hipStream_t stream);
 int launch_attention_v4(const AttnArgs& a, hipStream_t stream);  // hd 72, 4 waves x 64 query rows (attention_v4.hip)
 int launch_attention_v4_hd48(const AttnArgs& a, hipStream_t stream);  // hd 48, the same structure, softmax-bound (attention_v4_48.hip)
 int launch_attention_v4_hd96(const AttnArgs& a, hipStream_t stream);  // hd 96, the same structure without pad slots (attention_v4_96.hip)
-int launch_attention_v5(const AttnArgs& a, hipStream_t stream);  // the same with the PV product on 16x16x32 MFMAs (attention_v5.hip)
 bool attention_takes_raw_q(const AttnArgs& a);  // launch_attention would run this call on attn_fwd_kernel_v4<72> (the kernel with the q_raw prologue)
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
-void lt_set_attention_variant(int v);  // 1 = baseline online softmax, 2 = VALU-diet kernel (default)
-void lt_set_gemm_variant(int v);       // 0 = auto tile shape, 1 = 256x256, 2 = 256x288
-void lt_set_gemm_w4q(int v);           // 1: large dense GEMMs on the persistent 16x16x32 kernel (variants 15 / 16)
-void lt_set_gemm_w4q_grouped(int v);   // 1: grouped (MoE expert) GEMMs with >= 2 tiles per CU on the persistent kernel too (default 1)
-int device_slot();                     // current HIP device id (0..63)
-bool func_attr_done(int dev, const void* fn);  // first call per (device, kernel) returns false: set the kernel's dynamic-LDS attribute then
-void lt_set_gemm_splitk(int v);        // 1 (default): 512-row-class O / W2 GEMMs split their K range over two workgroups per tile; 2: wherever the shape allows (tests)
-void lt_set_gemm_group(int v);          // tile rows per group in the tile order of the 16x16x32 kernel (experiment; 0 = default 4)
-int lt_set_gemm_stagger(int v);        // 4-wave kernels (variants 10, 13, 14): start-phase spread per XCD, units of ~256 cycles (0 = off)
-bool lt_gemm_has_experimental();       // built with EXPERIMENTAL=1 (variants 4-6, 9-12, trace builds, pipeline knobs)
+int ensure_dynamic_lds(const void* fn, int bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel); marks the pair only on success
 const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant);  // name of the kernel launch_gemm_bf16 would run
 
 // ---- mixture-of-experts routing (moe.hip; Next-DiT-MoE/models/models2.py:451-506) --------------------------------

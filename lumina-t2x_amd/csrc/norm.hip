@@ -10,6 +10,7 @@
 // lane per chunk; wave shuffles for the reductions; no LDS, no barrier).
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
 #include "tile_order.h"
 
 namespace {
@@ -52,10 +53,12 @@ __device__ __forceinline__ float row_sumsq(const RowRaw<MAXCH>& r) {
 }
 
 // h = bfr(bfr(bfr(x * r) * w) * bfr(1 + scale)) (+ shift)   -- each step optional as in the reference;
-// scale_pre: `scale` already holds bfr(1 + scale)
+// scale_pre: `scale` already holds bfr(1 + scale).  apex (option rmsnorm_apex; a literal 0 from the specialised instantiations, so the
+// test folds away there): bfr(x * r * w) - the weight multiplies in fp32 before the one rounding (SURVEY.md 8c's description of
+// apex.FusedRMSNorm; DESIGN.md 6 on why the default order is expected to match an apex box as well)
 template <int MAXCH>
 __device__ __forceinline__ void apply_rms_mod_store(const RowRaw<MAXCH>& r, float rinv, const u16* w, const u16* scale,
-                                                    const u16* shift, int scale_pre, u16* out, int nch, int lane) {
+                                                    const u16* shift, int scale_pre, u16* out, int nch, int lane, int apex = 0) {
     const f32x2 rv = {rinv, rinv};
     const f32x2 one = {1.f, 1.f};
 #pragma unroll
@@ -69,7 +72,7 @@ __device__ __forceinline__ void apply_rms_mod_store(const RowRaw<MAXCH>& r, floa
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 f32x2 n = unpk_bf(r.c[i].w[k]) * rv;
-                if (w) n = bfr2(n) * unpk_bf(wv.w[k]);
+                if (w) n = (apex ? n : bfr2(n)) * unpk_bf(wv.w[k]);
                 if (scale) n = bfr2(n) * (scale_pre ? unpk_bf(sv.w[k]) : bfr2(one + unpk_bf(sv.w[k])));
                 if (shift) n = bfr2(n) + unpk_bf(hv.w[k]);
                 o.w[k] = pk_bf(n);
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(NormModArgs p) {
     load_row(p.x + (size_t)row * p.d, nch, lane, r);
     const float rinv = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
     apply_rms_mod_store(r, rinv, p.w, p.scale ? p.scale + (size_t)b * p.ld_mod : nullptr,
-                        p.shift ? p.shift + (size_t)b * p.ld_mod : nullptr, p.scale_pre, p.out + (size_t)row * p.d, nch, lane);
+                        p.shift ? p.shift + (size_t)b * p.ld_mod : nullptr, p.scale_pre, p.out + (size_t)row * p.d, nch, lane, p.apex);
 }
 
 // PM / GM / NM >= 0: post_mode / gate_mode / next_mode fixed at compile time (the engine's combinations; selected by
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(NormModArgs p) {
 template <int MAXCH, int PM = -1, int GM = -1, int NM = -1, bool MOE = false>
 __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p) {
     const int post_mode = PM >= 0 ? PM : p.post_mode, gate_mode = GM >= 0 ? GM : p.gate_mode, next_mode = NM >= 0 ? NM : p.next_mode;
+    const int apex = (PM >= 0 || MOE) ? 0 : p.apex;  // generic dense instantiations only (the launcher routes apex calls there)
     if ((int)blockIdx.x >= p.pf.first) {  // rider workgroups (GatedResArgs::pf): the next GEMM's weight panels -> their XCDs' L2
         prefetch_w_block(p.pf, (int)blockIdx.x - p.pf.first);
         return;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 f32x2 yn = unpk_bf(r.c[i].w[k]);
-                if (post_mode == 1) yn = bfr2(bfr2(yn * rv) * unpk_bf(wv.w[k]));
+                if (post_mode == 1) yn = bfr2((apex ? yn * rv : bfr2(yn * rv)) * unpk_bf(wv.w[k]));
                 if (gate_mode == 1) {
                     const f32x2 g = unpk_bf(gv.w[k]);
                     yn = bfr2(bfr2(f32x2{tanhf(g[0]), tanhf(g[1])}) * yn);
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
     u16* hrow = p.h + (size_t)row * p.d;
     if (next_mode == 1) {
         const float r2 = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
-        apply_rms_mod_store(r, r2, p.next_w, nscale, nshift, p.scale_pre, hrow, nch, lane);
+        apply_rms_mod_store(r, r2, p.next_w, nscale, nshift, p.scale_pre, hrow, nch, lane, apex);
     } else {
         // affine-free LayerNorm in fp32, modulate in fp32, one rounding (the cast autocast applies at the
         // final Linear) -- model.py:634-638, :660-661
@@ -225,9 +229,11 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
         default: hipLaunchKernelGGL(kernel<8>, grid, dim3(256), 0, stream, args); break;                  \
     }
 
-static int g_norm_specialize = 1;  // 1 (default): mode-specialised instantiations (bit-identical; 34.4 -> 31.6 us at cfg 2, profiles/r02); 0: generic kernel
+// option norm_specialize (options.h): 1 (default): mode-specialised instantiations (bit-identical; 34.4 -> 31.6 us at cfg 2, profiles/r02); 0: generic kernel
 
-int launch_rmsnorm_mod(const NormModArgs& a, hipStream_t stream) {
+int launch_rmsnorm_mod(const NormModArgs& a_in, hipStream_t stream) {
+    NormModArgs a = a_in;
+    a.apex = lt_opt(OPT_RMSNORM_APEX);
     LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH_LIMIT, "rmsnorm_mod: d=%d must be a multiple of 8 and <= 4096", a.d);
     LT_REQUIRE(a.rows_per_batch > 0 && a.rows > 0, "rmsnorm_mod: empty input");
     LT_DISPATCH_CHUNKS(rmsnorm_mod_kernel, dim3((a.rows + 3) / 4), a);
@@ -237,6 +243,7 @@ int launch_rmsnorm_mod(const NormModArgs& a, hipStream_t stream) {
 
 int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
     GatedResArgs a = a_in;
+    a.apex = lt_opt(OPT_RMSNORM_APEX);
     LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH_LIMIT, "gated_residual_norm: d=%d must be a multiple of 8 and <= 4096", a.d);
     LT_REQUIRE(a.rows_per_batch > 0 && a.rows > 0, "gated_residual_norm: empty input");
     LT_REQUIRE(a.gate_mode == 2 || a.gate != nullptr, "gated_residual_norm: gate pointer missing");
@@ -265,7 +272,7 @@ int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
         LT_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    if (g_norm_specialize && a.gate_mode == 0 && (a.post_mode == 0 || a.post_mode == 1) && (a.next_mode == 1 || a.next_mode == 2)) {
+    if (lt_opt(OPT_NORM_SPECIALIZE) && !a.apex && a.gate_mode == 0 && (a.post_mode == 0 || a.post_mode == 1) && (a.next_mode == 1 || a.next_mode == 2)) {
         const int nch64 = ((a.d >> 3) + 63) / 64;
 #define LT_GRN_SPEC(MC, PMV, NMV) \
     hipLaunchKernelGGL((gated_residual_norm_kernel<MC, PMV, 0, NMV>), grid, dim3(256), 0, stream, a)
@@ -287,4 +294,3 @@ int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
     return 0;
 }
 
-void lt_set_norm_specialize(int v) { g_norm_specialize = v; }

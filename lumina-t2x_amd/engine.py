@@ -109,6 +109,20 @@ class DiTEngine:
                 pass
             self.handle = None
 
+    # ---- options (include/lumina_dit_debug.h) ----------------------------------------------------------
+    def set_option(self, name: str, value: Optional[int]) -> None:
+        """override one kernel-selection option for THIS engine only (``None`` drops the override: the process default set by
+        ``lt_set_option`` applies again)"""
+        v = _lib.LT_OPTION_INHERIT if value is None else int(value)
+        _lib.check(self.lib.lt_engine_set_option(self.handle, name.encode(), v), f"lt_engine_set_option({name})")
+        self._prompt.clear()  # the hoisted text K / V may depend on the option (rmsnorm_apex): prepare the conditioning again
+
+    def get_option(self, name: str) -> int:
+        """the value in effect for this engine (its override, else the process default)"""
+        out = C.c_int32(0)
+        _lib.check(self.lib.lt_engine_get_option(self.handle, name.encode(), C.byref(out)), f"lt_engine_get_option({name})")
+        return int(out.value)
+
     # ---- weights ---------------------------------------------------------------------------------
     def load_state_dict(self, state: Dict[str, torch.Tensor], skip: Iterable[str] = ()) -> None:
         """Upload every tensor of a reference-format state_dict into the engine."""

@@ -55,8 +55,15 @@ class WeightWatch:
         return out
 
     def _signature(self):
-        if getattr(self, "_watch_modules", None) is None or self._watch_epoch != _PARAM_EPOCH[0]:
-            self._watch_modules = [m for m in self.modules() if m._parameters]
+        # REMOVING a sub-module fires no registration hook (ModuleList.pop / __delitem__, `del m.sub`, edits of `_modules`): the number of
+        # children over the cached tree is the structural term that catches it - a removal shrinks its parent's `_modules`
+        stale = getattr(self, "_watch_modules", None) is None or self._watch_epoch != _PARAM_EPOCH[0]
+        if not stale and sum(len(m._modules) for m in self._watch_tree) != self._watch_children:
+            stale = True
+        if stale:
+            self._watch_tree = list(self.modules())
+            self._watch_children = sum(len(m._modules) for m in self._watch_tree)
+            self._watch_modules = [m for m in self._watch_tree if m._parameters]
             self._watch_epoch = _PARAM_EPOCH[0]
         # (inference tensors carry no version counter: in-place edits of such parameters are not seen - rebuild the model then)
         return tuple((p.data_ptr(), -1 if p.is_inference() else p._version)

@@ -10,8 +10,6 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
-    config.addinivalue_line("markers", "experimental: exercises a csrc/experimental/ kernel (skips itself unless the library was built "
-                                       "with `make EXPERIMENTAL=1`)")
 
 
 @pytest.fixture(scope="session")

@@ -35,8 +35,7 @@ def test_binding_table_matches_header_prototypes():
     """argument COUNT and coarse kind (pointer / 32-bit / 64-bit / float) of every ctypes signature against the prototype in
     include/lumina_dit.h - an ABI drift between the header and the Python binding would otherwise only show up as memory
     corruption on the GPU box."""
-    text = open(os.path.join(REPO, "include", "lumina_dit.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = _lib.header_text()
     protos = dict(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
     assert set(protos) == set(_lib._SIGNATURES)
 
@@ -164,16 +163,50 @@ def test_missing_library_fails_loudly(tmp_path):
     assert "LOUD" in out.stdout and "no CPU/PyTorch fallback" in out.stdout, out.stdout + out.stderr
 
 
-def test_every_option_lt_set_option_accepts_is_documented_in_the_header():
-    """the knobs of lt_set_option live in engine.hip's strcmp chain; include/lumina_dit.h is where an integrator reads what they do
-    (gemm_group / gemm_persist are round-1 experiment knobs the header mentions as retired)"""
-    src = open(os.path.join(REPO, "lumina-t2x_amd", "csrc", "engine.hip")).read()
-    body = src[src.index('extern "C" int lt_set_option('):]
-    body = body[:body.index("\n}\n")]
-    names = set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', body))
-    assert {"attn_q_fused", "gemm_prefetch", "graph", "attention_variant"} <= names, names
-    header = open(os.path.join(REPO, "include", "lumina_dit.h")).read()
-    retired = {"gemm_pipeline", "gemm_pp_tail", "gemm_persist"}  # accepted with value 0 only; the header names them as removed
-    missing = sorted(n for n in names - retired if f'"{n}"' not in header)
-    assert not missing, missing
-    assert all(n in header for n in retired)
+def _option_table():
+    """(name, lo, hi, default, boolean) rows of kLtOptDesc in csrc/options.hip"""
+    src = open(os.path.join(REPO, "lumina-t2x_amd", "csrc", "options.hip")).read()
+    body = src[src.index("const LtOptDesc kLtOptDesc"):]
+    body = body[:body.index("};")]
+    rows = re.findall(r'\{"([a-z_0-9]+)",\s*(-?\d+),\s*(-?\d+),\s*(-?\d+),\s*(true|false)\}', body)
+    return [(n, int(lo), int(hi), int(d), b == "true") for n, lo, hi, d, b in rows]
+
+
+def test_every_option_is_documented_in_the_debug_header_with_its_range_and_default():
+    """the options live in ONE table (csrc/options.hip); include/lumina_dit_debug.h is where a reader learns what they do.  Every
+    name must appear there with the same (range, default); the boundary header documents none of them (they are not part of the
+    drop-in surface) but declares the three option entry points."""
+    table = _option_table()
+    names = {r[0] for r in table}
+    assert {"attn_q_fused", "gemm_prefetch", "graph", "attention_variant", "gemm_splitk", "gemm_w4q_grouped", "rmsnorm_apex"} <= names, names
+    debug = open(_lib.DEBUG_HEADER_PATH).read()
+    for n, lo, hi, d, _ in table:
+        assert re.search(r'"%s"\s*\(%d\.\.%d, %d\)' % (n, lo, hi, d), debug), f'option "{n}" ({lo}..{hi}, {d}) is not documented as such in lumina_dit_debug.h'
+    enum = open(os.path.join(REPO, "lumina-t2x_amd", "csrc", "options.h")).read()
+    assert len(table) == len(re.findall(r"\bOPT_[A-Z0-9_]+", enum[enum.index("enum LtOpt"):enum.index("LT_OPT_COUNT")]))
+    for n in ("gemm_pipeline", "gemm_pp_tail", "gemm_persist"):  # accepted with value 0 only; named as removed
+        assert n in debug
+    boundary = open(_lib.HEADER_PATH).read()
+    assert all(f'"{n}"' not in boundary for n in names - {"graph"})  # (lt_graph_replays' comment names the one option it depends on)
+    assert all(fn in boundary for fn in ("lt_set_option", "lt_engine_set_option", "lt_engine_get_option"))
+
+
+def test_options_validate_ranges_and_engine_overrides_do_not_leak(lib):
+    """gemm_prefetch / gemm_splitk / gemm_w4q_grouped took any integer.  Every option now validates against the table; an
+    engine override is visible through that engine only and LT_OPTION_INHERIT drops it (no GPU needed: lt_create fails here without a
+    device, so the engine-side half runs with e = NULL -> process default, and on the GPU box in tests/test_gpu_model.py)."""
+    val = C.c_int32(-7)
+    for n, lo, hi, d, boolean in _option_table():
+        assert lib.lt_engine_get_option(None, n.encode(), C.byref(val)) == 0 and val.value == d, (n, val.value, d)
+        if not boolean:
+            assert lib.lt_set_option(n.encode(), hi + 1) != 0 and n.encode() in lib.lt_last_error(), n
+            assert lib.lt_set_option(n.encode(), lo - 1) != 0
+        assert lib.lt_engine_get_option(None, n.encode(), C.byref(val)) == 0 and val.value == d  # a refused value changes nothing
+        assert lib.lt_set_option(n.encode(), hi) == 0
+        assert lib.lt_engine_get_option(None, n.encode(), C.byref(val)) == 0 and val.value == hi
+        assert lib.lt_set_option(n.encode(), d) == 0
+    assert lib.lt_set_option(b"attention_variant", 5) != 0 and b"removed" in lib.lt_last_error()
+    assert lib.lt_set_option(b"gemm_prefetch", 2) != 0 and b"removed" in lib.lt_last_error()
+    assert lib.lt_set_option(b"gemm_persist", 0) == 0 and lib.lt_set_option(b"gemm_persist", 1) != 0
+    assert lib.lt_engine_set_option(None, b"graph", 0) != 0 and b"null engine" in lib.lt_last_error()
+    assert lib.lt_engine_get_option(None, b"no_such", C.byref(val)) != 0

@@ -515,6 +515,47 @@ def test_hip_graph_replay_is_bit_identical_to_eager_launches(golden_dir):
         assert torch.equal(a, b)
 
 
+def test_engine_options_are_per_engine_and_do_not_leak(golden_dir):
+    """SURVEY.md 8b "no hidden global state" (VERDICT r4 item 8): lt_engine_set_option overrides an option for ONE engine.  Two engines of
+    the same model in one process: A runs with the HIP graph switched off for itself only, B follows the process default - B replays,
+    A never does, results are bit-identical; dropping the override (LT_OPTION_INHERIT) hands A back to the default; a process-default
+    change moves only the engine without an override."""
+    from gpu_util import set_option
+    g, cfg = _golden(golden_dir, "nextdit_tiny")
+    a, b = _model(cfg, int(g["seed_w"])), _model(cfg, int(g["seed_w"]))
+    z, t, cap, mask = _inputs(g)
+    kw = dict(base_seqlen=16, proportional_attn=True)
+    run = lambda m: [m.forward_with_cfg(z, t, cap, mask, 4.0, **kw) for _ in range(5)][-1]
+    run(a), run(b)  # engines exist now
+    ea, eb = a._engine, b._engine
+    assert ea.get_option("graph") == 1 and eb.get_option("graph") == 1
+    ea.set_option("graph", 0)
+    assert ea.get_option("graph") == 0 and eb.get_option("graph") == 1
+    ra, rb = ea.graph_replays(), eb.graph_replays()
+    oa, ob = run(a), run(b)
+    assert ea.graph_replays() == ra and eb.graph_replays() > rb
+    assert torch.equal(oa, ob)
+    with pytest.raises(Exception, match="must be"):
+        ea.set_option("gemm_splitk", 7)  # range-checked per engine as well
+    try:
+        set_option("graph", 0)             # process default off: B (no override) stops replaying ...
+        rb = eb.graph_replays()
+        run(b)
+        assert eb.graph_replays() == rb
+        ea.set_option("graph", 1)          # ... while A's own override says on
+        ra = ea.graph_replays()
+        run(a)
+        assert ea.graph_replays() > ra
+    finally:
+        set_option("graph", 1)
+    ea.set_option("graph", None)           # back to inheriting
+    assert ea.get_option("graph") == 1
+    ea.set_option("attention_variant", 3)  # another kernel for A only: B's output is untouched, A's agrees (bit-equal by test_attention_v4_*)
+    assert eb.get_option("attention_variant") == 4
+    assert torch.equal(run(b), ob)
+    ea.set_option("attention_variant", None)
+
+
 def test_hip_graph_replay_rebuilds_the_shared_rope_table_when_keys_alternate(golden_dir):
     """the RoPE table is one buffer outside every graph.  Key A (scale_factor 1) captured and replayed, then key B
     (scale_factor 2) rebuilds the table, then key A again: its cached graph must not replay against B's table."""

@@ -522,15 +522,14 @@ def test_bench_self_launch_command_and_flop_count():
 
 
 def test_generated_attention_accessors_are_in_sync_with_their_generator(tmp_path, monkeypatch):
-    """lumina-t2x_amd/csrc/attention_v4_asm.inc (and the experimental variant's) are generated files that are committed: the
+    """lumina-t2x_amd/csrc/attention_v4*_asm.inc are generated files that are committed: the
     generator must reproduce them byte for byte"""
     import importlib.util
     import shutil
     REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for gen, rel in (("gen_attn_v4_asm.py", ("lumina-t2x_amd", "csrc", "attention_v4_asm.inc")),
                      ("gen_attn_v4_96_asm.py", ("lumina-t2x_amd", "csrc", "attention_v4_96_asm.inc")),
-                     ("gen_attn_v4_48_asm.py", ("lumina-t2x_amd", "csrc", "attention_v4_48_asm.inc")),
-                     ("gen_attn_v5_asm.py", ("lumina-t2x_amd", "csrc", "experimental", "attention_v5_asm.inc"))):
+                     ("gen_attn_v4_48_asm.py", ("lumina-t2x_amd", "csrc", "attention_v4_48_asm.inc"))):
         committed = open(os.path.join(REPO, *rel)).read()
         # run the generator against a scratch copy of the tree layout (it writes next to its own location)
         root = tmp_path / gen.replace(".py", "")
@@ -599,4 +598,17 @@ def test_weight_watch_sees_every_kind_of_weight_change():
     assert s7 != s6 and len(s7) == len(s6) - 1
     spare_leaf = copy.deepcopy(m.layers[0].attention.wq)
     m.layers[0].attention.wq = spare_leaf       # a leaf module swap deep in the tree
-    assert m._signature() != s7
+    s8 = m._signature()
+    assert s8 != s7
+    # REMOVING a sub-module fires no registration hook at all
+    n_params_last = len(list(m.layers[1].parameters()))
+    del m.layers[1]                              # ModuleList.__delitem__
+    s9 = m._signature()
+    assert s9 != s8 and len(s9) == len(s8) - n_params_last
+    n_final = len(list(m.final_layer.parameters()))
+    del m.final_layer                            # Module.__delattr__
+    s10 = m._signature()
+    assert s10 != s9 and len(s10) == len(s9) - n_final
+    n0 = len(list(m.layers[0].parameters()))
+    m.layers._modules.pop("0")                   # a direct edit of the dict
+    assert len(m._signature()) == len(s10) - n0
