@@ -278,6 +278,53 @@ def test_fulldepth_16k_fixture_is_the_pinned_restatement(golden_dir):
         assert 5e-3 < float((floor - ora).norm() / ora.norm()) < 8e-2
 
 
+TRAJ = ["full_imagenet600m_traj_euler5", "full_2b_traj_euler30", "full_2b_traj_midpoint10"]
+
+
+@pytest.mark.parametrize("name", TRAJ)
+def test_trajectory_fixture_is_a_reference_trajectory_over_the_reference_grid(golden_dir, name):
+    """oracle/make_traj_golden.py: `ref_*` = the UNMODIFIED reference Sampler.sample_ode driving the unmodified
+    model, fp32; `floor_*` = the reference's bf16 choreography with a bf16 state over the same grid.  Checked here: the stored grid is
+    the reference's (integrators.py:97-99 = odeint_oracle.time_grid), the start state is the per-NFE fixture's draw, the floor's drift
+    starts at zero, stays finite and ends where a whole trajectory of the per-NFE noise can put it, and - for the 600M model, where a CPU
+    run takes seconds - the fp32 RESTATEMENT stepped over the same grid reproduces the reference's trajectory (the restatement and the
+    restated odeint together equal the reference's sampler + model end to end)."""
+    path = os.path.join(golden_dir, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{name}.npz not generated yet (hours of CPU: oracle/make_traj_golden.py)")
+    g = np.load(path, allow_pickle=False)
+    base = _load(golden_dir, str(g["base"]))
+    assert int(g["seed_w"]) == int(base["seed_w"]) and np.array_equal(g["wsum"], base["wsum"]) and str(g["config"]) == str(base["config"])
+    n, method, shift = int(g["num_steps"]), str(g["method"]), float(g["shift"])
+    grid = OD.time_grid(n, shift if shift > 0 else None)
+    np.testing.assert_array_equal(grid.numpy(), g["grid"])
+    pts = [int(p) for p in g["points"]]
+    assert pts[-1] == n - 1 and g["ref_points"].shape[0] == len(pts) == g["floor_points"].shape[0]
+    drift = g["drift_floor"]
+    assert drift.shape == (n,) and drift[0] == 0.0 and np.isfinite(drift).all() and 5e-3 < drift[-1] < 0.25, drift
+    np.testing.assert_array_equal(g["ref_points"][-1], g["ref_final"][0])
+    np.testing.assert_array_equal(g["floor_points"][-1], g["floor_final"][0])
+    cfg = _cfg(g)
+    calls = json.loads(str(base["calls"]))
+    hw = tuple(int(v) for v in g["latent_hw"])
+    if cfg.has_text:
+        ins = synth.synth_inputs(cfg, latent_hw=hw, text_len=int(g["text_len"]), uncond_len=int(g["uncond_len"]), seed=int(g["seed_x"]), t_value=calls[0][1])
+    else:
+        ins = synth.synth_inputs(cfg, latent_hw=hw, seed=int(g["seed_x"]), t_value=calls[0][1])
+    z0 = ins[0].to(torch.bfloat16).float()[:1]
+    np.testing.assert_array_equal(z0.numpy(), g["z0"])
+    if name != "full_imagenet600m_traj_euler5":
+        return  # a 2B trajectory on the CPU takes the better part of an hour: the per-NFE pin (full_2b) + the stepping pin (solver_kat) cover it
+    from oracle import variants_oracle as V
+    sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]), streams=True)
+    kw = json.loads(str(g["model_kw"]))
+    with torch.no_grad():
+        traj = OD.odeint(lambda t, y: V.imagenet_forward_with_cfg(sd, cfg, y, torch.ones(y.size(0)) * t, ins[2], **kw), z0.repeat(2, 1, 1, 1), grid,
+                         method=method)
+    ref = torch.from_numpy(g["ref_final"])
+    assert float((traj[-1] - ref).norm() / ref.norm()) < 1e-5
+
+
 def test_fulldepth_weight_draw_is_reproducible(golden_dir):
     """the per-key PCG64 streams of synth.synth_state_dict(streams=True) reproduce the draw the fixture was made from
     (checked on the smallest full model: 1.6 B parameters, a few seconds)"""
