@@ -290,6 +290,17 @@ int lt_op_attention(const void* q_dev, const void* k_dev, const void* vt_dev, co
                     void* out_dev, const void* gate_dev, int32_t accumulate, int32_t B, int32_t H,
                     int32_t Hkv, int32_t N, int32_t Nk, int32_t Nkpad, int32_t hd, float scale,
                     int32_t k_prescaled, void* stream);
+/* The two launches of a layer of the class-conditional 600M models at <= 512 tokens (round 5, option attn_small_fused): the QKV
+ * projection on the small-M GEMM tiles, whose epilogue also leaves per-row (sum, sum of squares) of every 128-column tile in
+ * rowstat_ws ([M][ceil(3 widths / 128)] float2), then ONE kernel that does q_norm / k_norm (affine LayerNorm over the full width, fp32),
+ * 2-D RoPE, the softmax scale fold (k_scale = scale * log2 e) and bf16 rounding of q and k, the V transpose and the attention itself
+ * (Next-DiT-ImageNet/models/models.py:358-404).  A [M, K], W [H hd + 2 Hkv hd, K] (q | k | v rows), qkv [M, H hd + 2 Hkv hd] (written),
+ * LayerNorm weights / biases bf16 [H hd] / [Hkv hd], cs_table = the (cos, sin) table of lt_op_qk_norm_rope in rope_mode 1 (branch 1 is
+ * used), out [M / tokens, tokens, H hd].  head_dim 48, 64 <= tokens <= 512 and tokens % 64 == 0, widths % 128 == 0. */
+int lt_op_qkv_attention_small(const void* A_dev, const void* W_dev, void* qkv_dev, int32_t M, int32_t K, int32_t H, int32_t Hkv,
+                              int32_t tokens, int32_t hd, const void* q_ln_w, const void* q_ln_b, const void* k_ln_w,
+                              const void* k_ln_b, const void* cs_table, int32_t table_len, int32_t grid_w, float k_scale,
+                              void* rowstat_ws, void* out_dev, void* stream);
 /* self-attention + zero-init gated text cross-attention in ONE launch (hd 72 / 96, attention_variant 3 or 4; model.py:392-434):
  *   out = bf16(softmax(q k^T) v) + bf16(bf16(softmax(q tk^T + tbias) tv) * tanh(tgate[h]))
  * k and tk must already carry their softmax scale * log2(e) (lt_op_qk_norm_rope out_scale); layouts as lt_op_attention,

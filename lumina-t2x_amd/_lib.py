@@ -110,6 +110,7 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_op_qk_norm_rope": (_i32, [_vp, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _vp]),
     "lt_op_v_transpose": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lt_op_qkv_attention_small": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
     "lt_op_attention_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_attention_trace": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "lt_op_linear_small_m": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -138,7 +138,8 @@ struct lt_engine {
     // parity hooks (lt_moe_routing_*): [L][2 branches][max rows][2] expert ids, recorded from / forced onto moe_route_kernel
     int *moe_rec = nullptr, *moe_force = nullptr;
     int moe_rec_on = 0, moe_force_rows = 0, moe_rec_rows = 0;
-    float* qstat = nullptr;  // [rows][32] float2: LayerNorm partial sums of the Q columns, written by the fused QKV GEMM (GemmArgs::qstat)
+    int qstat_slots = 32;
+    float* qstat = nullptr;  // [rows][qstat_slots] float2: LayerNorm partial sums of the Q columns, written by the fused QKV GEMM (GemmArgs::qstat)
     float* qmr = nullptr;    // [rows] float2 (mean, rstd) of the Q rows, reduced from qstat by the K pass of qk_norm_rope (AttnArgs::q_stat)
     float* rope_tr = nullptr;  // the 2-D rotary table once more as [branch][freq][pos] (AttnArgs::rope_cs_t)
     // split-K workspace of the 512-row-class GEMMs (GemmArgs::splitk_*): 128 tiles = one round of half the CUs
@@ -594,6 +595,28 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             at.tk = w.ky; at.tvt = w.vty; at.tbias = e->txt_bias; at.tgate = w.gate; at.Tk = e->prompt_T; at.Tkpad = e->prompt_Tpad;
         }
         bool raw_q = false;
+        // round 5, the class-conditional 600M models at <= 512 tokens: q_norm, k_norm, RoPE, the V transpose and the attention are ONE
+        // launch behind the small-M QKV GEMM, whose epilogue leaves the LayerNorm partials (AttnSmallArgs / GemmArgs::rowstat)
+        gq.VT = nullptr;
+        const bool small_fused = lt_opt(OPT_ATTN_SMALL_FUSED) && !v.text && c.qk_norm && !v.rope_1d && !pk && !vt_epi &&
+                                 attention_small_fusable(hd, N, H, Hkv, d, dkv) && gemm_is_small_m(gq, 0);
+        gq.VT = e->vt;
+        if (small_fused) {
+            gq.VT = nullptr; gq.rowstat = e->qstat; gq.rowstat_slots = e->qstat_slots;
+            {
+                ProfScope ps(e, 0, 2.0 * M * (double)(d + 2 * dkv) * d, s, true);
+                if (launch_gemm_bf16(gq, 0, 0, s, ps.ev0(), ps.ev1())) return 1;
+            }
+            AttnSmallArgs as;
+            as.qkv = e->qkv; as.ld = e->qkvn; as.q_col0 = 0; as.k_col0 = d; as.v_col0 = d + dkv;
+            as.rowstat = e->qstat; as.slots = e->qstat_slots; as.q_slot0 = 0; as.q_nslot = d / 128; as.k_slot0 = d / 128; as.k_nslot = dkv / 128;
+            as.q_ln_w = w.q_norm_w; as.q_ln_b = w.q_norm_b; as.k_ln_w = w.k_norm_w; as.k_ln_b = w.k_norm_b; as.ln_eps = 1e-5f;
+            as.cs = e->rope; as.t = t_dev; as.watershed = 0.f; as.cs_len = e->rope_len; as.grid_w = Wp;
+            as.k_scale = sm_scale * LOG2E; as.out = e->attn; as.B = B; as.H = H; as.Hkv = Hkv; as.N = N; as.hd = hd;
+            prefetch_rider(e, &as.pf, e->attn, d, w.wo, d, e->o, d, M, d, d, 0);
+            ProfScope ps(e, 1, 4.0 * B * H * (double)N * N * hd, s);
+            if (launch_attention_small(as, s)) return 1;
+        } else
         if (vt_epi && lt_opt(OPT_QKV_FUSED_GEMM) && gemm_qkv_fusable(gq)) {
             const int bn = gemm_qkv_tile_width(gq);
             raw_q = lt_opt(OPT_ATTN_Q_FUSED) && c.qk_norm && !v.rope_1d && !pk && !regional && (fuse_text || !v.text) && attention_takes_raw_q(at) &&
@@ -609,7 +632,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             ProfScope ps(e, 0, 2.0 * M * (double)dkv * d, s, true);
             if (launch_gemm_bf16(g, 2, 0, s, ps.ev0(), ps.ev1())) return 1;
         } else if (gemm(e, e->h, d, w.wqkv, d, e->qkv, e->qkvn, M, e->qkvn, d, nullptr, 0, s)) return 1;
-        {
+        if (!small_fused) {
             ProfScope ps(e, 2, 0, s);
             QkPostArgs qa;
             qa.src = e->qkv; qa.ld_src = e->qkvn; qa.B = B; qa.N = N; qa.hd = hd; qa.rope_mode = v.rope_1d ? 2 : 1;
@@ -646,7 +669,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 if (!vt_epi && launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
             }
         }
-        if (attention(e, at, s)) return 1;
+        if (!small_fused && attention(e, at, s)) return 1;
         if (regional) {
             // compositional Next-DiT (lumina_next_compositional_generation/models/model.py:422-446): every caption attends the
             // queries of its row (regional captions -> cond row 0, last caption -> uncond row 1) into its own buffer, then one
@@ -954,7 +977,10 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     }
     {
         void* q;
-        if (dev_alloc(e, &q, M * 32 * 2 * sizeof(float))) return fail();
+        // [rows][slots] float2: 32 slots for the fused QKV launch's Q partials (GemmArgs::qstat), one per 128-column tile of the whole
+        // projection for the small-M form (GemmArgs::rowstat)
+        e->qstat_slots = std::max(32, (e->qkvn + 127) / 128);
+        if (dev_alloc(e, &q, M * (size_t)e->qstat_slots * 2 * sizeof(float))) return fail();
         e->qstat = (float*)q;
         if (dev_alloc(e, &q, M * 2 * sizeof(float))) return fail();
         e->qmr = (float*)q;
@@ -1656,6 +1682,31 @@ extern "C" int lt_op_attention_qraw(const void* qkv, int32_t ld, int32_t q_col0,
     a.rope_cs = (const float*)cs_table; a.rope_cs_t = (const float*)cs_table_t; a.rope_t = nullptr; a.rope_watershed = 0.f;  // branch 1
     a.rope_cs_len = table_len; a.rope_grid_w = grid_w;
     return launch_attention(a, (hipStream_t)stream);
+}
+
+// The small-M QKV projection with the per-tile LayerNorm partials (GemmArgs::rowstat) followed by the fused q / k post-processing +
+// attention launch (AttnSmallArgs): exactly the two launches the engine makes per layer on the attn_small_fused path.
+extern "C" int lt_op_qkv_attention_small(const void* A, const void* W, void* qkv, int32_t M, int32_t K, int32_t H, int32_t Hkv, int32_t tokens,
+                                         int32_t hd, const void* q_ln_w, const void* q_ln_b, const void* k_ln_w, const void* k_ln_b,
+                                         const void* cs_table, int32_t table_len, int32_t grid_w, float k_scale, void* rowstat_ws,
+                                         void* out, void* stream) {
+    LT_REQUIRE(A && W && qkv && q_ln_w && q_ln_b && k_ln_w && k_ln_b && cs_table && rowstat_ws && out, "lt_op_qkv_attention_small: null pointer");
+    LT_REQUIRE(H > 0 && Hkv > 0 && hd > 0 && tokens > 0 && M > 0 && M % tokens == 0, "lt_op_qkv_attention_small: bad shape");
+    const int d = H * hd, dkv = Hkv * hd, N = d + 2 * dkv;
+    LT_REQUIRE(attention_small_fusable(hd, tokens, H, Hkv, d, dkv), "lt_op_qkv_attention_small: head_dim 48, 64 <= tokens <= 512 in whole tiles, widths %% 128 == 0");
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)qkv; g.bias = nullptr; g.bias_dtype = -1; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = N;
+    LT_REQUIRE(gemm_is_small_m(g, 0), "lt_op_qkv_attention_small: %d x %d x %d does not run on the small-M tiles", M, N, K);
+    g.rowstat = (float*)rowstat_ws; g.rowstat_slots = (N + 127) / 128;  // rowstat_ws: [M][ceil(N / 128)] float2
+    if (launch_gemm_bf16(g, 0, 0, (hipStream_t)stream)) return 1;
+    AttnSmallArgs a;
+    a.qkv = (const u16*)qkv; a.ld = N; a.q_col0 = 0; a.k_col0 = d; a.v_col0 = d + dkv;
+    a.rowstat = (const float*)rowstat_ws; a.slots = g.rowstat_slots; a.q_slot0 = 0; a.q_nslot = d / 128; a.k_slot0 = d / 128; a.k_nslot = dkv / 128;
+    a.q_ln_w = (const u16*)q_ln_w; a.q_ln_b = (const u16*)q_ln_b; a.k_ln_w = (const u16*)k_ln_w; a.k_ln_b = (const u16*)k_ln_b; a.ln_eps = 1e-5f;
+    a.cs = (const float*)cs_table; a.t = nullptr; a.watershed = 0.f; a.cs_len = table_len; a.grid_w = grid_w;  // branch 1
+    a.k_scale = k_scale; a.out = (u16*)out; a.B = M / tokens; a.H = H; a.Hkv = Hkv; a.N = tokens; a.hd = hd;
+    return launch_attention_small(a, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_attention_fused(const void* q, const void* k, const void* vt, const void* tk, const void* tvt,

@@ -276,6 +276,10 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
         if ((2 * tiles <= num_cus() || lt_opt(OPT_GEMM_SPLITK) == 2) && tiles <= a.splitk_tiles) a.split_k = 2;
     }
+    if (a.rowstat) {
+        LT_REQUIRE((k == GK_S128 || k == GK_S64) && epilogue == 0, "gemm: rowstat is written by the small-M tiles' plain epilogue only (this problem runs %s)", kGemmKernelName[k]);
+        LT_REQUIRE(a.rowstat_slots >= (a.N + 127) / 128, "gemm: rowstat_slots %d < %d column tiles", a.rowstat_slots, (a.N + 127) / 128);
+    }
     if (a.a_row_map) {  // gather-on-load lives in the ping-pong kernels' staging (the grouped SwiGLU GEMM of the MoE layers)
         LT_REQUIRE(k == GK_PP256_SWIGLU || k == GK_PP256 || k == GK_S128 || k == GK_S128_SWIGLU || k == GK_S64 || k == GK_W4Q256_GROUPED ||
                    k == GK_W4Q256_SWIGLU_GROUPED,
@@ -319,6 +323,11 @@ __global__ __launch_bounds__(256) void gemm_prefetch_w_kernel(PrefetchRider r) {
 // lt_set_option "gemm_prefetch": 3 (default) = the W panels of the 512-row-class GEMMs are read by rider workgroups of the row kernel
 // that precedes the GEMM (cfg 1 -1.6 %, cfg 5 -1..3 % on a fast-class box, -6.5 % on a slow one); 0 = off; 1 = a prefetch launch right in
 // front of every small-M GEMM (same stream: the upper bound experiment); 2 = on a side stream beside the preceding kernel (loses 33 %)
+
+bool gemm_is_small_m(const GemmArgs& a, int epilogue) {
+    const GemmKernel k = choose(a, epilogue, 0);
+    return k == GK_S64 || k == GK_S128;
+}
 
 bool gemm_prefetch_rider(const GemmArgs& a0, int epilogue, PrefetchRider* r) {
     GemmArgs a = a0;

@@ -763,6 +763,42 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     }
     store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
 
+    if constexpr (MODE == 1 && KS == 4 && EPI == 0 && !TRACE) {
+        // GemmArgs::rowstat (round 5, the 512-row-class QKV projection): per row and per BN-column tile, (sum, sum of squares) of the
+        // tile's bf16-ROUNDED outputs -> rowstat[row][n0 / BN].  The fused small-N attention kernel reduces the tiles of the Q (or K)
+        // columns to the LayerNorm statistics of q_norm / k_norm itself, so no q / k post-processing launch runs in between.
+        // v_dot2_f32_bf16 of each packed output pair with (1, 1) and with itself; row halves meet through lane ^ 32, the WN waves of a
+        // row through the (idle) slab ring.  Columns past N are zero accumulators (their W rows read as zero) and add nothing.
+        if (p.rowstat) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+            const bf16x2_ ones = __builtin_bit_cast(bf16x2_, 0x3F803F80u);
+            __syncthreads();  // every wave is past its last fragment read: the ring becomes the exchange buffer
+            float2* ex = (float2*)smem;  // [WN][BM]
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bf16x2_ v = __builtin_bit_cast(bf16x2_, pack2bf_pk(acc[mt][nt][2 * j], acc[mt][nt][2 * j + 1]));
+                        s1 = __builtin_amdgcn_fdot2_f32_bf16(v, ones, s1, false);
+                        s2 = __builtin_amdgcn_fdot2_f32_bf16(v, v, s2, false);
+                    }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (hi == 0) ex[wn * BM + wm * MT * 32 + mt * 32 + l31] = float2{s1, s2};
+            }
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.M) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) { s1 += ex[w * BM + tid].x; s2 += ex[w * BM + tid].y; }
+                ((float2*)p.rowstat)[(size_t)(m0 + tid) * p.rowstat_slots + tn] = float2{s1, s2};
+            }
+        }
+    }
+
     if constexpr (TRACE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores acknowledged
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();

@@ -44,6 +44,11 @@ struct GemmArgs {
     // prologue reduces the slots to the row's mean / rstd and applies q_norm + RoPE itself (AttnArgs::q_raw): Q is never re-written.
     float* qstat = nullptr;
     int qstat_cols = 0, qstat_slots = 0;
+    // round 5 (small-M tiles of gemm_bf16_pp, plain epilogue): rowstat[row][column tile of 128] = (sum, sum of squares) of that tile's
+    // bf16-rounded outputs of the row (float2; rowstat_slots = ceil(N / 128) per row) - the LayerNorm partials the fused small-N
+    // attention kernel (AttnSmallArgs) reduces; the launcher refuses it on any other kernel
+    float* rowstat = nullptr;
+    int rowstat_slots = 0;
     int group_rows = 0;  // experiment knob (lt_set_option "gemm_group"): tile rows per group of the XCD-aware tile order (0 = 4)
     int stagger = 0;  // experiment knob of the 4-wave kernels (lt_set_option "gemm_stagger"), filled by the launcher
 };
@@ -59,6 +64,7 @@ struct PrefetchRider {
     int first = 0x7fffffff, blocks = 0;
 };
 bool gemm_prefetch_rider(const GemmArgs& a, int epilogue, PrefetchRider* r);
+bool gemm_is_small_m(const GemmArgs& a, int epilogue);  // launch_gemm_bf16 would run this problem on the 128 x 128 / 64 x 128 small-M tiles (GemmArgs::rowstat needs them)
 int launch_gemm_prefetch_w(const GemmArgs& a, int epilogue, hipStream_t stream);  // experiment: W panels of a small-M GEMM -> the L2 of the XCDs that will stage them
 bool gemm_qkv_fusable(const GemmArgs& a);
 int gemm_qkv_tile_width(const GemmArgs& a);  // 288 / 256 (the fused launch's tile width), 0 = not fusable  // epilogue 3 can take this problem (else: one plain launch for Q | K + one V^T launch)
@@ -186,6 +192,27 @@ struct AttnArgs {
 int launch_region_text_combine(u16* out, const u16* txt, const u16* gate, int Y, int N, int H, int hd, int Hp, int Wp,
                                int h_split, int w_split, hipStream_t stream);
 int launch_attention(const AttnArgs& a, hipStream_t stream);
+// Fused q / k post-processing + V^T staging + attention for short sequences (attention_small.hip, round 5): one launch instead of
+// qkv_post + attention at the 600M class-conditional models' 256 tokens.  Reads the QKV projection's row-major output and the per-tile
+// LayerNorm partials its GEMM left (GemmArgs::rowstat).
+struct AttnSmallArgs {
+    const u16* qkv;        // [B * N, ld] bf16: q | k | v column blocks as the GEMM wrote them
+    int ld, q_col0, k_col0, v_col0;
+    const float* rowstat;  // [B * N][slots] float2 (sum, sum of squares) per 128-column tile of the projection
+    int slots, q_slot0, q_nslot, k_slot0, k_nslot;
+    const u16 *q_ln_w, *q_ln_b, *k_ln_w, *k_ln_b;  // affine LayerNorm over the full q / k width (bf16)
+    float ln_eps;
+    const float* cs;       // (cos, sin) table of QkPostArgs::cs, 2-D mode: [branch][pos][hd / 4]
+    const float* t;        // device timesteps (branch = t[0] < watershed ? 0 : 1) or null (branch 1)
+    float watershed;
+    int cs_len, grid_w;
+    float k_scale;         // softmax scale * log2(e), folded into K's one bf16 rounding
+    u16* out;              // [B, N, H * hd]
+    int B, H, Hkv, N, hd;
+    PrefetchRider pf;      // weight panels of the GEMM that follows (the O projection), read by extra workgroups of this launch
+};
+bool attention_small_fusable(int hd, int N, int H, int Hkv, int q_width, int k_width);
+int launch_attention_small(const AttnSmallArgs& a, hipStream_t stream);
 int launch_attention_v4(const AttnArgs& a, hipStream_t stream);  // hd 72, 4 waves x 64 query rows (attention_v4.hip)
 int launch_attention_v4_hd48(const AttnArgs& a, hipStream_t stream);  // hd 48, the same structure, softmax-bound (attention_v4_48.hip)
 int launch_attention_v4_hd96(const AttnArgs& a, hipStream_t stream);  // hd 96, the same structure without pad slots (attention_v4_96.hip)

@@ -13,11 +13,25 @@ not vendored).  Here:
   transport.py:349) is torchdiffeq's adaptive Dormand-Prince 5(4) solver, restated below: the step-size controller
   lives on the host (one scalar device->host read per attempted step is inherent to adaptive stepping), every
   model evaluation still runs on the engine through the model callable.  PARITY UNPINNED like the fixed-grid
-  solvers (torchdiffeq is neither vendored nor installed); anchored on closed-form ODEs in the tests.
+  solvers (torchdiffeq is neither vendored nor installed); anchored on closed-form ODEs in the tests;
+* the other tableau-defined methods ``--solver`` can name (the reference forwards ANY torchdiffeq method string,
+  ``lumina_next_t2i/sample.py:77`` -> ``integrators.py:115``): fixed-grid ``heun2`` / ``heun3`` and adaptive ``bosh3`` /
+  ``fehlberg2`` / ``adaptive_heun`` run on the same two host loops with their Butcher tableaus (restated from torchdiffeq 0.2.x,
+  unpinned like the rest).  ``dopri8``, the Adams multistep family and ``scipy_solver`` are NOT built and say so by name.
 """
 import torch as th
 
-FIXED_GRID_METHODS = ("euler", "midpoint", "rk4")
+FIXED_GRID_METHODS = ("euler", "midpoint", "rk4")           # also built inside the engine (lt_sample_ode): one C-ABI call per trajectory
+HOST_FIXED_GRID_METHODS = ("heun2", "heun3")                  # fixed grid, host loop only
+ADAPTIVE_METHODS = ("dopri5", "bosh3", "fehlberg2", "adaptive_heun")
+NOT_BUILT_METHODS = ("dopri8", "explicit_adams", "implicit_adams", "fixed_adams", "scipy_solver")
+ALL_METHODS = FIXED_GRID_METHODS + HOST_FIXED_GRID_METHODS + ADAPTIVE_METHODS
+
+
+def _unknown_method(method):
+    if method in NOT_BUILT_METHODS:
+        return NotImplementedError(f"ODE method '{method}' of torchdiffeq is not built here (built: {', '.join(ALL_METHODS)})")
+    return ValueError(f"unknown ODE method '{method}' (torchdiffeq names built here: {', '.join(ALL_METHODS)})")
 
 
 def _call(func, t, y):
@@ -32,10 +46,11 @@ def fixed_grid_odeint(func, y0, t, method="euler"):
     euler    y1 = y0 + dt f(t0, y0)
     midpoint y1 = y0 + dt f(t0 + dt/2, y0 + dt/2 f(t0, y0))
     rk4      3/8-rule variant (rk4_alt_step_func): k2 at t0+dt/3, k3 at t0+2dt/3, k4 at t1, weights 1/8 (1,3,3,1)
+    heun2    y1 = y0 + dt/2 (f(t0, y0) + f(t1, y0 + dt f(t0, y0)))                                  [tableau alpha 1 | 1 | 1/2 1/2]
+    heun3    k2 at t0+dt/3 (y0 + dt/3 k1), k3 at t0+2dt/3 (y0 + 2dt/3 k2), y1 = y0 + dt (k1 + 3 k3) / 4  [1/3 2/3 | 1/3; 0 2/3 | 1/4 0 3/4]
     """
-    if method not in FIXED_GRID_METHODS:
-        raise NotImplementedError(
-            f"ODE method '{method}': built solvers are {FIXED_GRID_METHODS} (fixed grid) and 'dopri5' (adaptive)")
+    if method not in FIXED_GRID_METHODS + HOST_FIXED_GRID_METHODS:
+        raise _unknown_method(method)
     out = th.empty((len(t),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
     out[0] = y0
     y = y0
@@ -49,6 +64,13 @@ def fixed_grid_odeint(func, y0, t, method="euler"):
         elif method == "midpoint":
             half = 0.5 * dt
             dy = dt * _call(func, t0 + half, y + k1 * half)
+        elif method == "heun2":
+            k2 = _call(func, t1, y + dt * k1)
+            dy = dt * (k1 * 0.5 + k2 * 0.5)
+        elif method == "heun3":
+            k2 = _call(func, t0 + dt * third, y + dt * k1 * third)
+            k3 = _call(func, t0 + dt * two_thirds, y + dt * k2 * two_thirds)
+            dy = dt * (k1 * 0.25 + k3 * 0.75)
         else:
             k2 = _call(func, t0 + dt * third, y + dt * k1 * third)
             k3 = _call(func, t0 + dt * two_thirds, y + dt * (k2 - k1 * third))
@@ -76,18 +98,40 @@ _DP_C_MID = (6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -
              187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2)
 
 
+# (alpha, beta, c_sol, c_err, c_mid, order) of torchdiffeq's other adaptive Runge-Kutta solvers (bosh3.py, fehlberg2.py, adaptive_heun.py)
+_TABLEAUS = {
+    "dopri5": (_DP_ALPHA, _DP_BETA, _DP_C_SOL, _DP_C_ERR, _DP_C_MID, 5),
+    "bosh3": ((1 / 2, 3 / 4, 1.0), ((1 / 2,), (0.0, 3 / 4), (2 / 9, 1 / 3, 4 / 9)), (2 / 9, 1 / 3, 4 / 9, 0.0),
+              (2 / 9 - 7 / 24, 1 / 3 - 1 / 4, 4 / 9 - 1 / 3, -1 / 8), (0.0, 0.5, 0.0, 0.0), 3),
+    "fehlberg2": ((1 / 2, 1.0), ((1 / 2,), (1 / 256, 255 / 256)), (1 / 512, 255 / 256, 1 / 512), (-1 / 512, 0.0, 1 / 512), (0.0, 0.5, 0.0), 2),
+    "adaptive_heun": ((1.0,), ((1.0,),), (0.5, 0.5), (0.5, -0.5), (0.5, 0.0), 2),
+}
+
+
 def _rms(x):
     return x.float().pow(2).mean().sqrt()
 
 
-def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 1, stats=None, norm=None):
-    """torchdiffeq.odeint(func, y0, t, rtol=rtol, atol=atol, method="dopri5"): solution at every point of ``t`` (dense
-    output through the 4th-order interpolant), steps chosen by the embedded error estimate.
+def dopri5_odeint(func, y0, t, **kw):
+    """torchdiffeq.odeint(..., method="dopri5") - see adaptive_odeint"""
+    return adaptive_odeint(func, y0, t, method="dopri5", **kw)
+
+
+def adaptive_odeint(func, y0, t, *, method="dopri5", rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 1, stats=None, norm=None):
+    """torchdiffeq.odeint(func, y0, t, rtol=rtol, atol=atol, method=...) for the adaptive Runge-Kutta family (rk_common.
+    RKAdaptiveStepsizeODESolver): solution at every point of ``t`` (dense output through the quartic fitted to y0, y1, a mid-point
+    value and the end slopes), steps chosen by the embedded error estimate.  ``method``: dopri5 (5(4), FSAL), bosh3 (3(2), FSAL),
+    fehlberg2 (2(1)), adaptive_heun (2(1)); like torchdiffeq, the last stage's slope stands in for f(t1, y1) also where the tableau is
+    not first-same-as-last.
 
     Follows torchdiffeq's controller: initial step from Hairer's heuristic (``_select_initial_step``), error ratio =
     rms(err / (atol + rtol max(|y0|, |y1|))), accept if <= 1, next step = dt * min(10, max(0.9 ratio^-1/5, 0.2 or 1)).
     ``stats`` (optional dict) receives the number of function evaluations and accepted / rejected steps; ``norm`` replaces the
     rms norm of the controller (tuple states use torchdiffeq's mixed norm, see ``tuple_odeint``)."""
+    if method not in _TABLEAUS:
+        raise _unknown_method(method)
+    ALPHA, BETA, C_SOL, C_ERR, C_MID, order = _TABLEAUS[method]
+    fsal = C_SOL[-1] == 0.0 and tuple(C_SOL[:-1]) == tuple(BETA[-1])
     nrm = norm if norm is not None else _rms
     t = t.to(device=y0.device)
     tdt = t.dtype
@@ -99,7 +143,7 @@ def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 
     t0 = t[0]
     f0 = f(t0, y0)
     nfe += 1
-    # _select_initial_step(func, t0, y0, order = 4, ...)
+    # _select_initial_step(func, t0, y0, order - 1, ...)
     scale = atol + y0.abs() * rtol
     d0, d1 = nrm(y0 / scale), nrm(f0 / scale)
     h0 = 0.01 * d0 / d1 if (float(d0) >= 1e-5 and float(d1) >= 1e-5) else th.tensor(1e-6, device=y0.device)
@@ -110,7 +154,7 @@ def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 
     if float(d1) <= 1e-15 and float(d2) <= 1e-15:
         h1 = th.max(th.tensor(1e-6, dtype=tdt, device=y0.device), h0 * 1e-3)
     else:
-        h1 = (0.01 / th.max(d1, d2)) ** (1.0 / 5.0)
+        h1 = (0.01 / th.max(d1, d2)) ** (1.0 / float(order))
     dt = th.min(100 * h0, h1.to(tdt)).to(tdt)
 
     out = th.empty((len(t),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
@@ -129,7 +173,7 @@ def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 
             dty = dt.to(y.dtype)
             k = [fy]
             yi = y
-            for alpha, beta in zip(_DP_ALPHA, _DP_BETA):
+            for alpha, beta in zip(ALPHA, BETA):
                 ti = t1 if alpha == 1.0 else tcur + alpha * dt
                 acc = k[0] * beta[0]
                 for kj, bj in zip(k[1:], beta[1:]):
@@ -138,17 +182,25 @@ def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 
                 yi = y + dty * acc
                 k.append(f(ti, yi))
                 nfe += 1
-            y1, f_1 = yi, k[-1]  # FSAL: the last stage is the 5th-order solution
-            err = k[0] * _DP_C_ERR[0]
-            for kj, cj in zip(k[1:], _DP_C_ERR[1:]):
+            f_1 = k[-1]
+            if fsal:  # the last stage IS the solution (dopri5, bosh3)
+                y1 = yi
+            else:
+                sol = k[0] * C_SOL[0]
+                for kj, cj in zip(k[1:], C_SOL[1:]):
+                    if cj != 0.0:
+                        sol = sol + kj * cj
+                y1 = y + dty * sol
+            err = k[0] * C_ERR[0]
+            for kj, cj in zip(k[1:], C_ERR[1:]):
                 if cj != 0.0:
                     err = err + kj * cj
             err = dty * err
             tol = atol + rtol * th.max(y.abs(), y1.abs())
             ratio = float(nrm(err / tol))
             if ratio <= 1.0:  # accept: dense-output coefficients of this step, then move on
-                mid = k[0] * _DP_C_MID[0]
-                for kj, cj in zip(k[1:], _DP_C_MID[1:]):
+                mid = k[0] * C_MID[0]
+                for kj, cj in zip(k[1:], C_MID[1:]):
                     if cj != 0.0:
                         mid = mid + kj * cj
                 y_mid = y + dty * mid
@@ -160,12 +212,12 @@ def dopri5_odeint(func, y0, t, *, rtol=1e-3, atol=1e-6, max_num_steps=2 ** 31 - 
                 accepted += 1
             else:
                 rejected += 1
-            # _optimal_step_size(dt, ratio, safety 0.9, ifactor 10, dfactor 0.2, order 5)
+            # _optimal_step_size(dt, ratio, safety 0.9, ifactor 10, dfactor 0.2, order)
             if ratio == 0.0:
                 dt = dt * 10.0
             else:
                 dfactor = 1.0 if ratio < 1.0 else 0.2
-                dt = dt * min(10.0, max(0.9 / ratio ** 0.2, dfactor))
+                dt = dt * min(10.0, max(0.9 / ratio ** (1.0 / order), dfactor))
         # _interp_evaluate(coeffs, tprev, tcur, next_t)
         x = ((next_t - tprev) / (tcur - tprev)).to(y.dtype)
         total = coeffs[0] + x * coeffs[1]
@@ -201,8 +253,8 @@ def tuple_odeint(func, y0, t, *, method, rtol=1e-3, atol=1e-6):
         return th.stack([_rms(c) for c in split(flat)]).max()
 
     flat0 = th.cat([y.reshape(-1) for y in y0])
-    if method == "dopri5":
-        sol = dopri5_odeint(f, flat0, t, rtol=rtol, atol=atol, norm=mixed_norm)
+    if method in ADAPTIVE_METHODS:
+        sol = adaptive_odeint(f, flat0, t, method=method, rtol=rtol, atol=atol, norm=mixed_norm)
     else:
         sol = fixed_grid_odeint(f, flat0, t, method=method)
     return split(sol, (len(t),))
@@ -255,8 +307,8 @@ class ode:
             tvec = th.ones(y.size(0)).to(device) * t  # fp32 [B] (reference integrators.py:108)
             return self.drift(y, tvec, model, **model_kwargs)
 
-        if self.sampler_type == "dopri5":
-            return dopri5_odeint(_fn, x, self.t.to(device), rtol=self.rtol, atol=self.atol)
+        if self.sampler_type in ADAPTIVE_METHODS:
+            return adaptive_odeint(_fn, x, self.t.to(device), method=self.sampler_type, rtol=self.rtol, atol=self.atol)
         return fixed_grid_odeint(_fn, x, self.t.to(device), method=self.sampler_type)
 
     def _sample_on_engine(self, x, target, kw):

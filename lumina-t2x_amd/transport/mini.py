@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import torch as th
 
-from .integrators import FIXED_GRID_METHODS, _engine_target, dopri5_odeint, fixed_grid_odeint
+from .integrators import ADAPTIVE_METHODS, FIXED_GRID_METHODS, _engine_target, adaptive_odeint, fixed_grid_odeint
 
 
 class ODE:
@@ -42,6 +42,6 @@ class ODE:
             tvec = th.ones(y.size(0)).to(device) * t  # transport.py:87
             return model(y, tvec, **model_kwargs)
 
-        if self.sampler_type == "dopri5":
-            return dopri5_odeint(_fn, x, self.t.to(device))
+        if self.sampler_type in ADAPTIVE_METHODS:
+            return adaptive_odeint(_fn, x, self.t.to(device), method=self.sampler_type)
         return fixed_grid_odeint(_fn, x, self.t.to(device), method=self.sampler_type)

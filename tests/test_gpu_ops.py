@@ -964,3 +964,67 @@ def test_qkv_qstat_then_attention_qraw_equal_the_separate_passes(B, tokens, H, H
                                   B, H, Hkv, tokens, tokens, hd, stream()), "attention_qraw (two-pass statistics)")
     torch.cuda.synchronize()
     assert rel_l2(out2, out0) < 1e-3, rel_l2(out2, out0)
+
+
+@pytest.mark.parametrize("B,tokens,H,Hkv,K,grid_w", [(2, 256, 32, 32, 1536, 16),   # the 600M ImageNet / MoE models at 256^2: 512 rows, 128 x 128 tiles
+                                                      (2, 64, 8, 8, 384, 8),        # the tiny test models: 64 x 128 tiles, one key tile
+                                                      (1, 512, 16, 8, 768, 32),     # the longest sequence the kernel keeps resident, GQA
+                                                      (3, 192, 16, 8, 384, 12)])    # three key tiles, odd batch x heads still a multiple of 8, two query heads per kv head
+def test_qkv_rowstat_then_fused_small_attention_equals_the_separate_passes(B, tokens, H, Hkv, K, grid_w):
+    """round 5, the attn_small_fused path of the engine at the op level (Next-DiT-ImageNet/models/models.py:358-404), head_dim 48:
+    (1) the small-M QKV GEMM with GemmArgs::rowstat writes C bit-identically to the plain launch and leaves, per row and 128-column
+        tile, (sum, sum of squares) of the bf16-rounded outputs - checked against torch on every tile;
+    (2) ONE kernel then does q_norm, k_norm, RoPE, scale fold, V transpose and attention: against the three separate passes
+        (lt_op_qk_norm_rope x 2, lt_op_v_transpose, lt_op_attention) up to the bf16 ulps the two forms of the row variance move, and
+        against an fp32 softmax attention on torch-made q / k."""
+    from oracle import nextdit_oracle as O
+    hd = 48
+    d, dkv = H * hd, Hkv * hd
+    M, Nall = B * tokens, d + 2 * dkv
+    g = torch.Generator().manual_seed(tokens * 3 + H + Hkv)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(Nall, K, generator=g) / math.sqrt(K))
+    W[:d] += bf(0.02 * torch.ones(1, K))  # a row mean that is not negligible beside the spread: exercises E[x^2] - mean^2
+    qw, qb = bf(1 + 0.1 * torch.randn(d, generator=g)), bf(0.1 * torch.randn(d, generator=g))
+    kw, kb = bf(1 + 0.1 * torch.randn(dkv, generator=g)), bf(0.1 * torch.randn(dkv, generator=g))
+    table = torch.empty(2, 384, hd // 4, 2, device="cuda", dtype=torch.float32)
+    ok(lib().lt_op_rope_table_2d(P(table), 384, hd, 10000.0, 1.0, stream()))
+    scale = 1 / math.sqrt(hd)
+    kscale = scale * 1.4426950408889634
+    # the separate passes
+    C0 = _gemm(A, W)
+    q0 = torch.empty(B, H, tokens, hd, device="cuda", dtype=torch.bfloat16)
+    k0 = torch.empty(B, Hkv, tokens, hd, device="cuda", dtype=torch.bfloat16)
+    vt0 = torch.empty(B, Hkv, hd, tokens, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_qk_norm_rope(P(C0), Nall, 0, P(qw), P(qb), 1e-5, P(q0), B, tokens, H, hd, 1, P(table[1]), grid_w, 1.0, stream()))
+    ok(lib().lt_op_qk_norm_rope(P(C0), Nall, d, P(kw), P(kb), 1e-5, P(k0), B, tokens, Hkv, hd, 1, P(table[1]), grid_w, kscale, stream()))
+    ok(lib().lt_op_v_transpose(P(C0), Nall, d + dkv, P(vt0), B, tokens, tokens, Hkv, hd, stream()))
+    out0 = torch.full((B, tokens, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_attention(P(q0), P(k0), P(vt0), None, P(out0), None, 0, B, H, Hkv, tokens, tokens, tokens, hd, scale, 1, stream()))
+    # the fused path
+    slots = (Nall + 127) // 128
+    C1 = torch.full((M, Nall), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ws = torch.full((M, slots, 2), float("nan"), device="cuda", dtype=torch.float32)
+    out1 = torch.full_like(out0, float("nan"))
+    ok(lib().lt_op_qkv_attention_small(P(A), P(W), P(C1), M, K, H, Hkv, tokens, hd, P(qw), P(qb), P(kw), P(kb), P(table), 384, grid_w, kscale,
+                                       P(ws), P(out1), stream()), "qkv_attention_small")
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C0)
+    x = C0.float().view(M, -1)
+    pad = slots * 128 - Nall
+    xt = F.pad(x, (0, pad)).view(M, slots, 128)
+    assert not torch.isnan(ws).any()
+    assert (ws[..., 0] - xt.sum(-1)).abs().max() < 2e-3 * xt.abs().sum(-1).max()
+    assert ((ws[..., 1] - xt.pow(2).sum(-1)).abs() / xt.pow(2).sum(-1).clamp_min(1e-3)).max() < 1e-5
+    assert not torch.isnan(out1.float()).any()
+    assert rel_l2(out1, out0) < 3e-3, rel_l2(out1, out0)
+    # fp32 reference: torch LayerNorm + the oracle's rotary on the bf16 projection, one bf16 rounding of q and k, exact softmax
+    xc = C0.float().cpu()
+    Hp = tokens // grid_w
+    freqs = O.rope_table(hd, 384)[:Hp, :grid_w].flatten(0, 1).unsqueeze(0)
+    qr = r16(O.apply_rotary(F.layer_norm(xc[:, :d], (d,), qw.float().cpu(), qb.float().cpu(), 1e-5).view(B, tokens, H, hd), freqs)).permute(0, 2, 1, 3)
+    kr = r16(O.apply_rotary(F.layer_norm(xc[:, d:d + dkv], (dkv,), kw.float().cpu(), kb.float().cpu(), 1e-5).view(B, tokens, Hkv, hd), freqs)).permute(0, 2, 1, 3)
+    vr = xc[:, d + dkv:].view(B, tokens, Hkv, hd).permute(0, 2, 1, 3)
+    ref = _attn_ref(qr, kr, vr, scale).permute(0, 2, 1, 3).reshape(B, tokens, d)
+    assert rel_l2(out1, ref) < 8e-3, rel_l2(out1, ref)
+    assert rel_l2(out0, ref) < 8e-3
