@@ -58,7 +58,7 @@ int lt_opt_validate(int id, int* value) {
     const LtOptDesc& d = kLtOptDesc[id];
     if (d.boolean) { *value = *value != 0; return 0; }
     if (id == OPT_ATTENTION_VARIANT && *value == 5) {
-        lt_set_error("attention_variant 5 (PV on 16x16x32 MFMAs) was a study kernel of csrc/experimental/, removed in round 5 (it lost on issue slots, DESIGN.md)");
+        lt_set_error("attention_variant 5 (PV on 16x16x32 MFMAs) was a study kernel of csrc/experimental/, removed in round 5 (it lost on issue slots, NOTEBOOK.md 5.8)");
         return 2;
     }
     if (id == OPT_GEMM_PREFETCH && *value == 2) {
