@@ -134,6 +134,7 @@ struct lt_engine {
     int E = 0, moe_tiles = 0;
     int moe_mode = 0;  // 0: time + space MoE per block (models2.py), 1: time-routed MoE only (models.py), 2: token-routed only (models1.py)
     u16 *moe_us = nullptr, *moe_ys = nullptr, *moe_logits = nullptr, *moe_wts = nullptr;
+    u16* gate_t_all = nullptr;  // [L * E, A]: every layer's time-router weight, contiguous (LayerW::gate_t point into it)
     int *moe_sel = nullptr, *moe_pos = nullptr, *moe_tile_expert = nullptr, *moe_src = nullptr;
     // parity hooks (lt_moe_routing_*): [L][2 branches][max rows][2] expert ids, recorded from / forced onto moe_route_kernel
     int *moe_rec = nullptr, *moe_force = nullptr;
@@ -397,7 +398,7 @@ int ensure_rope(lt_engine* e, const lt_step_args* a, hipStream_t s) {
 // one MoE feed-forward (branch 0 = TimeMoeLayer on the timestep embedding, 1 = SpaceMoeLayer on the tokens;
 // models2.py:451-506): e->h -> e->o
 int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B, hipStream_t s) {
-    const int d = e->d, F = e->F, A = e->A;
+    const int d = e->d, F = e->F;
     MoeArgs m;
     m.x = e->h; m.rows = M; m.rows_per_sample = N; m.d = d; m.E = e->E;
     // tile bound of THIS call's row count, not of the engine's capacity: a capacity-sized launch would be mostly padding
@@ -409,9 +410,9 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
     m.gate_w = nullptr; m.sample_logits = nullptr; m.forced = nullptr;
     {
         ProfScope ps(e, 2, 0, s);
-        if (branch == 0) {  // gate(cond) with cond = t_embedder(t) (models2.py:462, :950-951)
-            if (launch_linear_small_m(e->temb, w.gate_t, nullptr, e->moe_logits, B, e->E, A, 0, s)) return 1;
-            m.sample_logits = e->moe_logits;
+        if (branch == 0) {  // gate(cond) with cond = t_embedder(t) (models2.py:462, :950-951): computed for all layers at once, run_forward
+            m.sample_logits = e->moe_logits + (size_t)layer * e->E;
+            m.sample_ld = e->L * e->E;
         } else {
             m.gate_w = w.gate_s;
         }
@@ -548,6 +549,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         if (launch_timestep_features(t_dev, 0, e->tfeat, B, 256, s)) return 1;
         if (launch_linear_small_m(e->tfeat, e->t0_w, e->t0_b, e->t1, B, A, 256, 0, s)) return 1;
         if (launch_linear_small_m(e->t1, e->t2_w, e->t2_b, e->temb, B, A, A, 1, s)) return 1;
+        if (e->gate_t_all && launch_linear_small_m(e->temb, e->gate_t_all, nullptr, e->moe_logits, B, L * e->E, A, 0, s)) return 1;  // every layer's time-router logits
         if (launch_add_bf16(e->temb, e->cap_emb, e->adaln_in, (long long)B * A, s)) return 1;
         if (launch_linear_small_m(e->adaln_in, e->adaln_w, e->adaln_b, e->mod, B, e->ld_mod, A, 1, s)) return 1;
         // once per (sample, channel) instead of once per token inside the row kernels: tanh of the gate chunks (where the
@@ -897,7 +899,13 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         if (e->E == 0) { A16(w.w13, (size_t)2 * F * d); A16(w.w2, (size_t)d * F); }
         else {
             const size_t E_ = e->E;
-            if (e->moe_mode != 2) { A16(w.w13_t, E_ * 2 * F * d); A16(w.w2_t, E_ * d * F); A16(w.gate_t, E_ * A); }
+            if (e->moe_mode != 2) {
+                A16(w.w13_t, E_ * 2 * F * d); A16(w.w2_t, E_ * d * F);
+                // the time routers of ALL layers are one [L * E, A] matrix: their logits depend on the timestep embedding only, so one GEMV
+                // per evaluation computes every layer's (run_forward; 16 launches of 12 us each at the 600M model before round 5)
+                if (l == 0) A16(e->gate_t_all, (size_t)L * E_ * A);
+                w.gate_t = e->gate_t_all + (size_t)l * E_ * A;
+            }
             if (e->moe_mode != 1) { A16(w.w13_s, E_ * 2 * F * d); A16(w.w2_s, E_ * d * F); A16(w.gate_s, E_ * d); }
             A16(w.norm_time, d); A16(w.norm_space, d);
         }
@@ -964,7 +972,7 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         }
         e->moe_tiles = (int)((2 * M + (size_t)e->E * 255 + 255) / 256);
         const size_t P = (size_t)e->moe_tiles * 256;
-        A16(e->moe_us, P * F); A16(e->moe_ys, P * d); A16(e->moe_logits, Bm * e->E); A16(e->moe_wts, 2 * M);
+        A16(e->moe_us, P * F); A16(e->moe_ys, P * d); A16(e->moe_logits, Bm * e->E * (size_t)L); A16(e->moe_wts, 2 * M);
         void* q;
         if (dev_alloc(e, &q, (2 * M + 4) * sizeof(int))) return fail();  // (+4: moe_plan reads / writes whole 16-byte quads)
         e->moe_sel = (int*)q;

@@ -227,6 +227,8 @@ struct MoeArgs {
     const u16* gate_w;         // space router weight [E, d] (per-token logits) or null
     const u16* sample_logits;  // time router logits [B, E] bf16 (every token of a sample shares them) or null; with them the plan
                                // kernel routes as well (no separate route launch)
+    int sample_ld = 0;         // row stride of sample_logits in elements (0 = E): the engine computes every layer's time-router logits in ONE
+                               // GEMV per evaluation ([B, L * E]) and hands each layer its E columns
     const int* forced;         // [rows, 2] expert ids that replace the top-2 choice (parity hook, lt_moe_routing_force) or null
     int rows, rows_per_sample, d, E;
     int* sel;                  // [rows, 2] selected experts, ascending expert id (= the reference's accumulation order)

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void moe_route_kernel(MoeArgs p) {
     if (p.sample_logits) {
         const int b = row / p.rows_per_sample;
 #pragma unroll
-        for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[b * p.E + e]) : -INFINITY;
+        for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[b * p.sample_ld + e]) : -INFINITY;
     } else {
         float acc[MAX_E];
 #pragma unroll
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
             if (b != cached_b || p.forced) {  // every token of a sample shares the two experts (unless the parity hook forces per-row choices)
                 float logit[MAX_E];
 #pragma unroll
-                for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[b * p.E + e]) : -INFINITY;
+                for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[b * p.sample_ld + e]) : -INFINITY;
                 top2_route(logit, p.forced ? p.forced + 2 * row : nullptr, s0, s1, w0, w1);
                 cached_b = b;
             }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void moe_plan_time_kernel(MoeArgs p) {
     if (tid < B) {
         float logit[MAX_E];
 #pragma unroll
-        for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[tid * p.E + e]) : -INFINITY;
+        for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bf2f(p.sample_logits[tid * p.sample_ld + e]) : -INFINITY;
         int a, b;
         u16 wa, wb;
         top2_route(logit, nullptr, a, b, wa, wb);
@@ -343,7 +343,9 @@ int launch_moe_route(const MoeArgs& a, hipStream_t stream) {
     return 0;
 }
 
-int launch_moe_plan(const MoeArgs& a, hipStream_t stream) {
+int launch_moe_plan(const MoeArgs& a_in, hipStream_t stream) {
+    MoeArgs a = a_in;
+    if (a.sample_ld == 0) a.sample_ld = a.E;
     if (check(a)) return 2;
     LT_REQUIRE(2LL * a.rows <= 1024LL * 1023, "moe_plan: %d rows exceed the packed 16-bit counters of the scan (523776 rows)", a.rows);
     if (a.sample_logits && !a.forced && a.rows % a.rows_per_sample == 0 && a.rows / a.rows_per_sample <= PLAN_T_MAXB) {  // closed form

@@ -1028,3 +1028,13 @@ def test_qkv_rowstat_then_fused_small_attention_equals_the_separate_passes(B, to
     ref = _attn_ref(qr, kr, vr, scale).permute(0, 2, 1, 3).reshape(B, tokens, d)
     assert rel_l2(out1, ref) < 8e-3, rel_l2(out1, ref)
     assert rel_l2(out0, ref) < 8e-3
+    # the 64-query-row workgroups (option value 2): another partition of the same per-row arithmetic -> the same bits
+    set_option("attn_small_fused", 2)
+    try:
+        out2 = torch.full_like(out0, float("nan"))
+        ok(lib().lt_op_qkv_attention_small(P(A), P(W), P(C1), M, K, H, Hkv, tokens, hd, P(qw), P(qb), P(kw), P(kb), P(table), 384, grid_w, kscale,
+                                           P(ws), P(out2), stream()), "qkv_attention_small (2 waves)")
+        torch.cuda.synchronize()
+    finally:
+        set_option("attn_small_fused", 1)
+    assert torch.equal(out2, out1)
