@@ -193,11 +193,10 @@ int lt_profile_set_window(lt_engine* e, int32_t klass, int64_t skip_launches, in
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in/out, fp32 accumulate.  K % 64 == 0.
  * epilogue 0: plain, 1: SwiGLU on 32-row interleaved W (out has N/2 columns: silu(w1 x) * (w3 x)).
  * variant 0: what the engine uses (kernel picked from the problem size); 1 / 2: 256x256 / 256x288 tiles, classic double-buffered
- * loop; 3: 256x256 8-wave ping-pong; 7 / 8: 128x128 / 64x128 small-M tiles; 13 / 14: persistent 4 waves x (128 x 128), LDS ring
- * and DMA prefetch carried across tile boundaries (K % 64 == 0, K >= 128, no bias; 14 issues a tile's epilogue from inside the
- * next tile's first slab - the engine's SwiGLU kernel).  4 (256x288 ping-pong), 5 / 6 (single-barrier rendezvous), 9 (persistent
- * 8-wave ping-pong), 10 (4 x (128 x 128), one tile per workgroup), 11 (AGPR accumulators), 12 (VGPR-staged): round-1 study
- * kernels, only in EXPERIMENTAL=1 builds (csrc/experimental/). */
+ * loop; 3: 256x256 8-wave ping-pong; 7 / 8: 128x128 / 64x128 small-M tiles; 15 / 16: ONE persistent 4-wave kernel on 16x16x32 MFMAs,
+ * 256x256 / 256x288 tiles, LDS ring and DMA prefetch carried across tile boundaries (K % 64 == 0, K >= 128, no bias) - the engine's
+ * kernel for every large dense GEMM; 19: 256x128 8-wave ping-pong (SwiGLU epilogue only: the time-routed experts at 256 tokens).
+ * 4-6, 9-14, 17, 18 were study kernels of rounds 1-3 (csrc/experimental/, deleted in round 5) and are refused by name. */
 int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, int32_t bias_dtype,
                     void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,
                     void* stream);

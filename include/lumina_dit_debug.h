@@ -57,6 +57,10 @@ extern "C" {
  *                       per-tile LayerNorm partials its GEMM epilogue left (round 5: one launch boundary less per layer where every launch
  *                       is latency-bound), 128 query rows per workgroup | 2: the same with 64 query rows per workgroup (A/B) | 0: q / k / v
  *                       post-processing launch + attention launch
+ *   "moe_time_tiles"    (0..1, 1): the time-routed expert GEMMs know how many of their rows are real (every token of a sample goes to the same
+ *                       two experts: 2 x batch full segments) and pick their tile shape from that count instead of the launch's padded
+ *                       capacity - at the 600M MoE's 256 tokens 256 x 128 tiles for w1 | w3 and 64 x 128 tiles for w2 (round 5) | 0: shapes
+ *                       from the padded row count
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 
