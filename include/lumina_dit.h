@@ -195,7 +195,7 @@ int lt_profile_set_window(lt_engine* e, int32_t klass, int64_t skip_launches, in
  * variant 0: what the engine uses (kernel picked from the problem size); 1 / 2: 256x256 / 256x288 tiles, classic double-buffered
  * loop; 3: 256x256 8-wave ping-pong; 7 / 8: 128x128 / 64x128 small-M tiles; 15 / 16: ONE persistent 4-wave kernel on 16x16x32 MFMAs,
  * 256x256 / 256x288 tiles, LDS ring and DMA prefetch carried across tile boundaries (K % 64 == 0, K >= 128, no bias) - the engine's
- * kernel for every large dense GEMM; 19: 256x128 8-wave ping-pong (SwiGLU epilogue only: the time-routed experts at 256 tokens).
+ * kernel for every large dense GEMM.
  * 4-6, 9-14, 17, 18 were study kernels of rounds 1-3 (csrc/experimental/, deleted in round 5) and are refused by name. */
 int lt_op_gemm_bf16(const void* A_dev, const void* W_dev, const void* bias_dev, int32_t bias_dtype,
                     void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant,

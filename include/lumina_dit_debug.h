@@ -52,15 +52,10 @@ extern "C" {
  *                       match an apex box too.  Meant for the text-conditional families (Next-DiT T2I, Flag-DiT: the only ones whose
  *                       reference imports apex) - set it per engine (lt_engine_set_option) and before lt_prepare_prompt, whose hoisted
  *                       text K / V go through the same norm
- *   "attn_small_fused"  (0..2, 1): class-conditional models at head_dim 48 and <= 512 tokens (the 600M ImageNet / MoE models at 256^2): q_norm,
+ *   "attn_small_fused"  (0..1, 1): class-conditional models at head_dim 48 and <= 512 tokens (the 600M ImageNet / MoE models at 256^2): q_norm,
  *                       k_norm, RoPE, the V transpose and the attention itself are ONE launch that reads the QKV projection's output and the
  *                       per-tile LayerNorm partials its GEMM epilogue left (round 5: one launch boundary less per layer where every launch
- *                       is latency-bound), 128 query rows per workgroup | 2: the same with 64 query rows per workgroup (A/B) | 0: q / k / v
- *                       post-processing launch + attention launch
- *   "moe_time_tiles"    (0..1, 1): the time-routed expert GEMMs know how many of their rows are real (every token of a sample goes to the same
- *                       two experts: 2 x batch full segments) and pick their tile shape from that count instead of the launch's padded
- *                       capacity - at the 600M MoE's 256 tokens 256 x 128 tiles for w1 | w3 and 64 x 128 tiles for w2 (round 5) | 0: shapes
- *                       from the padded row count
+ *                       is latency-bound) | 0: q / k / v post-processing launch + attention launch
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

@@ -20,7 +20,6 @@
 // of squares) instead of the two-pass form, as on the attn_q_fused path of the large models.
 #include "common.h"
 #include "kernels.h"
-#include "options.h"
 #include "tile_order.h"
 
 namespace {
@@ -270,10 +269,9 @@ int launch_attention_small(const AttnSmallArgs& a_in, hipStream_t stream) {
     LT_REQUIRE(a.q_nslot == a.H * a.hd / 128 && a.k_nslot == a.Hkv * a.hd / 128 && a.q_slot0 + a.q_nslot <= a.slots && a.k_slot0 + a.k_nslot <= a.slots,
                "attention_small: the row-statistics slots do not cover the q / k widths");
     LT_REQUIRE((a.N - 1) / a.grid_w < a.cs_len && a.grid_w <= a.cs_len, "attention_small: token grid exceeds the RoPE table (%d)", a.cs_len);
-    // option attn_small_fused: 1 = 4 waves x 32 query rows per workgroup (128 workgroups at 2 x 32 heads x 256 tokens), 2 = 2 waves (256
-    // workgroups: every CU busy, the K / V^T images built twice as often)
-    const int nw = lt_opt(OPT_ATTN_SMALL_FUSED) == 2 ? 2 : 4;
-    const int nqb = (a.N + 32 * nw - 1) / (32 * nw);
+    constexpr int NW = 4;  // 4 waves x 32 query rows (64-row workgroups - twice the workgroups, the K / V^T images built twice as often - measured 4 % slower,
+                           // profiles/r05/bench_ab_moe_time_tiles_and_attn_small_64row_workgroups_both_lose.log)
+    const int nqb = (a.N + 32 * NW - 1) / (32 * NW);
     int nblk = a.B * a.H * nqb;
     if (a.pf.blocks > 0) {  // riders behind the attention blocks, from a multiple of 8 on (block index mod 8 = XCD)
         a.pf.first = (nblk + 7) / 8 * 8;
@@ -282,13 +280,8 @@ int launch_attention_small(const AttnSmallArgs& a_in, hipStream_t stream) {
         a.pf.first = 0x7fffffff;
     }
     const int smem = a.N * (48 * 2 + 16) + (a.N / 64) * 48 * 128 + a.N * 8;
-    if (nw == 2) {
-        if (ensure_dynamic_lds((const void*)attn_small_fused_kernel<48, 2>, smem)) return 1;
-        hipLaunchKernelGGL((attn_small_fused_kernel<48, 2>), dim3(nblk), dim3(128), smem, stream, a);
-    } else {
-        if (ensure_dynamic_lds((const void*)attn_small_fused_kernel<48, 4>, smem)) return 1;
-        hipLaunchKernelGGL((attn_small_fused_kernel<48, 4>), dim3(nblk), dim3(256), smem, stream, a);
-    }
+    if (ensure_dynamic_lds((const void*)attn_small_fused_kernel<48, NW>, smem)) return 1;
+    hipLaunchKernelGGL((attn_small_fused_kernel<48, NW>), dim3(nblk), dim3(64 * NW), smem, stream, a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

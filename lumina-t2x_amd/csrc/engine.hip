@@ -431,9 +431,6 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
     const int P = tiles * 256;
     GemmArgs g;
     g.bias = nullptr; g.bias_dtype = -1; g.tile_expert = e->moe_tile_expert;
-    // time branch without forced routing: every token of a sample goes to the same two experts -> exactly 2 x B segments of N rows, each
-    // padded to whole 256-row tiles (moe_plan); the GEMMs pick their tile shapes from this count instead of the padded capacity
-    if (branch == 0 && !e->moe_force_rows && lt_opt(OPT_MOE_TIME_TILES)) g.valid_rows = 2 * B * ((N + 255) / 256) * 256;
     {   // grouped SwiGLU GEMM: each 256-row tile multiplies with its expert's packed w1|w3
         // (A = the un-sorted FFN input: the GEMM gathers its rows through the plan's inverse map, no expert-sorted copy)
         g.A = e->h; g.a_row_map = e->moe_src; g.a_map_rows = M; g.W = branch == 0 ? w.w13_t : w.w13_s; g.C = e->moe_us; g.M = P; g.N = 2 * F; g.K = d;

@@ -36,7 +36,6 @@ template __global__ void gemm_bf16_tn<4, 3, 2, 3, 2>(GemmArgs);
 template __global__ void gemm_bf16_tn<2, 4, 4, 2, 1>(GemmArgs);   // SwiGLU on the classic loop (explicit variant 1)
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 0>(GemmArgs);   // 8-wave ping-pong (explicit variant 3)
 template __global__ void gemm_bf16_pp<2, 4, 4, 2, 1>(GemmArgs);   // ... grouped (MoE expert) SwiGLU GEMM
-template __global__ void gemm_bf16_pp<4, 2, 2, 2, 1>(GemmArgs);   // ... the same on 256 x 128 tiles (round 5: the time-routed experts at 256 tokens, see choose())
 template __global__ void gemm_bf16_w4q<0, 8>(GemmArgs);           // persistent 4 waves on 16x16x32 MFMAs: 256 x 256 tiles
 template __global__ void gemm_bf16_w4q<0, 9>(GemmArgs);           // ... 256 x 288 tiles (N = 2304 / 6912: whole rounds over 256 CUs)
 template __global__ void gemm_bf16_w4q<1, 8>(GemmArgs);           // ... SwiGLU
@@ -157,7 +156,7 @@ int launch_w4q(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
 
 // ---- kernel selection (one place: launch_gemm_bf16 launches what choose() names, lt_gemm_describe prints it) -------------
 enum GemmKernel {
-    GK_TN256, GK_TN288, GK_TN256_VT, GK_TN288_VT, GK_TN256_SWIGLU, GK_PP256, GK_PP256_SWIGLU, GK_PP256x128_SWIGLU,
+    GK_TN256, GK_TN288, GK_TN256_VT, GK_TN288_VT, GK_TN256_SWIGLU, GK_PP256, GK_PP256_SWIGLU,
     GK_S128, GK_S128_SWIGLU, GK_S64, GK_W4Q256, GK_W4Q288, GK_W4Q256_SWIGLU, GK_W4Q288_QKV, GK_W4Q256_QKV, GK_W4Q256_GROUPED,
     GK_W4Q256_SWIGLU_GROUPED, GK_REMOVED, GK_NONE
 };
@@ -165,7 +164,7 @@ const char* const kGemmKernelName[] = {
     "gemm_bf16_tn<2,4,4,2,0> (256x256, 8 waves)", "gemm_bf16_tn<4,3,2,3,0> (256x288, 12 waves)",
     "gemm_bf16_tn<2,4,4,2,2> (256x256, V^T epilogue)", "gemm_bf16_tn<4,3,2,3,2> (256x288, V^T epilogue)",
     "gemm_bf16_tn<2,4,4,2,1> (256x256, SwiGLU)", "gemm_bf16_pp<2,4,4,2,0> (256x256 ping-pong)",
-    "gemm_bf16_pp<2,4,4,2,1> (256x256 ping-pong, SwiGLU)", "gemm_bf16_pp<4,2,2,2,1> (256x128 ping-pong, SwiGLU)",
+    "gemm_bf16_pp<2,4,4,2,1> (256x256 ping-pong, SwiGLU)",
     "gemm_bf16_pp<2,4,2,1,0,..,1,4> (128x128)", "gemm_bf16_pp<4,2,1,2,1,..,1,4> (128x128, SwiGLU)",
     "gemm_bf16_pp<2,4,1,1,0,..,1,4> (64x128)", "gemm_bf16_w4q<0,8> (persistent 4 waves, 16x16x32 MFMA, 256x256)",
     "gemm_bf16_w4q<0,9> (persistent 4 waves, 16x16x32 MFMA, 256x288)", "gemm_bf16_w4q<1,8> (persistent 4 waves, 16x16x32 MFMA, 256x256, SwiGLU)",
@@ -194,7 +193,7 @@ bool w4q_grouped_ok(const GemmArgs& a, int epilogue) {
 }
 
 // variant: 0 = auto; 1 / 2 = 256x256 / 256x288 classic loop; 3 = 256x256 8-wave ping-pong; 7 / 8 = 128x128 / 64x128 small-M tiles;
-//          15 / 16 = persistent 4 waves on 16x16x32 MFMAs, 256x256 / 256x288 tiles; 19 = 256x128 8-wave ping-pong (SwiGLU epilogue only);
+//          15 / 16 = persistent 4 waves on 16x16x32 MFMAs, 256x256 / 256x288 tiles;
 //          4, 5, 6, 9 .. 14, 17, 18 = study kernels of rounds 1-3, removed (git history)
 GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     const bool w4p_ok = !a.tile_expert && !a.trace && a.bias_dtype < 0 && a.K % 64 == 0 && a.K >= 128 &&
@@ -210,14 +209,9 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
         return epilogue == 1 ? GK_W4Q256_SWIGLU : (variant == 15 ? GK_W4Q256 : GK_W4Q288);
     }
     if (variant == 4 || variant == 5 || variant == 6 || (variant >= 9 && variant <= 14) || variant == 17 || variant == 18) return GK_REMOVED;
-    if (variant == 19) return epilogue == 1 && !a.trace ? GK_PP256x128_SWIGLU : GK_NONE;  // explicit: the 256 x 128 ping-pong SwiGLU tile
     const int cus = num_cus();
-    // grouped launches are sized for the worst-case segment padding; GemmArgs::valid_rows (when the caller knows it) is the row count
-    // that holds real work - the tile counts that decide between tile shapes are taken from it (round 5: the time-routed experts of the
-    // 600M MoE at 256 tokens are exactly 2 x B full 256-row segments inside a launch sized for 8)
-    const int Mv = (a.tile_expert && a.valid_rows > 0 && a.valid_rows < a.M) ? a.valid_rows : a.M;
-    const long long t256 = (long long)((Mv + 255) / 256) * ((a.N + 255) / 256);
-    const long long t128 = (long long)((Mv + 127) / 128) * ((a.N + 127) / 128);
+    const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (epilogue == 2) {  // V^T epilogue: the two classic tile shapes
         int v = variant == 0 ? lt_opt(OPT_GEMM_VARIANT) : variant;
         if (v != 1 && v != 2) {
@@ -226,12 +220,6 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
         }
         return v == 2 ? GK_TN288_VT : GK_TN256_VT;
     }
-    // a grouped SwiGLU GEMM with a known valid row count whose 256 x 256 tiles fill at most half the CUs while its 256 x 128 tiles still fit one
-    // round: twice the workgroups, each staging (256 + 128) instead of (256 + 256) rows per slab - at ~50 GB/s per CU (NOTEBOOK.md 9.1) 24
-    // instead of 31+ us.  (In front of the small-M rule: 128 x 128 tiles would be two rounds here.)
-    if (variant == 0 && lt_opt(OPT_GEMM_VARIANT) == 0 && epilogue == 1 && a.tile_expert && Mv < a.M && lt_opt(OPT_MOE_TIME_TILES) && 2 * t256 <= cus &&
-        (long long)((Mv + 255) / 256) * ((a.N + 127) / 128) <= cus)
-        return GK_PP256x128_SWIGLU;
     // small-M problems (cfg 1 / cfg 5: 512 rows): 256-wide tiles leave most CUs idle and every workgroup is a long serial
     // K loop that streams weights nobody else re-uses; 128 x 128 (or 64 x 128) tiles give 4-8x the workgroups, each with
     // its own 3-slab prefetch window, single-barrier rendezvous loop over 64-deep slabs (profiles/r01/opbench_small_m.log)
@@ -279,7 +267,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         LT_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0, "gemm: N=%d and ldc=%d must be multiples of 8", a.N, a.ldc);
     }
     LT_REQUIRE(epilogue != 1 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
-    LT_REQUIRE(variant >= 0 && variant <= 19, "gemm: unknown variant %d", variant);
+    LT_REQUIRE(variant >= 0 && variant <= 18, "gemm: unknown variant %d", variant);
     const GemmKernel k = choose(a, epilogue, variant);
     // split-K: dense plain-epilogue problems on the 64 x 128 tiles whose two halves still fit one round of the CUs, K >= 1024
     a.split_k = 0;
@@ -293,7 +281,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         LT_REQUIRE(a.rowstat_slots >= (a.N + 127) / 128, "gemm: rowstat_slots %d < %d column tiles", a.rowstat_slots, (a.N + 127) / 128);
     }
     if (a.a_row_map) {  // gather-on-load lives in the ping-pong kernels' staging (the grouped SwiGLU GEMM of the MoE layers)
-        LT_REQUIRE(k == GK_PP256_SWIGLU || k == GK_PP256x128_SWIGLU || k == GK_PP256 || k == GK_S128 || k == GK_S128_SWIGLU || k == GK_S64 || k == GK_W4Q256_GROUPED ||
+        LT_REQUIRE(k == GK_PP256_SWIGLU || k == GK_PP256 || k == GK_S128 || k == GK_S128_SWIGLU || k == GK_S64 || k == GK_W4Q256_GROUPED ||
                    k == GK_W4Q256_SWIGLU_GROUPED,
                    "gemm: a_row_map is supported by the gemm_bf16_pp kernels and the grouped persistent kernel only (this problem runs %s)", kGemmKernelName[k]);
         LT_REQUIRE(a.a_map_rows > 0 && (long long)a.a_map_rows * a.lda * 2 < 0x40000000LL, "gemm: a_row_map needs 0 < a_map_rows * lda * 2 < 2^30");
@@ -306,7 +294,6 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         case GK_TN256_SWIGLU: return launch_cfg<2, 4, 4, 2, 1, false>(a, stream, ev0, ev1);
         case GK_PP256: return launch_cfg<2, 4, 4, 2, 0, true>(a, stream, ev0, ev1);
         case GK_PP256_SWIGLU: return launch_cfg<2, 4, 4, 2, 1, true>(a, stream, ev0, ev1);
-        case GK_PP256x128_SWIGLU: return launch_cfg<4, 2, 2, 2, 1, true>(a, stream, ev0, ev1);
         case GK_S128: return launch_cfg<2, 4, 2, 1, 0, true, 1, 4>(a, stream, ev0, ev1);
         case GK_S128_SWIGLU: return launch_cfg<4, 2, 1, 2, 1, true, 1, 4>(a, stream, ev0, ev1);
         case GK_S64: return launch_cfg<2, 4, 1, 1, 0, true, 1, 4>(a, stream, ev0, ev1);

@@ -17,7 +17,6 @@ struct GemmArgs {
     // tile_expert[tm] < 0 -> the tile is padding and the workgroup exits.  Device array of ceil(M / 256) ints.
     const int* tile_expert = nullptr;
     long long w_expert_stride = 0;
-    int valid_rows = 0;  // grouped mode, optional: rows of M that belong to non-padding tiles (kernel selection only; 0 = unknown = M)
     // gather-on-load (grouped SwiGLU GEMM of the MoE layers, gemm_bf16_pp kernels only): row m of the problem is row a_row_map[m] of A
     // (-1: a padding row, reads as zero); A then has a_map_rows rows.  Replaces a gather pass + an expert-sorted copy of the FFN input.
     const int* a_row_map = nullptr;

@@ -24,8 +24,7 @@ const LtOptDesc kLtOptDesc[LT_OPT_COUNT] = {
     {"gemm_stagger", 0, 256, 0, false},
     {"gemm_variant", 0, 2, 0, false},
     {"rmsnorm_apex", 0, 1, 0, true},
-    {"attn_small_fused", 0, 2, 1, false},
-    {"moe_time_tiles", 0, 1, 1, true},
+    {"attn_small_fused", 0, 1, 1, true},
 };
 
 namespace {

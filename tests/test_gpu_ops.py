@@ -146,14 +146,12 @@ def test_gemm_4wave_persistent_16x16x32(M, N, K, epi, variant):
         assert rel_l2(got, A.float() @ W.float().t()) < 4e-3
 
 
-@pytest.mark.parametrize("variant", [0, 3, 7, 19])
+@pytest.mark.parametrize("variant", [0, 3, 7])
 @pytest.mark.parametrize("epilogue", [0, 1])
 def test_gemm_grouped_gather_on_load(variant, epilogue):
     """round 3: the experts' GEMM reads its rows through the routing plan's inverse map (sorted position -> token row, -1 = padding)
     instead of a gathered copy - must equal, bit for bit, the same kernel on a gathered copy; every token appears twice (top-2),
     ragged segments, a padding-only tile, padding rows inside real tiles leave zeros x W = 0 rows (they are never read back)."""
-    if variant == 19 and epilogue == 0:
-        pytest.skip("the 256 x 128 ping-pong tile (round 5, the time-routed experts' w1 | w3 at 256 tokens) has the SwiGLU epilogue only")
     E, K, N, T = 4, 1536, 512, 600
     te = [2, 2, 0, -1, 3, 1, 1, -1]
     M = 256 * len(te)
@@ -181,11 +179,6 @@ def test_gemm_grouped_gather_on_load(variant, epilogue):
        "grouped_gather")
     torch.cuda.synchronize()
     assert torch.equal(got, want)
-    if variant == 19:  # same MFMA, same k order per output as the 256 x 256 ping-pong tile: bit-identical to it
-        ref3 = torch.full((M, No), 3.0, device="cuda", dtype=torch.bfloat16)
-        ok(lib().lt_op_gemm_grouped(P(gathered), P(W), P(tile_expert), N * K, P(ref3), M, N, K, epilogue, 3, stream()), "grouped (variant 3)")
-        torch.cuda.synchronize()
-        assert torch.equal(got, ref3)
     assert torch.all(got[256 * 3: 256 * 4] == 3.0) and torch.all(got[256 * 7:] == 3.0)
     y = X[row_map[256 * 4: 256 * 4 + 131].long().cuda()].float() @ W[3].float().t()
     if not epilogue:
@@ -1035,13 +1028,3 @@ def test_qkv_rowstat_then_fused_small_attention_equals_the_separate_passes(B, to
     ref = _attn_ref(qr, kr, vr, scale).permute(0, 2, 1, 3).reshape(B, tokens, d)
     assert rel_l2(out1, ref) < 8e-3, rel_l2(out1, ref)
     assert rel_l2(out0, ref) < 8e-3
-    # the 64-query-row workgroups (option value 2): another partition of the same per-row arithmetic -> the same bits
-    set_option("attn_small_fused", 2)
-    try:
-        out2 = torch.full_like(out0, float("nan"))
-        ok(lib().lt_op_qkv_attention_small(P(A), P(W), P(C1), M, K, H, Hkv, tokens, hd, P(qw), P(qb), P(kw), P(kb), P(table), 384, grid_w, kscale,
-                                           P(ws), P(out2), stream()), "qkv_attention_small (2 waves)")
-        torch.cuda.synchronize()
-    finally:
-        set_option("attn_small_fused", 1)
-    assert torch.equal(out2, out1)
