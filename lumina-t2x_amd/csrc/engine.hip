@@ -786,7 +786,8 @@ int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* ou
     const size_t sbytes = (size_t)B * e->cfg.in_channels * a->latent_h * a->latent_w * (a->io_dtype == LT_BF16 ? 2 : 4);
     const size_t cap_bytes = (size_t)e->cfg.max_batch * e->cfg.in_channels * e->cfg.max_tokens * e->cfg.patch_size * e->cfg.patch_size * 4;
     if (sbytes > cap_bytes) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
-    const int extra[8] = {use_cfg, e->prompt_B, e->prompt_T, e->prompt_Tpad, e->reg_Y, e->reg_h, e->reg_w, lt_opt_generation()};
+    // (both option generations: the process defaults' and this engine's overrides' - kernel selection is baked into a captured graph)
+    const int extra[9] = {use_cfg, e->prompt_B, e->prompt_T, e->prompt_Tpad, e->reg_Y, e->reg_h, e->reg_w, lt_opt_generation(), e->opts.gen};
     std::vector<char> key(sizeof(lt_step_args) + sizeof(extra));
     memcpy(key.data(), a, sizeof(lt_step_args));
     memcpy(key.data() + sizeof(lt_step_args), extra, sizeof(extra));

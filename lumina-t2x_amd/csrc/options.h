@@ -26,7 +26,7 @@ extern const LtOptDesc kLtOptDesc[LT_OPT_COUNT];
 
 int lt_opt_find(const char* name);                 // index into kLtOptDesc, -1 = unknown
 int lt_opt(int id);                                // effective value on this thread
-int lt_opt_generation();                           // changes whenever an effective value may have changed (HIP-graph cache key)
+int lt_opt_generation();                           // bumped by every change of a process default (HIP-graph cache key, beside LtEngineOptions::gen)
 int lt_opt_validate(int id, int* value);           // 0 ok (booleans normalised), else lt_set_error was called
 void lt_opt_set_process(int id, int value);
 void lt_opt_reset_process();

@@ -52,7 +52,7 @@ int lt_opt(int id) {
     return process().v[id].load(std::memory_order_relaxed);
 }
 
-int lt_opt_generation() { return process().gen.load(std::memory_order_relaxed) * 65536 + (tl_engine ? tl_engine->gen : 0); }
+int lt_opt_generation() { return process().gen.load(std::memory_order_relaxed); }
 
 int lt_opt_validate(int id, int* value) {
     const LtOptDesc& d = kLtOptDesc[id];
