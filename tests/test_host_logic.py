@@ -91,8 +91,8 @@ def test_drift_shape_assert_and_unknown_method():
     fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=3)
     with pytest.raises(AssertionError, match="Output shape"):
         fn(torch.ones(2, 4, 8, 8), lambda x, t, **kw: x[:, :2])
-    fn = Sampler(create_transport()).sample_ode(sampling_method="bosh3", num_steps=3)  # a torchdiffeq solver we do not restate
-    with pytest.raises(NotImplementedError):
+    fn = Sampler(create_transport()).sample_ode(sampling_method="dopri8", num_steps=3)  # a torchdiffeq solver we do not restate
+    with pytest.raises(NotImplementedError, match="dopri8"):
         fn(torch.ones(2, 4, 8, 8), lambda x, t, **kw: -x)
 
 
