@@ -70,18 +70,48 @@ __global__ __launch_bounds__(64 * NW) void attn_small_fused_kernel(AttnSmallArgs
     constexpr int NFREQ = HD >> 2;
     const float* cs = p.cs + (size_t)branch * p.cs_len * NFREQ * 2;
 
-    // ---- 1. LayerNorm statistics of this sample's K rows -> LDS ------------------------------------------------------------
-    {
-        const float inv_w = 1.0f / (float)(p.Hkv * HD);
-        for (int n = tid; n < N; n += NT) {
-            const float2* ps = (const float2*)p.rowstat + (row_b0 + n) * p.slots + p.k_slot0;
-            float s1 = 0.f, s2 = 0.f;
-            for (int i = 0; i < p.k_nslot; ++i) { const float2 v = ps[i]; s1 += v.x; s2 += v.y; }
-            const float mean = s1 * inv_w;
-            const float var = fmaxf(s2 * inv_w - mean * mean, 0.f);
-            kst[n] = float2{mean, rsqrtf(var + p.ln_eps)};
+    // ---- 0. the first batch of K / V rows of (b, hk) is requested before anything else: its latency hides behind steps 1 and 2 ----------
+    // Items (key n, 8-channel chunk ci) in batches of BATCH per thread: every global load of a batch is issued before the first use.
+    constexpr int BATCH = 6;
+    const int items = N * CPR;
+    bf8_t rk[BATCH], rvv[BATCH], kwv[BATCH], kbv[BATCH];
+    float4 krf[BATCH], kcf[BATCH];
+    int nn[BATCH], cc[BATCH];
+    auto load_batch = [&](int base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int id = min(base + u * NT, items - 1);  // (a surplus slot repeats the last item: same bytes to the same place)
+            const int n = id / CPR, ci = id - n * CPR;
+            nn[u] = n; cc[u] = ci;
+            const u16* rowp = p.qkv + (row_b0 + n) * p.ld + hk * HD + ci * 8;
+            rk[u] = *(const bf8_t*)(rowp + p.k_col0);
+            rvv[u] = *(const bf8_t*)(rowp + p.v_col0);
+            kwv[u] = *(const bf8_t*)(p.k_ln_w + hk * HD + ci * 8);
+            kbv[u] = *(const bf8_t*)(p.k_ln_b + hk * HD + ci * 8);
+            const int gr = n / p.grid_w, gc = n - gr * p.grid_w;
+            krf[u] = *(const float4*)(cs + ((size_t)gr * NFREQ + 2 * ci) * 2);
+            kcf[u] = *(const float4*)(cs + ((size_t)gc * NFREQ + 2 * ci) * 2);
         }
-    }
+    };
+    load_batch(tid);
+
+    // ---- 1. LayerNorm statistics of this sample's K rows -> LDS ------------------------------------------------------------
+    // (loads in groups of four with the sums behind them: a loop that loads and adds one slot per iteration serialises on the memory
+    //  latency - the first form of this kernel spent 10 of its 17 us in such loops, profiles/r05/rocprofv3_kernel_stats_cfg1_r05_before_*.csv)
+    auto row_stat = [&](const float2* ps, int ns, float inv_w) __attribute__((always_inline)) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < ns; i += 4) {
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = i + u < ns ? ps[i + u] : float2{0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s1 += v[u].x; s2 += v[u].y; }
+        }
+        const float mean = s1 * inv_w;
+        return float2{mean, rsqrtf(fmaxf(s2 * inv_w - mean * mean, 0.f) + p.ln_eps)};
+    };
+    for (int n = tid; n < N; n += NT)
+        kst[n] = row_stat((const float2*)p.rowstat + (row_b0 + n) * p.slots + p.k_slot0, p.k_nslot, 1.0f / (float)(p.Hkv * HD));
 
     // ---- 2. Q fragments (B operand of S^T = K Q^T): lane = (q row l31, d = 16 s + 8 hi .. +8), q_norm + RoPE in registers -----
     int qrow = qb * QB + wave * 32 + l31;
@@ -89,12 +119,8 @@ __global__ __launch_bounds__(64 * NW) void attn_small_fused_kernel(AttnSmallArgs
     if (!q_ok) qrow = N - 1;
     bf16x8 qf[KS];
     {
-        const float2* ps = (const float2*)p.rowstat + (row_b0 + qrow) * p.slots + p.q_slot0;
-        float s1 = 0.f, s2 = 0.f;
-        for (int i = 0; i < p.q_nslot; ++i) { const float2 v = ps[i]; s1 += v.x; s2 += v.y; }
-        const float inv_w = 1.0f / (float)(p.H * HD);
-        const float mean = s1 * inv_w;
-        const float rstd = rsqrtf(fmaxf(s2 * inv_w - mean * mean, 0.f) + p.ln_eps);
+        const float2 qst = row_stat((const float2*)p.rowstat + (row_b0 + qrow) * p.slots + p.q_slot0, p.q_nslot, 1.0f / (float)(p.H * HD));
+        const float mean = qst.x, rstd = qst.y;
         const f32x2 mv = {mean, mean}, rv = {rstd, rstd};
         const int gr = qrow / p.grid_w, gc = qrow - gr * p.grid_w;
         const u16* src = p.qkv + (row_b0 + qrow) * p.ld + p.q_col0 + h * HD;
@@ -124,39 +150,35 @@ __global__ __launch_bounds__(64 * NW) void attn_small_fused_kernel(AttnSmallArgs
     // ---- 3. K image (k_norm + RoPE + scale, one rounding) and V^T tile image of (b, hk) -------------------------------------------
     {
         const f32x2 osc = {p.k_scale, p.k_scale};
-        for (int id = tid; id < N * CPR; id += NT) {
-            const int n = id / CPR, ci = id - n * CPR;
-            const u16* rowp = p.qkv + (row_b0 + n) * p.ld + hk * HD + ci * 8;
-            const bf8_t raw = *(const bf8_t*)(rowp + p.k_col0);
-            const bf8_t rawv = *(const bf8_t*)(rowp + p.v_col0);
-            const bf8_t wv = *(const bf8_t*)(p.k_ln_w + hk * HD + ci * 8);
-            const bf8_t bv = *(const bf8_t*)(p.k_ln_b + hk * HD + ci * 8);
-            const float2 st = kst[n];
-            const f32x2 mv = {st.x, st.x}, rv = {st.y, st.y};
-            const int gr = n / p.grid_w, gc = n - gr * p.grid_w;
-            const float4 rf = *(const float4*)(cs + ((size_t)gr * NFREQ + 2 * ci) * 2);
-            const float4 cf = *(const float4*)(cs + ((size_t)gc * NFREQ + 2 * ci) * 2);
-            const float tc[4] = {rf.x, cf.x, rf.z, cf.z}, ts[4] = {rf.y, cf.y, rf.w, cf.w};
-            bf8_t o;
+        for (int base = tid; base < items; base += NT * BATCH) {
+            if (base != tid) load_batch(base);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x2 y = (unpk_bf(raw.w[j]) - mv) * rv * unpk_bf(wv.w[j]) + unpk_bf(bv.w[j]);
-                y = f32x2{y[0] * tc[j] - y[1] * ts[j], y[0] * ts[j] + y[1] * tc[j]};
-                o.w[j] = pk_bf(y * osc);
-            }
-            *(bf8_t*)(kimg + (size_t)n * KROW + ci * 16) = o;
-            // V^T: key position inside its group of 16 with bits 2 and 3 swapped (the order in which a lane of the swapped QK^T MFMA holds
-            // its P values, qkv_post.hip v_transpose); chunk c of row d sits in slot c ^ ((d >> 1) & 7) (the staging swizzle of attention.hip)
-            const int tok = n & 63;
-            const int tp = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
-            char* vt = vimg + (size_t)(n >> 6) * VTILE + (tp & 7) * 2;
-            const int c = tp >> 3;
+            for (int u = 0; u < BATCH; ++u) {
+                const int n = nn[u], ci = cc[u];
+                const float2 st = kst[n];
+                const f32x2 mv = {st.x, st.x}, rv = {st.y, st.y};
+                const float tc[4] = {krf[u].x, kcf[u].x, krf[u].z, kcf[u].z}, ts[4] = {krf[u].y, kcf[u].y, krf[u].w, kcf[u].w};
+                bf8_t o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int d = ci * 8 + 2 * e;  // d and d + 1 share (d >> 1)
-                const int slot = (c ^ ((d >> 1) & 7)) << 4;
-                *(u16*)(vt + d * 128 + slot) = (u16)(rawv.w[e] & 0xffffu);
-                *(u16*)(vt + (d + 1) * 128 + slot) = (u16)(rawv.w[e] >> 16);
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 y = (unpk_bf(rk[u].w[j]) - mv) * rv * unpk_bf(kwv[u].w[j]) + unpk_bf(kbv[u].w[j]);
+                    y = f32x2{y[0] * tc[j] - y[1] * ts[j], y[0] * ts[j] + y[1] * tc[j]};
+                    o.w[j] = pk_bf(y * osc);
+                }
+                *(bf8_t*)(kimg + (size_t)n * KROW + ci * 16) = o;
+                // V^T: key position inside its group of 16 with bits 2 and 3 swapped (the order in which a lane of the swapped QK^T MFMA holds
+                // its P values, qkv_post.hip v_transpose); chunk c of row d sits in slot c ^ ((d >> 1) & 7) (the staging swizzle of attention.hip)
+                const int tok = n & 63;
+                const int tp = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
+                char* vt = vimg + (size_t)(n >> 6) * VTILE + (tp & 7) * 2;
+                const int c = tp >> 3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = ci * 8 + 2 * e;  // d and d + 1 share (d >> 1)
+                    const int slot = (c ^ ((d >> 1) & 7)) << 4;
+                    *(u16*)(vt + d * 128 + slot) = (u16)(rvv[u].w[e] & 0xffffu);
+                    *(u16*)(vt + (d + 1) * 128 + slot) = (u16)(rvv[u].w[e] >> 16);
+                }
             }
         }
     }
