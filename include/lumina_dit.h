@@ -238,13 +238,6 @@ int lt_op_gemm_splitk(const void* A_dev, const void* W_dev, void* C_dev, int32_t
  * marks a padding segment whose output rows are left untouched.  M % 256 == 0; tile_expert_dev: int32 [M / 256]. */
 int lt_op_gemm_grouped(const void* A_dev, const void* W_dev, const void* tile_expert_dev, int64_t w_expert_stride,
                        void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* stream);
-/* lt_op_gemm_grouped (plain epilogue, variant 0) with the caller's split-K workspace: part_f32 [slots][2][64 * 128] floats and
- * counters_u32 [slots] (zero before the first launch, left zero by every launch).  Where the problem runs on the 128 x 128 small-M tiles
- * (at most #CUs tiles incl. padding), K >= 2048, K % 512 == 0 and slots >= 2 x tiles, every valid tile's K range is split over two
- * workgroups and the second arriver adds the first one's fp32 partial (round 5: how the engine runs the experts' w2 of the 600M MoE at 256
- * tokens, option moe_w2_splitk); otherwise the call is lt_op_gemm_grouped.  Padding segments are left untouched either way. */
-int lt_op_gemm_grouped_splitk(const void* A_dev, const void* W_dev, const void* tile_expert_dev, int64_t w_expert_stride, void* C_dev,
-                              int32_t M, int32_t N, int32_t K, void* part_f32_dev, void* counters_u32_dev, int32_t slots, void* stream);
 /* the same with gather-on-load (round 3: how the engine runs the experts' W1 | W3 GEMM - no gather pass, no expert-sorted copy of
  * the FFN input): row m of the problem is row row_map_dev[m] (int32 [M]) of A_dev [a_rows, K]; -1 = a padding row that reads as
  * zero.  Ping-pong tile kernels (explicit 3 / 7 / 8) and the grouped mode of the persistent 16x16x32 kernel (explicit 15; K >= 256, all of A

@@ -56,9 +56,6 @@ extern "C" {
  *                       k_norm, RoPE, the V transpose and the attention itself are ONE launch that reads the QKV projection's output and the
  *                       per-tile LayerNorm partials its GEMM epilogue left (round 5: one launch boundary less per layer where every launch
  *                       is latency-bound) | 0: q / k / v post-processing launch + attention launch
- *   "moe_w2_splitk"     (0..1, 1): the experts' w2 GEMM of a mixture-of-experts layer that runs on the 128 x 128 small-M tiles (the 600M MoE at 256
- *                       tokens: K = 4096, 2 MB staged per valid tile) splits K over two workgroups per tile, the second arriver adds the
- *                       first one's fp32 partial (the hand-off of "gemm_splitk") | 0: one workgroup per tile
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

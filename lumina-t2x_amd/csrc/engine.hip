@@ -441,7 +441,6 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
     {
         g.A = e->moe_us; g.a_row_map = nullptr; g.a_map_rows = 0; g.W = branch == 0 ? w.w2_t : w.w2_s; g.C = e->moe_ys; g.M = P; g.N = d; g.K = F;
         g.lda = F; g.ldw = F; g.ldc = d; g.w_expert_stride = (long long)d * F;
-        g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;  // (the launcher decides: option moe_w2_splitk)
         ProfScope ps(e, 0, 2.0 * (2.0 * M) * (double)d * F, s, true);
         if (launch_gemm_bf16(g, 0, 0, s, ps.ev0(), ps.ev1())) return 1;
     }
@@ -998,12 +997,6 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     {   // split-K workspace (zeroed by dev_alloc: the counters must start at 0; every launch leaves them at 0)
         void* q;
         e->splitk_tiles = 128;
-        // mixture-of-experts at small token counts: the experts' w2 on 128 x 128 tiles takes two slots per tile (launch_gemm_bf16); sized
-        // for the padded segment capacity as long as that stays a one-round problem (larger ones run on the persistent grouped kernel)
-        if (e->E > 0) {
-            const long long t128 = (long long)e->moe_tiles * 2 * ((d + 127) / 128);
-            if (t128 <= 256) e->splitk_tiles = std::max(e->splitk_tiles, (int)(2 * t128));
-        }
         if (dev_alloc(e, &q, (size_t)e->splitk_tiles * 2 * 64 * 128 * sizeof(float))) return fail();
         e->splitk_part = (float*)q;
         if (dev_alloc(e, &q, (size_t)e->splitk_tiles * sizeof(unsigned))) return fail();
@@ -1606,20 +1599,6 @@ extern "C" int lt_op_gemm_grouped(const void* A, const void* W, const void* tile
     g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = -1;
     g.tile_expert = (const int*)tile_expert; g.w_expert_stride = w_expert_stride;
     return launch_gemm_bf16(g, epilogue, variant, (hipStream_t)stream);
-}
-
-// the experts' w2 GEMM as the engine runs it at small token counts (option moe_w2_splitk): grouped, plain epilogue, 128 x 128 tiles, the K
-// range of every tile split over two workgroups that meet in the caller's fp32 workspace
-extern "C" int lt_op_gemm_grouped_splitk(const void* A, const void* W, const void* tile_expert, int64_t w_expert_stride, void* C, int32_t M,
-                                         int32_t N, int32_t K, void* part_f32, void* counters_u32, int32_t slots, void* stream) {
-    LT_REQUIRE(A && W && C && tile_expert && part_f32 && counters_u32, "lt_op_gemm_grouped_splitk: null pointer");
-    LT_REQUIRE(M > 0 && M % 256 == 0, "lt_op_gemm_grouped_splitk: M=%d must be a positive multiple of 256 (expert segments)", M);
-    GemmArgs g;
-    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
-    g.lda = K; g.ldw = K; g.ldc = N; g.bias_dtype = -1;
-    g.tile_expert = (const int*)tile_expert; g.w_expert_stride = w_expert_stride;
-    g.splitk_part = (float*)part_f32; g.splitk_cnt = (unsigned*)counters_u32; g.splitk_tiles = slots;
-    return launch_gemm_bf16(g, 0, 0, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_gemm_grouped_gather(const void* A, int32_t a_rows, const void* row_map, const void* W, const void* tile_expert,

@@ -276,15 +276,6 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
         if ((2 * tiles <= num_cus() || lt_opt(OPT_GEMM_SPLITK) == 2) && tiles <= a.splitk_tiles) a.split_k = 2;
     }
-    // ... and (round 5, option moe_w2_splitk) the experts' W2 of the 600M MoE at 256 tokens: a grouped plain-epilogue problem on the 128 x 128
-    // tiles, K = 4096.  A valid tile stages 2 MB through its CU (40 us at ~50 GB/s, NOTEBOOK.md 9.1) and only 96-144 of the launch's
-    // 192 tiles are valid (the rest are segment padding and exit at once): two K halves per tile are 192-288 workgroups of 1 MB.  The
-    // workspace holds [2][64 x 128] floats per slot, a 128 x 128 tile takes two slots.
-    if (k == GK_S128 && epilogue == 0 && a.tile_expert && lt_opt(OPT_MOE_W2_SPLITK) && variant == 0 && a.splitk_part && a.splitk_cnt && !a.a_row_map &&
-        a.bias_dtype < 0 && !a.rowstat && a.K >= 2048 && a.K % 512 == 0) {
-        const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-        if (tiles <= num_cus() && 2 * tiles <= a.splitk_tiles) a.split_k = 2;
-    }
     if (a.rowstat) {
         LT_REQUIRE((k == GK_S128 || k == GK_S64) && epilogue == 0, "gemm: rowstat is written by the small-M tiles' plain epilogue only (this problem runs %s)", kGemmKernelName[k]);
         LT_REQUIRE(a.rowstat_slots >= (a.N + 127) / 128, "gemm: rowstat_slots %d < %d column tiles", a.rowstat_slots, (a.N + 127) / 128);

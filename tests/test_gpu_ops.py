@@ -222,46 +222,6 @@ def test_gemm_splitk_small_m(M, N, K, force):
     assert rel_l2(outs[0], plain) < 2e-3, rel_l2(outs[0], plain)
 
 
-@pytest.mark.parametrize("K,N,te", [(4096, 1536, [0, 3, -1, 1, 1, 2, -1, -1]),     # the 600M MoE's w2 at 256 tokens: 16 x 12 tiles incl. padding
-                                    (2048, 1160, [2, -1, 0, 0, -1, 3, 1, 1]),         # ragged N (9.06 -> 10 column tiles), holes between real segments
-                                    (1536, 1536, [0, 1, 2, 3])])                     # K below the split's bound: must run unsplit, bit-identical
-def test_gemm_grouped_splitk_on_small_m_tiles(K, N, te):
-    """round 5 (option moe_w2_splitk): the grouped plain-epilogue GEMM on 128 x 128 tiles with every valid tile's K range split over two
-    workgroups.  Against the unsplit grouped launch (equal to fp32 rounding of one addition) and an fp32 reference per segment; padding
-    segments untouched by both halves; counters back at zero; a second launch on the same workspace gives the same bits."""
-    E = 4
-    M = 256 * len(te)
-    g = torch.Generator().manual_seed(K + N + len(te))
-    A = bf(torch.randn(M, K, generator=g))
-    W = bf(torch.randn(E, N, K, generator=g) / math.sqrt(K))
-    tile_expert = torch.tensor(te, dtype=torch.int32, device="cuda")
-    tiles = (M // 128) * ((N + 127) // 128)
-    part = torch.full((2 * tiles * 2 * 64 * 128,), float("nan"), device="cuda", dtype=torch.float32)
-    cnt = torch.zeros(2 * tiles, device="cuda", dtype=torch.int32)
-    plain = torch.full((M, N), 3.0, device="cuda", dtype=torch.bfloat16)
-    ok(lib().lt_op_gemm_grouped(P(A), P(W), P(tile_expert), N * K, P(plain), M, N, K, 0, 0, stream()), "grouped")
-    outs = []
-    for _ in range(2):
-        out = torch.full((M, N), 3.0, device="cuda", dtype=torch.bfloat16)
-        ok(lib().lt_op_gemm_grouped_splitk(P(A), P(W), P(tile_expert), N * K, P(out), M, N, K, P(part), P(cnt), 2 * tiles, stream()), "grouped_splitk")
-        torch.cuda.synchronize()
-        outs.append(out)
-        assert int(cnt.abs().sum()) == 0, "a tile counter was left non-zero"
-    assert torch.equal(outs[0], outs[1])
-    split_ran = not torch.isnan(part).all()
-    assert split_ran == (K >= 2048)  # (all three shapes are 128 x 128-tile problems only when 2 x tiles > #CUs: the K = 1536 one runs on 64 x 128)
-    if not split_ran:
-        assert torch.equal(outs[0], plain)
-    for t_, ex in enumerate(te):
-        rows = slice(256 * t_, 256 * (t_ + 1))
-        if ex < 0:
-            assert torch.all(outs[0][rows] == 3.0), "padding segment was written"
-            continue
-        ref = A[rows].float() @ W[ex].float().t()
-        assert rel_l2(outs[0][rows], ref) < 4e-3, (t_, ex)
-        assert rel_l2(outs[0][rows], plain[rows]) < 2e-3
-
-
 def test_gemm_splitk_handoff_stress():
     """the split-K halves of a tile hand their fp32 partials over between two workgroups that may sit on different XCDs (sc0 sc1
     stores -> s_waitcnt vmcnt(0) -> relaxed system-scope counter -> sc0 sc1 loads, no L2-wide fence).  A stale read would silently corrupt
