@@ -123,6 +123,11 @@ def test_bench_launches_two_ranks_on_one_gpu():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["ranks"] == 2 and rec["shared_device"] is True and rec["steps"] == 3 and rec["value"] > 0
     assert "NOT a scaling" in rec["note"]
+    # round 5: the line itself shows what the collective layer saw - every rank took part in an all-reduce, each reports its own time
+    comm = rec["comm"]
+    assert comm["backend"] == "gloo" and comm["world"] == 2 and comm["ranks_seen"] == 2 and len(comm["ms_per_step_per_rank"]) == 2
+    assert all(v > 0 for v in comm["ms_per_step_per_rank"]) and max(comm["ms_per_step_per_rank"]) == pytest.approx(rec["ms_per_step"], rel=1e-6)
+    assert len(comm["devices"]) == 2 and comm["collective_in_timed_region"] is False
 
 
 def _worker_rccl_one_rank(rank, world, port, out_dir):
