@@ -37,7 +37,6 @@ sys.path.insert(0, REPO)
 
 from oracle import make_fulldepth_golden as F  # noqa: E402
 from oracle import odeint_oracle as OD  # noqa: E402
-from oracle import ref_harness as R  # noqa: E402
 from oracle import synth  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
