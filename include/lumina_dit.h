@@ -159,7 +159,7 @@ int lt_sample_ode(lt_engine* e, const void* z_dev, void* traj_dev, void* final_d
 
 /* number of model evaluations issued by the last lt_sample_ode call */
 int64_t lt_last_nfe(lt_engine* e);
-/* model evaluations served by replaying a captured HIP graph since lt_create (0 with lt_set_option("graph", 0)) */
+/* model evaluations served by replaying a captured HIP graph since lt_create (0 with lt_set_option("graph", 0), and below 1025 rows under the default "graph" 2) */
 int64_t lt_graph_replays(lt_engine* e);
 
 /* ---- mixture-of-experts routing hooks (parity tests: hold the discrete top-2 choice equal to a reference run's) ----

@@ -15,8 +15,9 @@ extern "C" {
 #endif
 
 /* Options - name (range, default): meaning.
- *   "graph"             (0..1, 1): one model evaluation is captured into a HIP graph per (shape, arguments, option generation) and
- *                       replayed | 0: eager launches
+ *   "graph"             (0..2, 2): 1 one model evaluation is captured into a HIP graph per (shape, arguments, option generation) and replayed
+ *                       | 2 the same above 1024 rows only: at 512 rows plain launches are 1.5-4.6 % faster (round 5 same-box A/B) | 0: eager
+ *                       launches
  *   "attention_variant" (1..6, 4): 1 baseline | 2 VALU-diet | 3 ping-pong wave groups (hd 72 / 96) | 4 one wave per SIMD x 64 query
  *                       rows, asm-owned AGPRs (hd 72, 96 and 48 with whole 64-key tiles; variant 3 otherwise) | 6 = 4 with the hd-48
  *                       one-wave kernel forced at every size | 5 is refused (the PV-on-16x16x32 study kernel, removed in round 5)

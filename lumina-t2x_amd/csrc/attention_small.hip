@@ -95,6 +95,28 @@ __global__ __launch_bounds__(64 * NW) void attn_small_fused_kernel(AttnSmallArgs
     };
     load_batch(tid);
 
+    // ---- 0b. ... and the query row's own loads (B operand of S^T = K Q^T: lane = (q row l31, d = 16 s + 8 hi .. +8)) ----------------------
+    int qrow = qb * QB + wave * 32 + l31;
+    const bool q_ok = qrow < N;
+    if (!q_ok) qrow = N - 1;
+    bf16x8 qf[KS];
+    // (every load of the query row is requested before any statistic is reduced: one memory round trip for the whole prologue)
+    const int gr = qrow / p.grid_w, gc = qrow - gr * p.grid_w;
+    const u16* src = p.qkv + (row_b0 + qrow) * p.ld + p.q_col0 + h * HD;
+    bf8_t qraw[KS], qwv[KS], qbv[KS];
+    float4 qrf[KS], qcf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int d0 = 16 * s + 8 * hi;  // < HD (HD % 16 == 0)
+        qraw[s] = *(const bf8_t*)(src + d0);
+        qwv[s] = *(const bf8_t*)(p.q_ln_w + h * HD + d0);
+        qbv[s] = *(const bf8_t*)(p.q_ln_b + h * HD + d0);
+        // complex slot pr = d0 / 2 + j rotates at frequency pr >> 1 with the ROW position (pr even) or the COLUMN position (pr odd)
+        const int fi0 = d0 >> 2;
+        qrf[s] = *(const float4*)(cs + ((size_t)gr * NFREQ + fi0) * 2);  // (cos, sin) at fi0, fi0 + 1 for the row
+        qcf[s] = *(const float4*)(cs + ((size_t)gc * NFREQ + fi0) * 2);
+    }
+
     // ---- 1. LayerNorm statistics of this sample's K rows -> LDS ------------------------------------------------------------
     // (loads in groups of four with the sums behind them: a loop that loads and adds one slot per iteration serialises on the memory
     //  latency - the first form of this kernel spent 10 of its 17 us in such loops, profiles/r05/rocprofv3_kernel_stats_cfg1_r05_before_*.csv)
@@ -113,32 +135,17 @@ __global__ __launch_bounds__(64 * NW) void attn_small_fused_kernel(AttnSmallArgs
     for (int n = tid; n < N; n += NT)
         kst[n] = row_stat((const float2*)p.rowstat + (row_b0 + n) * p.slots + p.k_slot0, p.k_nslot, 1.0f / (float)(p.Hkv * HD));
 
-    // ---- 2. Q fragments (B operand of S^T = K Q^T): lane = (q row l31, d = 16 s + 8 hi .. +8), q_norm + RoPE in registers -----
-    int qrow = qb * QB + wave * 32 + l31;
-    const bool q_ok = qrow < N;
-    if (!q_ok) qrow = N - 1;
-    bf16x8 qf[KS];
+    // ---- 2. q_norm + RoPE of the query fragments in registers (their loads were requested in step 0b) -----------------------------------
     {
         const float2 qst = row_stat((const float2*)p.rowstat + (row_b0 + qrow) * p.slots + p.q_slot0, p.q_nslot, 1.0f / (float)(p.H * HD));
-        const float mean = qst.x, rstd = qst.y;
-        const f32x2 mv = {mean, mean}, rv = {rstd, rstd};
-        const int gr = qrow / p.grid_w, gc = qrow - gr * p.grid_w;
-        const u16* src = p.qkv + (row_b0 + qrow) * p.ld + p.q_col0 + h * HD;
+        const f32x2 mv = {qst.x, qst.x}, rv = {qst.y, qst.y};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const int d0 = 16 * s + 8 * hi;  // < HD (HD % 16 == 0)
-            const bf8_t raw = *(const bf8_t*)(src + d0);
-            const bf8_t wv = *(const bf8_t*)(p.q_ln_w + h * HD + d0);
-            const bf8_t bv = *(const bf8_t*)(p.q_ln_b + h * HD + d0);
-            // complex slot pr = d0 / 2 + j rotates at frequency pr >> 1 with the ROW position (pr even) or the COLUMN position (pr odd)
-            const int fi0 = d0 >> 2;
-            const float4 rf = *(const float4*)(cs + ((size_t)gr * NFREQ + fi0) * 2);  // (cos, sin) at fi0, fi0 + 1 for the row
-            const float4 cf = *(const float4*)(cs + ((size_t)gc * NFREQ + fi0) * 2);
-            const float tc[4] = {rf.x, cf.x, rf.z, cf.z}, ts[4] = {rf.y, cf.y, rf.w, cf.w};
+            const float tc[4] = {qrf[s].x, qcf[s].x, qrf[s].z, qcf[s].z}, ts[4] = {qrf[s].y, qcf[s].y, qrf[s].w, qcf[s].w};
             bf8_t o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x2 y = (unpk_bf(raw.w[j]) - mv) * rv * unpk_bf(wv.w[j]) + unpk_bf(bv.w[j]);
+                f32x2 y = (unpk_bf(qraw[s].w[j]) - mv) * rv * unpk_bf(qwv[s].w[j]) + unpk_bf(qbv[s].w[j]);
                 y = f32x2{y[0] * tc[j] - y[1] * ts[j], y[0] * ts[j] + y[1] * tc[j]};
                 o.w[j] = pk_bf(y);
             }

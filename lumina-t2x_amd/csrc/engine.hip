@@ -46,7 +46,8 @@ constexpr float LOG2E = 1.44269504088896340736f;
 //   qkv_fused_gemm   Q | K | V in one launch of the persistent kernel where the shapes allow it
 //   attn_q_fused     q_norm + RoPE of the queries inside the attention prologue (hd 72 one-wave kernel, fused QKV GEMM)
 //   qk_post_pair     1 = q and k post-processing share one persistent launch (large problems)
-//   graph            1 = a model evaluation (~250 launches) is captured into a HIP graph per (arguments, shapes) and replayed.  Every option
+//   graph            1 = a model evaluation (~250 launches) is captured into a HIP graph per (arguments, shapes) and replayed; 2 (default) = above
+//                    1024 rows only (forward_graphed).  Every option
 //                    change moves lt_opt_generation(), which is part of the graph key (kernel selection is baked into a captured graph).
 
 struct DevBuf {
@@ -781,6 +782,13 @@ bool profiling_wants_events(const lt_engine* e) {
 int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* out, const lt_step_args* a, int use_cfg, hipStream_t s) {
     if (!lt_opt(OPT_GRAPH) || profiling_wants_events(e) || e->moe_rec_on || e->moe_force_rows) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
     const int B = a->batch;
+    // "graph" 2 (default): replay above 1024 rows only.  At 512 rows a replay (three staging copies + the graph launch) costs more than it
+    // saves - plain launches are 1.5-4.6 % faster for the 600M ImageNet model, same box (profiles/r05/bench_ab_hip_graph_on_off_cfg1_cfg5.log:
+    // 1.652 against 1.68-1.73 ms per NFE; the MoE model is neutral) - and the host issues its ~125 launches per evaluation in a quarter of
+    // the time the GPU needs for them.  Above that the two are equal and the graph keeps a busy host out of the picture.
+    if (lt_opt(OPT_GRAPH) == 2 && a->latent_h > 0 && a->latent_w > 0 && e->cfg.patch_size > 0 &&
+        (long long)B * (a->latent_h / e->cfg.patch_size) * (a->latent_w / e->cfg.patch_size) <= 1024)
+        return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
     if (B < 1 || B > e->cfg.max_batch || a->latent_h <= 0 || a->latent_w <= 0 || (a->io_dtype != LT_BF16 && a->io_dtype != LT_F32))
         return run_forward(e, x_in, t_dev, out, a, use_cfg, s);  // let the eager path produce the error message
     const size_t sbytes = (size_t)B * e->cfg.in_channels * a->latent_h * a->latent_w * (a->io_dtype == LT_BF16 ? 2 : 4);

@@ -8,7 +8,7 @@
 
 // name, lowest, highest, default, boolean.  include/lumina_dit_debug.h documents what each one selects (tests/test_abi.py keeps the two in step).
 const LtOptDesc kLtOptDesc[LT_OPT_COUNT] = {
-    {"graph", 0, 1, 1, true},
+    {"graph", 0, 2, 2, false},
     {"attention_variant", 1, 6, 4, false},
     {"qkv_post_fused", 0, 2, 2, false},
     {"qkv_vt_epilogue", 0, 1, 1, true},

@@ -509,7 +509,7 @@ def test_hip_graph_replay_is_bit_identical_to_eager_launches(golden_dir):
         eager = runs()
         assert model._engine.graph_replays() - before == replays  # no replay while switched off
     finally:
-        set_option("graph", 1)
+        set_option("graph", 2)
     assert replays >= 8, replays  # 5 + 1 + 1 + 6 evaluations on the main key, minus warm-up and capture
     for a, b in zip(with_graph, eager):
         assert torch.equal(a, b)
@@ -526,18 +526,19 @@ def test_engine_options_are_per_engine_and_do_not_leak(golden_dir):
     z, t, cap, mask = _inputs(g)
     kw = dict(base_seqlen=16, proportional_attn=True)
     run = lambda m: [m.forward_with_cfg(z, t, cap, mask, 4.0, **kw) for _ in range(5)][-1]
-    run(a), run(b)  # engines exist now
-    ea, eb = a._engine, b._engine
-    assert ea.get_option("graph") == 1 and eb.get_option("graph") == 1
-    ea.set_option("graph", 0)
-    assert ea.get_option("graph") == 0 and eb.get_option("graph") == 1
-    ra, rb = ea.graph_replays(), eb.graph_replays()
-    oa, ob = run(a), run(b)
-    assert ea.graph_replays() == ra and eb.graph_replays() > rb
-    assert torch.equal(oa, ob)
-    with pytest.raises(Exception, match="must be"):
-        ea.set_option("gemm_splitk", 7)  # range-checked per engine as well
     try:
+        set_option("graph", 1)  # (the default, 2, replays above 1024 rows only: this model has 128)
+        run(a), run(b)  # engines exist now
+        ea, eb = a._engine, b._engine
+        assert ea.get_option("graph") == 1 and eb.get_option("graph") == 1
+        ea.set_option("graph", 0)
+        assert ea.get_option("graph") == 0 and eb.get_option("graph") == 1
+        ra, rb = ea.graph_replays(), eb.graph_replays()
+        oa, ob = run(a), run(b)
+        assert ea.graph_replays() == ra and eb.graph_replays() > rb
+        assert torch.equal(oa, ob)
+        with pytest.raises(Exception, match="must be"):
+            ea.set_option("gemm_splitk", 7)  # range-checked per engine as well
         set_option("graph", 0)             # process default off: B (no override) stops replaying ...
         rb = eb.graph_replays()
         run(b)
@@ -546,14 +547,19 @@ def test_engine_options_are_per_engine_and_do_not_leak(golden_dir):
         ra = ea.graph_replays()
         run(a)
         assert ea.graph_replays() > ra
-    finally:
         set_option("graph", 1)
-    ea.set_option("graph", None)           # back to inheriting
-    assert ea.get_option("graph") == 1
-    ea.set_option("attention_variant", 3)  # another kernel for A only: B's output is untouched, A's agrees (bit-equal by test_attention_v4_*)
-    assert eb.get_option("attention_variant") == 4
-    assert torch.equal(run(b), ob)
-    ea.set_option("attention_variant", None)
+        ea.set_option("graph", None)           # back to inheriting
+        assert ea.get_option("graph") == 1
+        ea.set_option("attention_variant", 3)  # another kernel for A only: B's output is untouched, A's agrees (bit-equal by test_attention_v4_*)
+        assert eb.get_option("attention_variant") == 4
+        assert torch.equal(run(b), ob)
+        ea.set_option("attention_variant", None)
+        # the default: replay above 1024 rows only - this 128-row model runs plain launches under it
+        set_option("graph", 2)
+        rb = eb.graph_replays()
+        assert torch.equal(run(b), ob) and eb.graph_replays() == rb
+    finally:
+        set_option("graph", 2)
 
 
 def test_hip_graph_replay_rebuilds_the_shared_rope_table_when_keys_alternate(golden_dir):
@@ -582,7 +588,7 @@ def test_hip_graph_replay_rebuilds_the_shared_rope_table_when_keys_alternate(gol
         set_option("graph", 0)
         eager = runs()
     finally:
-        set_option("graph", 1)
+        set_option("graph", 2)
     assert replays >= 6, replays
     assert not torch.equal(eager[0], eager[3])  # the two keys really differ (NTK branch at t = 0.8)
     for i, (a, b) in enumerate(zip(with_graph, eager)):

@@ -355,7 +355,7 @@ def test_regional_caption_buffer_growth_drops_cached_graphs(golden_dir):
         replays = model._engine.graph_replays()
         assert model._engine.limits.max_batch == 8  # one engine throughout: the growth happened inside it
     finally:
-        set_option("graph", 1)
+        set_option("graph", 2)
     assert replays >= 4, replays
     for i, (a, b) in enumerate(zip(graphed, eager)):
         assert torch.equal(a, b), i
