@@ -260,6 +260,14 @@ int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
     const dim3 grid(nblk);
     if (a.moe_pos) {  // y = top-2 combine of the experts' outputs (MoE families: d = 1536 ... 4096)
         LT_REQUIRE(a.moe_ys && a.moe_wts, "gated_residual_norm: incomplete MoE combine arguments");
+        // the 600M MoE's combination (d = 1536, weighted post-norm, prepared gate, next pre-norm or the final LayerNorm) with its mode switches
+        // fixed at compile time, like the dense instantiations below (round 5; same statements in the same order: bit-identical)
+        if (lt_opt(OPT_NORM_SPECIALIZE) && !a.apex && a.gate_mode == 0 && a.post_mode == 1 && (a.next_mode == 1 || a.next_mode == 2) && ((a.d >> 3) + 63) / 64 == 3) {
+            if (a.next_mode == 1) hipLaunchKernelGGL((gated_residual_norm_kernel<3, 1, 0, 1, true>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((gated_residual_norm_kernel<3, 1, 0, 2, true>), grid, dim3(256), 0, stream, a);
+            LT_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
         switch (((a.d >> 3) + 63) / 64) {
             case 1: hipLaunchKernelGGL((gated_residual_norm_kernel<1, -1, -1, -1, true>), grid, dim3(256), 0, stream, a); break;
             case 2: hipLaunchKernelGGL((gated_residual_norm_kernel<2, -1, -1, -1, true>), grid, dim3(256), 0, stream, a); break;

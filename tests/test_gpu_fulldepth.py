@@ -182,6 +182,19 @@ def test_full_moe_600m_16_layers_vs_reference(golden_dir):
     g1, g2 = _load(golden_dir, "full_moe600m")[0], _load(golden_dir, "full_moe600m_256")[0]
     assert int(g1["seed_w"]) == int(g2["seed_w"]) and np.array_equal(g1["wsum"], g2["wsum"])
     _, model = _check("full_moe600m_256", golden_dir, ctor, model=model, keep=True)
+    # round 5: the MoE row kernel (top-2 combine + gated residual + next pre-norm) runs mode-specialised instantiations at d = 1536 - the
+    # same statements in the same order as the generic kernel, so the whole 16-layer forward must not move by a bit
+    from gpu_util import set_option
+    cfg2 = synth.NextDiTConfig(**json.loads(str(g2["config"])))
+    ins = _inputs(g2, cfg2, 0.5)
+    zb = ins[0].to("cuda", torch.bfloat16)
+    spec = model.forward_with_cfg(zb, ins[1].cuda(), ins[2].cuda(), 4.0)
+    try:
+        set_option("norm_specialize", 0)
+        generic = model.forward_with_cfg(zb, ins[1].cuda(), ins[2].cuda(), 4.0)
+    finally:
+        set_option("norm_specialize", 1)
+    assert torch.equal(spec, generic)
     # BASELINE configs[4] as worded, 1024 x 1024: 4096 tokens, 16 384 routed rows per MoE FFN on the grouped persistent GEMM
     g3 = _load(golden_dir, "full_moe600m_4096")[0]
     assert int(g1["seed_w"]) == int(g3["seed_w"]) and np.array_equal(g1["wsum"], g3["wsum"]) and tuple(g3["latent_hw"]) == (128, 128)
