@@ -16,7 +16,7 @@
 #   sh:<command>               anything else ('+' for spaces)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${LT_ROUND:-r4}
+ROUND=${LT_ROUND:-r5}
 TAG=$1; shift
 OUT=$R/gpurun_out/$ROUND/$TAG
 mkdir -p "$OUT"
