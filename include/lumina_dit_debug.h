@@ -57,6 +57,10 @@ extern "C" {
  *                       k_norm, RoPE, the V transpose and the attention itself are ONE launch that reads the QKV projection's output and the
  *                       per-tile LayerNorm partials its GEMM epilogue left (round 5: one launch boundary less per layer where every launch
  *                       is latency-bound) | 0: q / k / v post-processing launch + attention launch
+ *   "moe_route_fused"   (0..1, 1): Next-DiT-MoE with both MoE layers per block (models2.py): the row kernel between the time and the space layer
+ *                       (combine + gated residual + pre-norm) also routes the space layer - it has the router's input row in registers:
+ *                       bf16 logits, top-2, fp32 softmax, bf16 weights, moe_route_kernel's arithmetic statement for statement, bit-identical
+ *                       selections (round 5: one launch less per layer) | 0: a separate routing launch
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

@@ -398,7 +398,8 @@ int ensure_rope(lt_engine* e, const lt_step_args* a, hipStream_t s) {
 
 // one MoE feed-forward (branch 0 = TimeMoeLayer on the timestep embedding, 1 = SpaceMoeLayer on the tokens;
 // models2.py:451-506): e->h -> e->o
-int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B, hipStream_t s) {
+// routed: sel / wts of this (token-routed) branch were already written by the row kernel that produced its input (GatedResArgs::route_*)
+int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B, hipStream_t s, bool routed = false) {
     const int d = e->d, F = e->F;
     MoeArgs m;
     m.x = e->h; m.rows = M; m.rows_per_sample = N; m.d = d; m.E = e->E;
@@ -422,7 +423,7 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
             LT_REQUIRE(e->moe_force_rows == M, "forced MoE routing was given for %d rows, this call has %d", e->moe_force_rows, M);
             m.forced = e->moe_force + slot;
         }
-        if (branch != 0 && launch_moe_route(m, s)) return 1;  // (the time branch routes inside the plan kernel)
+        if (branch != 0 && !routed && launch_moe_route(m, s)) return 1;  // (the time branch routes inside the plan kernel)
         if (launch_moe_plan(m, s)) return 1;
         if (e->moe_rec_on) {
             LT_CHECK_HIP(hipMemcpyAsync(e->moe_rec + slot, e->moe_sel, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
@@ -719,9 +720,18 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 g.x = e->x; moe_y(e, g); g.post_w = w.norm_time; g.gate = chunk(l, 3); g.post_mode = 1; g.gate_mode = 0;
                 g.next_w = nullptr; g.next_scale = chunk(l, 4); g.next_shift = nullptr; g.next_mode = 1; g.h = e->h;
                 g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
+                // round 5 (option moe_route_fused): h is the space router's input and this kernel holds the row - it routes on its way out
+                // (one launch less per layer; moe_route_kernel's arithmetic, statement for statement)
+                if (lt_opt(OPT_MOE_ROUTE_FUSED)) {
+                    g.route_w = w.gate_s; g.route_E = e->E; g.route_sel = e->moe_sel; g.route_wts = e->moe_wts;
+                    if (e->moe_force_rows) {
+                        LT_REQUIRE(e->moe_force_rows == M, "forced MoE routing was given for %d rows, this call has %d", e->moe_force_rows, M);
+                        g.route_forced = e->moe_force + ((size_t)l * 2 + 1) * (size_t)e->cfg.max_batch * e->cfg.max_tokens * 2;
+                    }
+                }
                 if (launch_gated_residual_norm(g, s)) return 1;
             }
-            if (moe_ffn(e, w, l, 1, M, N, B, s)) return 1;
+            if (moe_ffn(e, w, l, 1, M, N, B, s, lt_opt(OPT_MOE_ROUTE_FUSED) != 0)) return 1;
             last_post_w = w.norm_space;
             last_gate = chunk(l, 5);
         }

@@ -104,6 +104,14 @@ struct GatedResArgs {
     const int* moe_pos = nullptr;
     const u16* moe_wts = nullptr;
     PrefetchRider pf;  // weight panels of the GEMM that follows, read by extra workgroups of this launch (512-row-class problems)
+    // round 5 (MoE kernels, next_mode 1): h is the input of a token-routed MoE layer - the row kernel has the row in registers and routes it on
+    // its way out: logits = bf16(h . route_w[e]) (nn.Linear under autocast), top-2, fp32 softmax, bf16 weights -> route_sel / route_wts
+    // ([rows][2], MoeArgs::sel / wts), exactly moe_route_kernel's arithmetic; route_forced: the parity hook's [rows][2] expert ids or null
+    const u16* route_w = nullptr;  // [route_E, d] bf16
+    int route_E = 0;
+    int* route_sel = nullptr;
+    u16* route_wts = nullptr;
+    const int* route_forced = nullptr;
 };
 int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream);
 

@@ -16,36 +16,12 @@
 // routes every token on its own FFN input.  Both go through the same four kernels.
 #include "common.h"
 #include "kernels.h"
+#include "moe_route.h"
 
 namespace {
 
-constexpr int MAX_E = 8;
+constexpr int MAX_E = LT_MOE_MAX_E;
 constexpr int TILE = 256;
-
-// top-2 of E logits (lowest index wins ties), fp32 softmax over the two, bf16 weights; (sel, wts) in ascending expert id
-__device__ __forceinline__ void top2_route(const float (&logit)[MAX_E], const int* forced2, int& s0, int& s1, u16& w0, u16& w1) {
-    int i1 = 0;
-#pragma unroll
-    for (int e = 1; e < MAX_E; ++e) if (logit[e] > logit[i1]) i1 = e;
-    int i2 = i1 == 0 ? 1 : 0;
-#pragma unroll
-    for (int e = 0; e < MAX_E; ++e) if (e != i1 && e != i2 && logit[e] > logit[i2]) i2 = e;
-    if (forced2) {  // the discrete choice comes from outside (a reference run's); the weights stay this run's own arithmetic
-        i1 = forced2[0];
-        i2 = forced2[1];
-    }
-    float l1 = 0.f, l2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < MAX_E; ++e) { l1 = e == i1 ? logit[e] : l1; l2 = e == i2 ? logit[e] : l2; }
-    // softmax over (v1, v2) in fp32, then the cast back to the activation dtype (:466-470)
-    const float ex = __expf(l2 - l1);
-    const float wa = 1.0f / (1.0f + ex), wb = ex / (1.0f + ex);
-    const bool swap = i2 < i1;  // accumulate in ascending expert id
-    s0 = swap ? i2 : i1;
-    s1 = swap ? i1 : i2;
-    w0 = f2bf(swap ? wb : wa);
-    w1 = f2bf(swap ? wa : wb);
-}
 
 __global__ __launch_bounds__(256) void moe_route_kernel(MoeArgs p) {
     const int lane = threadIdx.x & 63;
@@ -62,19 +38,7 @@ __global__ __launch_bounds__(256) void moe_route_kernel(MoeArgs p) {
         for (int e = 0; e < MAX_E; ++e) acc[e] = 0.f;
         const int nch = p.d >> 3;
         const u16* xr = p.x + (size_t)row * p.d;
-        for (int c = lane; c < nch; c += 64) {
-            float xf[8];
-            unpack8(*(const bf8_t*)(xr + c * 8), xf);
-#pragma unroll
-            for (int e = 0; e < MAX_E; ++e) {
-                if (e < p.E) {
-                    float wf[8];
-                    unpack8(*(const bf8_t*)(p.gate_w + (size_t)e * p.d + c * 8), wf);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[e] += xf[i] * wf[i];
-                }
-            }
-        }
+        for (int c = lane; c < nch; c += 64) route_accumulate(*(const bf8_t*)(xr + c * 8), p.gate_w, p.E, p.d, c, acc);
 #pragma unroll
         for (int e = 0; e < MAX_E; ++e) logit[e] = e < p.E ? bfr(wave_sum(acc[e])) : -INFINITY;  // nn.Linear output in bf16
     }

@@ -10,6 +10,7 @@
 // lane per chunk; wave shuffles for the reductions; no LDS, no barrier).
 #include "common.h"
 #include "kernels.h"
+#include "moe_route.h"
 #include "options.h"
 #include "tile_order.h"
 
@@ -58,7 +59,8 @@ __device__ __forceinline__ float row_sumsq(const RowRaw<MAXCH>& r) {
 // apex.FusedRMSNorm; DESIGN.md 6 on why the default order is expected to match an apex box as well)
 template <int MAXCH>
 __device__ __forceinline__ void apply_rms_mod_store(const RowRaw<MAXCH>& r, float rinv, const u16* w, const u16* scale,
-                                                    const u16* shift, int scale_pre, u16* out, int nch, int lane, int apex = 0) {
+                                                    const u16* shift, int scale_pre, u16* out, int nch, int lane, int apex = 0,
+                                                    const u16* route_w = nullptr, int route_E = 0, int d = 0, float* route_acc = nullptr) {
     const f32x2 rv = {rinv, rinv};
     const f32x2 one = {1.f, 1.f};
 #pragma unroll
@@ -78,6 +80,10 @@ __device__ __forceinline__ void apply_rms_mod_store(const RowRaw<MAXCH>& r, floa
                 o.w[k] = pk_bf(n);
             }
             *(bf8_t*)(out + ch * 8) = o;
+            if (route_w) {  // (a literal nullptr from every instantiation but the MoE ones: folds away)
+                float (&ra)[LT_MOE_MAX_E] = *reinterpret_cast<float (*)[LT_MOE_MAX_E]>(route_acc);
+                route_accumulate(o, route_w, route_E, d, ch, ra);
+            }
         }
     }
 }
@@ -170,6 +176,28 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
     u16* hrow = p.h + (size_t)row * p.d;
     if (next_mode == 1) {
         const float r2 = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
+        if constexpr (MOE) {
+            if (p.route_w) {  // the row is the input of a token-routed MoE layer: route it here (GatedResArgs::route_*), wave-uniform
+                float racc[LT_MOE_MAX_E];
+#pragma unroll
+                for (int e = 0; e < LT_MOE_MAX_E; ++e) racc[e] = 0.f;
+                apply_rms_mod_store(r, r2, p.next_w, nscale, nshift, p.scale_pre, hrow, nch, lane, apex, p.route_w, p.route_E, p.d, racc);
+                float logit[LT_MOE_MAX_E];
+#pragma unroll
+                for (int e = 0; e < LT_MOE_MAX_E; ++e) logit[e] = e < p.route_E ? bfr(wave_sum(racc[e])) : -INFINITY;  // nn.Linear output in bf16
+                if (lane == 0) {
+                    int s0, s1;
+                    u16 w0, w1;
+                    top2_route(logit, p.route_forced ? p.route_forced + 2 * row : nullptr, s0, s1, w0, w1);
+                    p.route_sel[2 * row] = s0;
+                    p.route_sel[2 * row + 1] = s1;
+                    // (the wave read moe_wts[2 row ..] of the branch it consumed at its start; nobody else reads this row's pair)
+                    p.route_wts[2 * row] = w0;
+                    p.route_wts[2 * row + 1] = w1;
+                }
+                return;
+            }
+        }
         apply_rms_mod_store(r, r2, p.next_w, nscale, nshift, p.scale_pre, hrow, nch, lane, apex);
     } else {
         // affine-free LayerNorm in fp32, modulate in fp32, one rounding (the cast autocast applies at the
@@ -250,6 +278,8 @@ int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
     LT_REQUIRE(a.y != nullptr || a.moe_pos != nullptr, "gated_residual_norm: branch output missing");
     LT_REQUIRE(a.post_mode == 0 || a.post_w != nullptr, "gated_residual_norm: post-norm weight missing");
     LT_REQUIRE(a.next_mode == 0 || a.h != nullptr, "gated_residual_norm: h output missing");
+    LT_REQUIRE(a.route_w == nullptr || (a.moe_pos && a.next_mode == 1 && a.route_sel && a.route_wts && a.route_E >= 2 && a.route_E <= LT_MOE_MAX_E),
+               "gated_residual_norm: routing on the way out needs the MoE kernel, next_mode 1, 2 <= E <= %d and the sel / wts outputs", LT_MOE_MAX_E);
     int nblk = (a.rows + 3) / 4;
     if (a.pf.blocks > 0) {  // riders behind the row blocks, from a multiple of 8 on (block index mod 8 = XCD)
         a.pf.first = (nblk + 7) / 8 * 8;

@@ -25,6 +25,7 @@ const LtOptDesc kLtOptDesc[LT_OPT_COUNT] = {
     {"gemm_variant", 0, 2, 0, false},
     {"rmsnorm_apex", 0, 1, 0, true},
     {"attn_small_fused", 0, 1, 1, true},
+    {"moe_route_fused", 0, 1, 1, true},
 };
 
 namespace {

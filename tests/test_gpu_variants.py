@@ -180,6 +180,24 @@ def test_moe_engine_matches_reference_golden(golden_dir):
     fc = rel_l2(c16, ref)
     assert rel_l2(got, ref) < max(TOL_CFG4, 1.5 * fc), (rel_l2(got, ref), fc)
     assert torch.equal(got[0, :3], got[1, :3])
+    # round 5 (option moe_route_fused, default on): the row kernel between the time and the space MoE layer routes the space layer on its
+    # way out - moe_route_kernel's arithmetic statement for statement.  The separate routing launch must select the same experts with the
+    # same weights in every layer, i.e. the whole forward must not move by a bit; the recorded selections say that the hook sees both
+    from gpu_util import set_option
+    eng = model._engine
+    rows = 2 * (z.shape[2] // 2) * (z.shape[3] // 2)
+    eng.moe_routing_record(True)
+    try:
+        fused = model.forward_with_cfg(z, t, y, 4.0)
+        sel_fused = eng.moe_routing_read(rows).copy()
+        set_option("moe_route_fused", 0)
+        split = model.forward_with_cfg(z, t, y, 4.0)
+        sel_split = eng.moe_routing_read(rows).copy()
+    finally:
+        set_option("moe_route_fused", 1)
+        eng.moe_routing_record(False)
+    assert torch.equal(fused, got) and np.array_equal(sel_fused, sel_split) and (sel_fused[:, 1] >= 0).all()
+    assert torch.equal(split, fused)
 
 
 @pytest.mark.parametrize("name,ctor", [("moe_time_tiny", "DiT_Llama_TimeMoE"), ("moe_space_tiny", "DiT_Llama_SpaceMoE")])
