@@ -232,6 +232,12 @@ int lt_op_moe_plan(void* sel_dev, const void* sample_logits_dev, void* wts_dev, 
  * stream-ordered.  Result: bf16(fp32 sum of the two halves' fp32 partial sums) - independent of which half finishes last. */
 int lt_op_gemm_splitk(const void* A_dev, const void* W_dev, void* C_dev, int32_t M, int32_t N, int32_t K, void* part_f32_dev,
                       void* counters_u32_dev, int32_t tiles, void* stream);
+/* lt_op_gemm_splitk with the tile shape and the split left to the launcher, exactly as the engine calls it (variant 0): slots of
+ * [2][64 * 128] floats in part_f32 and one counter each; a dense plain-epilogue small-M problem splits K two ways on 64 x 128 tiles (one slot per
+ * tile, K >= 1024) or - round 5, K >= 4096, K % 1024 == 0, 4 x ceil(M / 128) x ceil(N / 128) <= #CUs and <= slots - four ways on 128 x 128 tiles
+ * (four slots per tile; the last arriver sums the four fp32 partials in K order), else runs unsplit. */
+int lt_op_gemm_splitk_auto(const void* A_dev, const void* W_dev, void* C_dev, int32_t M, int32_t N, int32_t K, void* part_f32_dev,
+                           void* counters_u32_dev, int32_t slots, void* stream);
 /* grouped (mixture-of-experts) form of lt_op_gemm_bf16 - replaces the per-expert Python loop `for i, expert in
  * enumerate(self.experts): ... expert(x[batch_idx])` of Next-DiT-MoE/models/models2.py:470-476, :499-505 on expert-sorted
  * rows: rows [256 t, 256 t + 256) of A multiply with W_dev + tile_expert[t] * w_expert_stride (elements); tile_expert[t] < 0

@@ -61,6 +61,9 @@ extern "C" {
  *                       (combine + gated residual + pre-norm) also routes the space layer - it has the router's input row in registers:
  *                       bf16 logits, top-2, fp32 softmax, bf16 weights, moe_route_kernel's arithmetic statement for statement, bit-identical
  *                       selections (round 5: one launch less per layer) | 0: a separate routing launch
+ *   "gemm_splitk4"      (0..1, 1): with "gemm_splitk" on, a dense small-M plain-epilogue GEMM with K >= 4096 (the 512-row w2 projection) runs on
+ *                       128 x 128 tiles with K split FOUR ways when that still fits one round of the CUs; the last arriver sums the four
+ *                       fp32 partials in K order (round 5) | 0: the two-way split on 64 x 128 tiles
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

@@ -101,6 +101,7 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_op_gemm_describe": (_i32, [_i32, _i32, _i32, _i32, _i32, C.c_char_p, _i32]),
     "lt_op_moe_plan": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "lt_op_gemm_splitk": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "lt_op_gemm_splitk_auto": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "lt_op_gemm_grouped": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_grouped_gather": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_pack_w13": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),

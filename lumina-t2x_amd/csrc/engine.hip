@@ -1014,7 +1014,7 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
     }
     {   // split-K workspace (zeroed by dev_alloc: the counters must start at 0; every launch leaves them at 0)
         void* q;
-        e->splitk_tiles = 128;
+        e->splitk_tiles = 256;  // slots of [2][64 x 128] floats (a 64 x 128 tile split two ways; a 128 x 128 tile split four ways takes four)
         if (dev_alloc(e, &q, (size_t)e->splitk_tiles * 2 * 64 * 128 * sizeof(float))) return fail();
         e->splitk_part = (float*)q;
         if (dev_alloc(e, &q, (size_t)e->splitk_tiles * sizeof(unsigned))) return fail();
@@ -1606,6 +1606,18 @@ extern "C" int lt_op_gemm_splitk(const void* A, const void* W, void* C, int32_t 
     g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.bias_dtype = -1; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
     g.splitk_part = (float*)part_f32; g.splitk_cnt = (unsigned*)counters_u32; g.splitk_tiles = tiles;
     return launch_gemm_bf16(g, 0, 8, (hipStream_t)stream);  // variant 8 = the 64 x 128 tile, the only one that splits
+}
+
+// the same workspace with the kernel and the split left to the launcher, as in the engine (variant 0): two ways on 64 x 128 tiles, or - round 5,
+// K >= 4096 - four ways on 128 x 128 tiles, or none
+extern "C" int lt_op_gemm_splitk_auto(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, void* part_f32, void* counters_u32,
+                                      int32_t slots, void* stream) {
+    LT_REQUIRE(A && W && C && part_f32 && counters_u32, "lt_op_gemm_splitk_auto: null pointer");
+    LT_REQUIRE(M > 0 && N > 0 && K > 0, "lt_op_gemm_splitk_auto: empty problem");
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.bias_dtype = -1; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+    g.splitk_part = (float*)part_f32; g.splitk_cnt = (unsigned*)counters_u32; g.splitk_tiles = slots;
+    return launch_gemm_bf16(g, 0, 0, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_gemm_grouped(const void* A, const void* W, const void* tile_expert, int64_t w_expert_stride, void* C,

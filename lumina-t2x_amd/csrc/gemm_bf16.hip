@@ -127,7 +127,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t
     else fn = (const void*)gemm_bf16_tn<WM, WN, MT, NT, EPI>;
     if (ensure_dynamic_lds(fn, SMEM)) return 1;
     const int TM = (a.M + BM - 1) / BM, TN = (a.N + BN - 1) / BN;
-    const dim3 grid(TM * TN * (a.split_k == 2 ? 2 : 1)), block(WM * WN * 64);
+    const dim3 grid(TM * TN * (a.split_k >= 2 ? a.split_k : 1)), block(WM * WN * 64);
     if constexpr (PP) {
         if (ev0) hipExtLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, 0, MODE, KS>), grid, block, SMEM, stream, ev0, ev1, 0, a);
         else hipLaunchKernelGGL((gemm_bf16_pp<WM, WN, MT, NT, EPI, false, 0, MODE, KS>), grid, block, SMEM, stream, a);
@@ -268,13 +268,22 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
     }
     LT_REQUIRE(epilogue != 1 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
     LT_REQUIRE(variant >= 0 && variant <= 18, "gemm: unknown variant %d", variant);
-    const GemmKernel k = choose(a, epilogue, variant);
+    GemmKernel k = choose(a, epilogue, variant);
     // split-K: dense plain-epilogue problems on the 64 x 128 tiles whose two halves still fit one round of the CUs, K >= 1024
     a.split_k = 0;
     if (k == GK_S64 && lt_opt(OPT_GEMM_SPLITK) && (variant == 0 || variant == 8) && a.splitk_part && a.splitk_cnt && !a.tile_expert && !a.a_row_map && a.bias_dtype < 0 &&
         a.K >= 1024 && a.K % 512 == 0) {
         const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
         if ((2 * tiles <= num_cus() || lt_opt(OPT_GEMM_SPLITK) == 2) && tiles <= a.splitk_tiles) a.split_k = 2;
+    }
+    // ... and four ways on the 128 x 128 tile where K is long (round 5, option gemm_splitk4; the 512-row w2 projection of the 600M models:
+    // K = 4096): a 64 x 128 half stages (64 + 128) x 2048 x 2 = 786 KB through its CU, a quarter of a 128 x 128 tile (128 + 128) x 1024 x 2 =
+    // 524 KB - the same 192 workgroups, a third less per workgroup (NOTEBOOK.md 9.3 priced it at 4 us per layer).  The last arriver sums
+    // the four partials in K order, so the result is independent of the arrival order here too.
+    if ((k == GK_S64 || k == GK_S128) && epilogue == 0 && variant == 0 && lt_opt(OPT_GEMM_SPLITK) && lt_opt(OPT_GEMM_SPLITK4) && a.splitk_part && a.splitk_cnt &&
+        !a.tile_expert && !a.a_row_map && a.bias_dtype < 0 && !a.rowstat && a.K >= 4096 && a.K % 1024 == 0) {
+        const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+        if (4 * t128 <= num_cus() && 4 * t128 <= a.splitk_tiles) { k = GK_S128; a.split_k = 4; }  // (a 128 x 128 part takes two [2][64 x 128] slots, four parts per tile)
     }
     if (a.rowstat) {
         LT_REQUIRE((k == GK_S128 || k == GK_S64) && epilogue == 0, "gemm: rowstat is written by the small-M tiles' plain epilogue only (this problem runs %s)", kGemmKernelName[k]);

@@ -315,11 +315,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 
     const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
     int tm, tn;
-    // split-K (GemmArgs::split_k == 2): workgroups [0, tiles) take the first half of K, [tiles, 2 tiles) the second half of the same tiles
+    // split-K (GemmArgs::split_k = S = 2 or 4): workgroups [j tiles, (j + 1) tiles) take the j-th of S equal K ranges of the same tiles
     const int ntile = TM * TN;
-    const int ksplit = p.split_k == 2 ? (int)blockIdx.x / ntile : 0;
-    const int bid = p.split_k == 2 ? (int)blockIdx.x - ksplit * ntile : (int)blockIdx.x;
-    tile_coords(bid, p.split_k == 2 ? ntile : (int)gridDim.x, TM, TN, tm, tn);
+    const int S = p.split_k >= 2 ? p.split_k : 1;
+    const int ksplit = S > 1 ? (int)blockIdx.x / ntile : 0;
+    const int bid = S > 1 ? (int)blockIdx.x - ksplit * ntile : (int)blockIdx.x;
+    tile_coords(bid, S > 1 ? ntile : (int)gridDim.x, TM, TN, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const long long a_left = (long long)(p.M - m0) * p.lda * 2;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         }
         ldsoff[i] = q * 1024;
     }
-    const int kbase = p.split_k == 2 ? ksplit * p.K : 0;  // byte offset along K of this workgroup's range (K / 2 elements = K bytes)
+    const int kbase = S > 1 ? ksplit * (p.K / S) * 2 : 0;  // byte offset along K of this workgroup's range (K / S elements)
     auto stage = [&](int slab) {
         char* base = smem + (slab & 3) * SLAB;
         const int soff = kbase + slab * RB;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int ns = (p.split_k == 2 ? p.K / 2 : p.K) / (16 * KS);
+    const int ns = (p.K / S) / (16 * KS);
     if constexpr (MODE == 2 && G == 1) stagger_start(p.stagger);  // 4-wave kernel only (variant 10)
     // prologue: slabs 0..2 in flight, slab 0 landed and visible
     stage(0);
@@ -713,9 +714,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
     if constexpr (TRACE) t_loop_end = __builtin_amdgcn_s_memtime();
 
     if constexpr (MODE == 1 && KS == 4 && !TRACE)  // (the small-M tiles only: keeps the 256-wide instantiations' code as it was)
-    if (p.split_k == 2) {
-        // Both halves park their fp32 partial (register image, [register quad][thread] = coalesced 16-byte accesses); the second
-        // arriver at the tile's counter adds the first one's and stores the tile.  The two workgroups may sit on different XCDs, whose
+    if (S > 1) {
+        // Every part parks its fp32 partial (register image, [register quad][thread] = coalesced 16-byte accesses); the LAST arriver at
+        // the tile's counter adds the others' and stores the tile (S = 2: a + b commutes; S = 4, round 5: summed in K-range order whichever
+        // part arrives last, so the result does not depend on the arrival order either).  The two workgroups may sit on different XCDs, whose
         // L2s are not coherent: the partials are stored and loaded SYSTEM-coherent (sc0 sc1: written through to / read from the memory
         // side) and the counter is a system-scope atomic.  NOT __threadfence(): an agent-scope release / acquire on this part is
         // buffer_wbl2 + buffer_inv - a write-back and invalidate of the XCD's whole 4 MiB L2 - and made every split GEMM 40 us slower.
@@ -729,8 +731,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         // concurrent L2-thrashing stream and checks every output word of every launch.
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
         constexpr int PART_BYTES = BM * BN * 4, CP = 17;  // aux bits: sc0 | sc1
-        const __amdgpu_buffer_rsrc_t rMine = __builtin_amdgcn_make_buffer_rsrc((void*)(p.splitk_part + ((size_t)bid * 2 + ksplit) * (BM * BN)), 0, PART_BYTES, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rOther = __builtin_amdgcn_make_buffer_rsrc((void*)(p.splitk_part + ((size_t)bid * 2 + (1 - ksplit)) * (BM * BN)), 0, PART_BYTES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rMine = __builtin_amdgcn_make_buffer_rsrc((void*)(p.splitk_part + ((size_t)bid * S + ksplit) * (BM * BN)), 0, PART_BYTES, 0x00020000);
+        // (all S partials of the tile behind one descriptor: part j at byte offset j * PART_BYTES)
+        const __amdgpu_buffer_rsrc_t rAll = __builtin_amdgcn_make_buffer_rsrc((void*)(p.splitk_part + (size_t)bid * S * (BM * BN)), 0, S * PART_BYTES, 0x00020000);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -745,21 +748,45 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_bf16_pp(G
         int* flag = (int*)smem;  // (the slab ring is idle: every wave is past its last fragment read)
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(p.splitk_cnt + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (old == 1u) __hip_atomic_store(p.splitk_cnt + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // both arrived: free for the next launch
+            if (old == (unsigned)(S - 1)) __hip_atomic_store(p.splitk_cnt + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // all arrived: free for the next launch
             *flag = (int)old;
         }
         __syncthreads();
-        if (*flag == 0) return;  // first arriver (uniform)
+        if (*flag != S - 1) return;  // not the last arriver (uniform)
+        if (S == 2) {  // own + other (fp32 addition commutes)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rOther, (((mt * NT + nt) * 4 + q) * (NW * 64) + tid) * 16, 0, CP));
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rAll, (((mt * NT + nt) * 4 + q) * (NW * 64) + tid) * 16, (1 - ksplit) * PART_BYTES, CP));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[mt][nt][4 * q + j] += o[j];
-                }
+                        for (int j = 0; j < 4; ++j) acc[mt][nt][4 * q + j] += o[j];
+                    }
+        } else {  // ((p0 + p1) + p2) + p3 with this workgroup's own part taken from its registers, whichever position it has
+            f32x16 tot[MT][NT];
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                if (part >= S) break;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 o = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                            if (part != ksplit)  // (uniform)
+                                o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rAll, (((mt * NT + nt) * 4 + q) * (NW * 64) + tid) * 16, part * PART_BYTES, CP));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) tot[mt][nt][4 * q + j] = part == 0 ? o[j] : tot[mt][nt][4 * q + j] + o[j];
+                        }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = tot[mt][nt];
+        }
     }
     store_tile<MT, NT, EPI>(acc, p, m0, n0, wm, wn, hi, l31);
 

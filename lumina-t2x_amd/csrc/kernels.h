@@ -37,7 +37,7 @@ struct GemmArgs {
     float* splitk_part = nullptr;    // [splitk_tiles][2][64 * 128] fp32, or null: never split
     unsigned* splitk_cnt = nullptr;  // [splitk_tiles], zero between launches
     int splitk_tiles = 0;
-    int split_k = 0;                 // set by the launcher: 0 off, 2 two halves
+    int split_k = 0;                 // set by the launcher: 0 off, 2 two halves (64 x 128 tiles), 4 four quarters (128 x 128 tiles, round 5)
     // epilogue 3, round 4: LayerNorm statistics of the Q columns on the way out.  Every plain tile whose first column lies below
     // qstat_cols (= the Q width) adds, per row and per wave column-half, (sum, sum of squares) of its bf16-ROUNDED outputs to
     // qstat[row][slot] with slot = 2 * (n0 / BN) + wn  (float2; qstat_slots = 2 * qstat_cols / BN per row).  The attention kernel's

@@ -26,6 +26,7 @@ const LtOptDesc kLtOptDesc[LT_OPT_COUNT] = {
     {"rmsnorm_apex", 0, 1, 0, true},
     {"attn_small_fused", 0, 1, 1, true},
     {"moe_route_fused", 0, 1, 1, true},
+    {"gemm_splitk4", 0, 1, 1, true},
 };
 
 namespace {

@@ -222,6 +222,53 @@ def test_gemm_splitk_small_m(M, N, K, force):
     assert rel_l2(outs[0], plain) < 2e-3, rel_l2(outs[0], plain)
 
 
+@pytest.mark.parametrize("M,N,K,parts", [(512, 1536, 4096, 4),    # the 600M models' w2: 48 tiles of 128 x 128, four K quarters each = 192 workgroups
+                                          (500, 1528, 8192, 4),    # ragged M / N, 64 slabs per quarter
+                                          (512, 1536, 1536, 2),    # their O projection: K below the four-way bound -> two halves on 64 x 128 tiles
+                                          (1024, 2304, 4096, 0)])  # 8 x 18 tiles x 4 > #CUs: unsplit
+def test_gemm_splitk_four_ways_on_128_tiles(M, N, K, parts):
+    """round 5 (option gemm_splitk4): K split four ways on 128 x 128 tiles, the last arriver sums the four fp32 partials in K order.  Through
+    the launcher's own decision (lt_op_gemm_splitk_auto = what the engine calls): against the unsplit kernel (fp32 rounding of three
+    additions) and the fp32 reference; counters back at zero; the same bits from a second launch and from 40 more (arrival order varies);
+    option off -> the round-4 two-way form."""
+    g = torch.Generator().manual_seed(M + N + K + 5)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    slots = 256
+    part = torch.full((slots * 2 * 64 * 128,), float("nan"), device="cuda", dtype=torch.float32)
+    cnt = torch.zeros(slots, device="cuda", dtype=torch.int32)
+    plain = _gemm(A, W, variant=7)
+
+    def run():
+        out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ok(lib().lt_op_gemm_splitk_auto(P(A), P(W), P(out), M, N, K, P(part), P(cnt), slots, stream()), "gemm_splitk_auto")
+        return out
+
+    first = run()
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0, "a tile counter was left non-zero"
+    touched = int((~torch.isnan(part)).sum())
+    t128, t64 = ((M + 127) // 128) * ((N + 127) // 128), ((M + 63) // 64) * ((N + 127) // 128)
+    assert touched == {4: t128 * 4 * 128 * 128, 2: t64 * 2 * 64 * 128, 0: 0}[parts], (touched, parts)
+    for _ in range(40):
+        assert torch.equal(run(), first)
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0
+    assert not torch.isnan(first.float()).any()
+    assert rel_l2(first, A.float() @ W.float().t()) < 4e-3
+    assert rel_l2(first, plain) < 2e-3, rel_l2(first, plain)
+    if parts == 4:
+        set_option("gemm_splitk4", 0)
+        try:
+            part.fill_(float("nan"))
+            two = run()
+            torch.cuda.synchronize()
+        finally:
+            set_option("gemm_splitk4", 1)
+        assert int((~torch.isnan(part)).sum()) in (0, t64 * 2 * 64 * 128)  # two halves on 64 x 128 tiles where those fit one round, else unsplit
+        assert rel_l2(two, first) < 2e-3
+
+
 def test_gemm_splitk_handoff_stress():
     """the split-K halves of a tile hand their fp32 partials over between two workgroups that may sit on different XCDs (sc0 sc1
     stores -> s_waitcnt vmcnt(0) -> relaxed system-scope counter -> sc0 sc1 loads, no L2-wide fence).  A stale read would silently corrupt
@@ -233,16 +280,19 @@ def test_gemm_splitk_handoff_stress():
     thrash_dst = torch.empty_like(thrash_src)
     side = torch.cuda.Stream()
     bad = torch.zeros(1, device="cuda", dtype=torch.int32)
-    for M, N, K, force in ((512, 1536, 1536, False), (512, 1536, 4096, False), (1024, 2304, 2048, True)):
+    for M, N, K, force in ((512, 1536, 1536, False), (512, 1536, 4096, False), (1024, 2304, 2048, True), (512, 1536, 4096, "four")):
         g = torch.Generator().manual_seed(M + N + K + 1)
         A = bf(torch.randn(M, K, generator=g))
         W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
         tiles = ((M + 63) // 64) * ((N + 127) // 128)
+        four = force == "four"  # round 5: the same problem as the launcher runs it by default - four K quarters on 128 x 128 tiles, summed in K order
+        if four:
+            tiles = 256
         part = torch.zeros(tiles * 2 * 64 * 128, device="cuda", dtype=torch.float32)
         cnt = torch.zeros(tiles, device="cuda", dtype=torch.int32)
         plain = _gemm(A, W, variant=8)
         outs = [torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(100)]
-        if force:
+        if force is True:
             set_option("gemm_splitk", 2)
         try:
             first = None
@@ -253,7 +303,10 @@ def test_gemm_splitk_handoff_stress():
                 for o in outs:
                     o.fill_(float("nan"))
                 for o in outs:
-                    ok(lib().lt_op_gemm_splitk(P(A), P(W), P(o), M, N, K, P(part), P(cnt), tiles, stream()), "gemm_splitk")
+                    if four:
+                        ok(lib().lt_op_gemm_splitk_auto(P(A), P(W), P(o), M, N, K, P(part), P(cnt), tiles, stream()), "gemm_splitk_auto")
+                    else:
+                        ok(lib().lt_op_gemm_splitk(P(A), P(W), P(o), M, N, K, P(part), P(cnt), tiles, stream()), "gemm_splitk")
                 if first is None:
                     first = outs[0].clone()
                     assert not torch.isnan(first.float()).any() and rel_l2(first, plain) < 2e-3
