@@ -18,9 +18,10 @@ def available() -> bool:
 
 
 def copy_root():
-    """``oracle/_ref`` when it holds a verified byte-identical copy of the files the timing leg imports (oracle/build_ref.py), else None"""
+    """a scratch directory with the files of the verified archive ``oracle/_ref/reference_files.tar`` (oracle/build_ref.py: byte-identical
+    reference files, every sha256 re-checked on extraction), or None when no archive travelled"""
     from oracle import build_ref
-    return build_ref.REF_DST if build_ref.verify() else None
+    return build_ref.extract() if build_ref.verify() else None
 
 
 def timing_root():

@@ -130,20 +130,23 @@ def test_product_path_never_imports_the_oracle():
     assert not bad, bad
 
 
-def test_reference_copy_for_the_cpu_baseline_is_byte_identical_or_absent():
-    """oracle/_ref (git-ignored, filled by oracle/build_ref.py from __graft_entry__.build()): when present every file must still carry the
-    sha256 recorded when it was copied from the reference; in the authoring container the sources are compared directly"""
+def test_reference_archive_for_the_cpu_baseline_is_byte_identical_or_absent():
+    """oracle/_ref/reference_files.tar (git-ignored build artefact, packed by oracle/build_ref.py from __graft_entry__.build()): when present
+    the archive must be the one its manifest describes and every member must still carry the sha256 of the reference file it was read from;
+    in the authoring container the sources are compared directly.  No loose reference source may sit in the tree, nothing of it in git."""
     import hashlib
     import json
     from oracle import build_ref
-    man_path = os.path.join(build_ref.REF_DST, "MANIFEST.json")
-    if not os.path.exists(man_path):
+    if not os.path.exists(build_ref.MANIFEST):
         pytest.skip("oracle/_ref not built (no reference checkout was present when build() ran)")
     assert build_ref.verify()
-    man = json.load(open(man_path))["sha256"]
-    if os.path.isdir(os.path.join(build_ref.REF_SRC, "lumina_next_t2i")):
-        for rel, h in man.items():
+    root = build_ref.extract()
+    man = json.load(open(build_ref.MANIFEST))["sha256"]
+    for rel, h in man.items():
+        assert hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest() == h, rel
+        if os.path.isdir(os.path.join(build_ref.REF_SRC, "lumina_next_t2i")):
             assert hashlib.sha256(open(os.path.join(build_ref.REF_SRC, rel), "rb").read()).hexdigest() == h, rel
+    assert sorted(os.listdir(build_ref.REF_DST)) == ["MANIFEST.json", "reference_files.tar"], os.listdir(build_ref.REF_DST)
     tracked = subprocess.run(["git", "-C", REPO, "ls-files", "oracle/_ref"], capture_output=True, text=True).stdout.strip()
     assert tracked == "", "reference sources must never enter git history: " + tracked
 
