@@ -49,6 +49,8 @@ CASES = {
     "full_2b_traj_euler30": dict(base="full_2b", method="euler", num_steps=30, shift=4.0, points=[1, 5, 10, 15, 20, 25, 29]),
     # the demo's default solver (demo.py:395-431): midpoint, 2 NFE per interval; 10 grid points = 18 NFE (the CPU budget of one round)
     "full_2b_traj_midpoint10": dict(base="full_2b", method="midpoint", num_steps=10, shift=4.0, points=[1, 3, 5, 7, 9]),
+    # ... and the demo's recipe in full: 30 grid points = 58 NFE (three hours of CPU for the two legs)
+    "full_2b_traj_midpoint30": dict(base="full_2b", method="midpoint", num_steps=30, shift=4.0, points=[1, 5, 10, 15, 20, 25, 29]),
     # BASELINE configs[0] in its own form: class-conditional 256^2, "4-step Euler ODE" = 5 grid points, no time shift
     # (Next-DiT-ImageNet/sample.py defaults)
     "full_imagenet600m_traj_euler5": dict(base="full_imagenet600m", method="euler", num_steps=5, shift=None, points=[1, 2, 3, 4]),

@@ -287,6 +287,11 @@ def test_full_2b_midpoint_10_point_trajectory_vs_reference(golden_dir):
     _traj_check("full_2b_traj_midpoint10", golden_dir, lambda cfg: models.NextDiT_2B_patch2(qk_norm=True, cap_feat_dim=cfg.cap_feat_dim))
 
 
+def test_full_2b_midpoint_30_point_trajectory_vs_reference(golden_dir):
+    """the demo's recipe in full (demo.py:395-431): midpoint over the 30-point shifted grid = 58 NFE at full depth"""
+    _traj_check("full_2b_traj_midpoint30", golden_dir, lambda cfg: models.NextDiT_2B_patch2(qk_norm=True, cap_feat_dim=cfg.cap_feat_dim))
+
+
 def test_full_imagenet_600m_4_step_euler_trajectory_vs_reference(golden_dir):
     """BASELINE configs[0] in its own form: class-conditional 256^2, 4-step Euler ODE (5 grid points, no time shift), 16 layers, against
     the unmodified Next-DiT-ImageNet sampler + model"""

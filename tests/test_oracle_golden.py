@@ -278,7 +278,7 @@ def test_fulldepth_16k_fixture_is_the_pinned_restatement(golden_dir):
         assert 5e-3 < float((floor - ora).norm() / ora.norm()) < 8e-2
 
 
-TRAJ = ["full_imagenet600m_traj_euler5", "full_2b_traj_euler30", "full_2b_traj_midpoint10"]
+TRAJ = ["full_imagenet600m_traj_euler5", "full_2b_traj_euler30", "full_2b_traj_midpoint10", "full_2b_traj_midpoint30"]
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -301,7 +301,7 @@ def test_trajectory_fixture_is_a_reference_trajectory_over_the_reference_grid(go
     pts = [int(p) for p in g["points"]]
     assert pts[-1] == n - 1 and g["ref_points"].shape[0] == len(pts) == g["floor_points"].shape[0]
     drift = g["drift_floor"]
-    assert drift.shape == (n,) and drift[0] == 0.0 and np.isfinite(drift).all() and 5e-3 < drift[-1] < 0.25, drift
+    assert drift.shape == (n,) and drift[0] == 0.0 and np.isfinite(drift).all() and 5e-3 < drift[-1] < 0.5, drift
     np.testing.assert_array_equal(g["ref_points"][-1], g["ref_final"][0])
     np.testing.assert_array_equal(g["floor_points"][-1], g["floor_final"][0])
     cfg = _cfg(g)
