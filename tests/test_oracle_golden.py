@@ -294,7 +294,9 @@ def test_trajectory_fixture_is_a_reference_trajectory_over_the_reference_grid(go
         pytest.skip(f"{name}.npz not generated yet (hours of CPU: oracle/make_traj_golden.py)")
     g = np.load(path, allow_pickle=False)
     base = _load(golden_dir, str(g["base"]))
-    assert int(g["seed_w"]) == int(base["seed_w"]) and np.array_equal(g["wsum"], base["wsum"]) and str(g["config"]) == str(base["config"])
+    # (wsum is a float64 reduction over ~5e6 values: its last bits follow the thread count of the run that made the fixture)
+    assert int(g["seed_w"]) == int(base["seed_w"]) and np.allclose(g["wsum"], base["wsum"], rtol=1e-12, atol=0) and str(g["config"]) == str(base["config"])
+    assert np.array_equal(g["wprobe"], base["wprobe"])
     n, method, shift = int(g["num_steps"]), str(g["method"]), float(g["shift"])
     grid = OD.time_grid(n, shift if shift > 0 else None)
     np.testing.assert_array_equal(grid.numpy(), g["grid"])
