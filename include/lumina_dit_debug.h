@@ -64,6 +64,10 @@ extern "C" {
  *   "gemm_splitk4"      (0..1, 1): with "gemm_splitk" on, a dense small-M plain-epilogue GEMM with K >= 4096 (the 512-row w2 projection) runs on
  *                       128 x 128 tiles with K split FOUR ways when that still fits one round of the CUs; the last arriver sums the four
  *                       fp32 partials in K order (round 5) | 0: the two-way split on 64 x 128 tiles
+ *   "moe_time_plan_hoist" (0..1, 1): the time-routed MoE layers' plans (selection, weights, expert-sorted positions, tile table) of ALL layers
+ *                       are written by one launch at the top of the evaluation - the time router's logits depend on the timestep embedding
+ *                       only and are already computed there for every layer (round 5: one launch less per layer); not used while routing is
+ *                       forced by the parity hook or with more than 64 samples | 0: one plan launch per layer
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

@@ -137,6 +137,11 @@ struct lt_engine {
     u16 *moe_us = nullptr, *moe_ys = nullptr, *moe_logits = nullptr, *moe_wts = nullptr;
     u16* gate_t_all = nullptr;  // [L * E, A]: every layer's time-router weight, contiguous (LayerW::gate_t point into it)
     int *moe_sel = nullptr, *moe_pos = nullptr, *moe_tile_expert = nullptr, *moe_src = nullptr;
+    // round 5 (option moe_time_plan_hoist): one plan per layer for the time router, all written by ONE launch at the top of the evaluation
+    int *moe_tp_sel = nullptr, *moe_tp_pos = nullptr, *moe_tp_tile_expert = nullptr, *moe_tp_src = nullptr;
+    u16* moe_tp_wts = nullptr;
+    size_t moe_tp_stride_rows = 0, moe_tp_stride_src = 0;
+    bool moe_tp_live = false;  // this evaluation's time plans were hoisted (set by run_forward, read by moe_ffn / moe_y)
     // parity hooks (lt_moe_routing_*): [L][2 branches][max rows][2] expert ids, recorded from / forced onto moe_route_kernel
     int *moe_rec = nullptr, *moe_force = nullptr;
     int moe_rec_on = 0, moe_force_rows = 0, moe_rec_rows = 0;
@@ -407,8 +412,14 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
     // tiles, and the XCD-contiguous tile order would put every real tile on XCD 0 (measured: 255 us instead of 60 us per
     // expert GEMM at 512 rows in an engine sized for 8192)
     const int tiles = (int)((2 * (size_t)M + (size_t)e->E * 255 + 255) / 256);
+    const bool hoisted = branch == 0 && e->moe_tp_live;  // this layer's time plan was written at the top of the evaluation (run_forward)
     m.sel = e->moe_sel; m.wts = e->moe_wts; m.pos = e->moe_pos; m.tile_expert = e->moe_tile_expert; m.max_tiles = tiles;
     m.src = e->moe_src;
+    if (hoisted) {
+        m.sel = e->moe_tp_sel + (size_t)layer * e->moe_tp_stride_rows; m.pos = e->moe_tp_pos + (size_t)layer * e->moe_tp_stride_rows;
+        m.wts = e->moe_tp_wts + (size_t)layer * e->moe_tp_stride_rows; m.src = e->moe_tp_src + (size_t)layer * e->moe_tp_stride_src;
+        m.tile_expert = e->moe_tp_tile_expert + (size_t)layer * e->moe_tiles;
+    }
     m.gate_w = nullptr; m.sample_logits = nullptr; m.forced = nullptr;
     {
         ProfScope ps(e, 2, 0, s);
@@ -424,18 +435,18 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
             m.forced = e->moe_force + slot;
         }
         if (branch != 0 && !routed && launch_moe_route(m, s)) return 1;  // (the time branch routes inside the plan kernel)
-        if (launch_moe_plan(m, s)) return 1;
+        if (!hoisted && launch_moe_plan(m, s)) return 1;
         if (e->moe_rec_on) {
-            LT_CHECK_HIP(hipMemcpyAsync(e->moe_rec + slot, e->moe_sel, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
+            LT_CHECK_HIP(hipMemcpyAsync(e->moe_rec + slot, m.sel, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
             e->moe_rec_rows = M;
         }
     }
     const int P = tiles * 256;
     GemmArgs g;
-    g.bias = nullptr; g.bias_dtype = -1; g.tile_expert = e->moe_tile_expert;
+    g.bias = nullptr; g.bias_dtype = -1; g.tile_expert = m.tile_expert;
     {   // grouped SwiGLU GEMM: each 256-row tile multiplies with its expert's packed w1|w3
         // (A = the un-sorted FFN input: the GEMM gathers its rows through the plan's inverse map, no expert-sorted copy)
-        g.A = e->h; g.a_row_map = e->moe_src; g.a_map_rows = M; g.W = branch == 0 ? w.w13_t : w.w13_s; g.C = e->moe_us; g.M = P; g.N = 2 * F; g.K = d;
+        g.A = e->h; g.a_row_map = m.src; g.a_map_rows = M; g.W = branch == 0 ? w.w13_t : w.w13_s; g.C = e->moe_us; g.M = P; g.N = 2 * F; g.K = d;
         g.lda = d; g.ldw = d; g.ldc = F; g.w_expert_stride = (long long)2 * F * d;
         ProfScope ps(e, 0, 2.0 * (2.0 * M) * (2.0 * F) * d, s, true);  // algorithmic: every token visits two experts
         if (launch_gemm_bf16(g, 1, 0, s, ps.ev0(), ps.ev1())) return 1;
@@ -451,8 +462,13 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
 }
 
 // the branch output of a MoE FFN as gated_residual_norm takes it: experts' outputs + routing, combined on the way in
-void moe_y(const lt_engine* e, GatedResArgs& g) {
+// layer >= 0: the branch is the time router's and its plan may be the hoisted one of that layer
+void moe_y(const lt_engine* e, GatedResArgs& g, int time_layer = -1) {
     g.y = nullptr; g.moe_ys = e->moe_ys; g.moe_pos = e->moe_pos; g.moe_wts = e->moe_wts;
+    if (time_layer >= 0 && e->moe_tp_live) {
+        g.moe_pos = e->moe_tp_pos + (size_t)time_layer * e->moe_tp_stride_rows;
+        g.moe_wts = e->moe_tp_wts + (size_t)time_layer * e->moe_tp_stride_rows;
+    }
 }
 
 // one forward pass of the configured family [+ CFG combine]:
@@ -552,6 +568,17 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         if (launch_linear_small_m(e->tfeat, e->t0_w, e->t0_b, e->t1, B, A, 256, 0, s)) return 1;
         if (launch_linear_small_m(e->t1, e->t2_w, e->t2_b, e->temb, B, A, A, 1, s)) return 1;
         if (e->gate_t_all && launch_linear_small_m(e->temb, e->gate_t_all, nullptr, e->moe_logits, B, L * e->E, A, 0, s)) return 1;  // every layer's time-router logits
+        e->moe_tp_live = e->gate_t_all && e->moe_tp_sel && lt_opt(OPT_MOE_TIME_PLAN_HOIST) && !e->moe_force_rows && B <= LT_MOE_PLAN_TIME_MAX_SAMPLES;
+        if (e->moe_tp_live) {  // ... and every layer's time plan: they depend on nothing else (one launch instead of L)
+            MoeArgs m;
+            m.x = nullptr; m.gate_w = nullptr; m.forced = nullptr; m.sample_logits = e->moe_logits; m.sample_ld = L * e->E;
+            m.rows = M; m.rows_per_sample = N; m.d = d; m.E = e->E;
+            m.sel = e->moe_tp_sel; m.pos = e->moe_tp_pos; m.wts = e->moe_tp_wts; m.src = e->moe_tp_src; m.tile_expert = e->moe_tp_tile_expert;
+            m.max_tiles = (int)((2 * (size_t)M + (size_t)e->E * 255 + 255) / 256);  // = moe_ffn's bound for this call's rows
+            m.layers = L; m.layer_stride_rows = (long long)e->moe_tp_stride_rows; m.layer_stride_src = (long long)e->moe_tp_stride_src;
+            m.layer_stride_tiles = e->moe_tiles;
+            if (launch_moe_plan(m, s)) return 1;
+        }
         if (launch_add_bf16(e->temb, e->cap_emb, e->adaln_in, (long long)B * A, s)) return 1;
         if (launch_linear_small_m(e->adaln_in, e->adaln_w, e->adaln_b, e->mod, B, e->ld_mod, A, 1, s)) return 1;
         // once per (sample, channel) instead of once per token inside the row kernels: tanh of the gate chunks (where the
@@ -717,7 +744,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             {
                 ProfScope ps(e, 2, 0, s);
                 GatedResArgs g;
-                g.x = e->x; moe_y(e, g); g.post_w = w.norm_time; g.gate = chunk(l, 3); g.post_mode = 1; g.gate_mode = 0;
+                g.x = e->x; moe_y(e, g, l); g.post_w = w.norm_time; g.gate = chunk(l, 3); g.post_mode = 1; g.gate_mode = 0;
                 g.next_w = nullptr; g.next_scale = chunk(l, 4); g.next_shift = nullptr; g.next_mode = 1; g.h = e->h;
                 g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
                 // round 5 (option moe_route_fused): h is the space router's input and this kernel holds the row - it routes on its way out
@@ -739,7 +766,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
             g.x = e->x; g.y = e->o; g.post_w = last_post_w; g.gate = last_gate;
-            if (e->E != 0) moe_y(e, g);
+            if (e->E != 0) moe_y(e, g, e->moe_mode == 1 ? l : -1);
             g.post_mode = post_mode; g.gate_mode = gate_mode; g.h = e->h;
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
             if (l + 1 < L) {
@@ -1001,6 +1028,20 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         e->moe_tile_expert = (int*)q;
         if (dev_alloc(e, &q, P * sizeof(int))) return fail();
         e->moe_src = (int*)q;
+        if (e->moe_mode != 2) {  // per-layer plans of the time router (a few hundred KB per layer at 8192 rows)
+            e->moe_tp_stride_rows = 2 * M + 4;
+            e->moe_tp_stride_src = P;
+            if (dev_alloc(e, &q, (size_t)L * e->moe_tp_stride_rows * sizeof(int))) return fail();
+            e->moe_tp_sel = (int*)q;
+            if (dev_alloc(e, &q, (size_t)L * e->moe_tp_stride_rows * sizeof(int))) return fail();
+            e->moe_tp_pos = (int*)q;
+            if (dev_alloc(e, &q, (size_t)L * e->moe_tp_stride_rows * sizeof(u16))) return fail();
+            e->moe_tp_wts = (u16*)q;
+            if (dev_alloc(e, &q, (size_t)L * e->moe_tiles * sizeof(int))) return fail();
+            e->moe_tp_tile_expert = (int*)q;
+            if (dev_alloc(e, &q, (size_t)L * P * sizeof(int))) return fail();
+            e->moe_tp_src = (int*)q;
+        }
     }
     {
         void* q;

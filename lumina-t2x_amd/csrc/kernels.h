@@ -245,7 +245,13 @@ struct MoeArgs {
     int* src;                  // [max_tiles * 256] inverse map: token row of each sorted position, -1 for padding (GemmArgs::a_row_map)
     int* tile_expert;          // [max_tiles] expert of each 256-row tile of the sorted buffers, -1 = padding
     int max_tiles;
+    // round 5: the time router's plans of ALL layers in one launch (the logits of every layer exist before the first block runs):
+    // layer l reads sample_logits + l * E and writes sel / pos at + l * layer_stride_rows, wts likewise (u16), src at + l * layer_stride_src,
+    // tile_expert at + l * layer_stride_tiles.  layers <= 1 = one plan (the fields above as they are)
+    int layers = 1;
+    long long layer_stride_rows = 0, layer_stride_src = 0, layer_stride_tiles = 0;
 };
+constexpr int LT_MOE_PLAN_TIME_MAX_SAMPLES = 64;               // the closed-form time plan holds this many samples' routings in LDS
 int launch_moe_route(const MoeArgs& a, hipStream_t stream);    // logits -> top-2, weights
 int launch_moe_plan(const MoeArgs& a, hipStream_t stream);     // counts -> tile-aligned segments, pos, src, tile_expert
 

@@ -226,12 +226,18 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs p) {
 // row (round 4: the single-workgroup kernel took 26 us per TimeMoeLayer at 8192 rows, this one a few).  Every workgroup recomputes the
 // B routings and the E segment offsets (B x E bf16 loads), then writes its rows' sel / wts / pos / src and its slice of the padding
 // positions and of the tile table.  Same outputs as moe_plan_kernel, bit for bit (tests/test_moe_plan.py).
-constexpr int PLAN_T_MAXB = 64;
+constexpr int PLAN_T_MAXB = LT_MOE_PLAN_TIME_MAX_SAMPLES;
 __global__ __launch_bounds__(256) void moe_plan_time_kernel(MoeArgs p) {
     __shared__ int s_sel[PLAN_T_MAXB][2], s_base[PLAN_T_MAXB][2], s_off[MAX_E], s_cnt[MAX_E];
     __shared__ u16 s_w[PLAN_T_MAXB][2];
     const int tid = threadIdx.x;
     const int N = p.rows_per_sample, B = p.rows / N;
+    if (p.layers > 1) {  // blockIdx.y = layer: its E logit columns in, its own plan out
+        const long long l = blockIdx.y;
+        p.sample_logits += l * p.E;
+        p.sel += l * p.layer_stride_rows; p.pos += l * p.layer_stride_rows; p.wts += l * p.layer_stride_rows;
+        p.src += l * p.layer_stride_src; p.tile_expert += l * p.layer_stride_tiles;
+    }
     if (tid < B) {
         float logit[MAX_E];
 #pragma unroll
@@ -312,8 +318,10 @@ int launch_moe_plan(const MoeArgs& a_in, hipStream_t stream) {
     if (a.sample_ld == 0) a.sample_ld = a.E;
     if (check(a)) return 2;
     LT_REQUIRE(2LL * a.rows <= 1024LL * 1023, "moe_plan: %d rows exceed the packed 16-bit counters of the scan (523776 rows)", a.rows);
-    if (a.sample_logits && !a.forced && a.rows % a.rows_per_sample == 0 && a.rows / a.rows_per_sample <= PLAN_T_MAXB) {  // closed form
-        hipLaunchKernelGGL(moe_plan_time_kernel, dim3((a.rows + 255) / 256), dim3(256), 0, stream, a);
+    const bool closed_form = a.sample_logits && !a.forced && a.rows % a.rows_per_sample == 0 && a.rows / a.rows_per_sample <= PLAN_T_MAXB;
+    LT_REQUIRE(a.layers <= 1 || closed_form, "moe_plan: the all-layers form is the time router's closed-form plan (per-sample logits, no forced routing, <= %d samples)", PLAN_T_MAXB);
+    if (closed_form) {
+        hipLaunchKernelGGL(moe_plan_time_kernel, dim3((a.rows + 255) / 256, a.layers > 1 ? a.layers : 1), dim3(256), 0, stream, a);
         LT_CHECK_HIP(hipGetLastError());
         return 0;
     }

@@ -198,6 +198,18 @@ def test_moe_engine_matches_reference_golden(golden_dir):
         eng.moe_routing_record(False)
     assert torch.equal(fused, got) and np.array_equal(sel_fused, sel_split) and (sel_fused[:, 1] >= 0).all()
     assert torch.equal(split, fused)
+    # round 5 (option moe_time_plan_hoist, default on): the time router's plans of all layers are written by one launch at the top of the
+    # evaluation (its logits depend on the timestep only).  One plan launch per layer must give the same forward bit for bit and the same
+    # recorded selections in every (layer, branch) slot
+    eng.moe_routing_record(True)
+    try:
+        set_option("moe_time_plan_hoist", 0)
+        per_layer = model.forward_with_cfg(z, t, y, 4.0)
+        sel_per_layer = eng.moe_routing_read(rows).copy()
+    finally:
+        set_option("moe_time_plan_hoist", 1)
+        eng.moe_routing_record(False)
+    assert torch.equal(per_layer, got) and np.array_equal(sel_per_layer, sel_fused)
 
 
 @pytest.mark.parametrize("name,ctor", [("moe_time_tiny", "DiT_Llama_TimeMoE"), ("moe_space_tiny", "DiT_Llama_SpaceMoE")])
@@ -222,6 +234,13 @@ def test_single_moe_engine_matches_reference_golden(golden_dir, name, ctor):
     fc = rel_l2(V.imagenet_forward_with_cfg(sd, cfg, z.float().cpu(), t.cpu(), y.cpu(), 4.0, bf16=True), ref)
     assert rel_l2(got, ref) < max(TOL_CFG4, 1.5 * fc), (rel_l2(got, ref), fc)
     assert torch.equal(got[0, :3], got[1, :3])
+    if ctor == "DiT_Llama_TimeMoE":  # the hoisted all-layers time plan (option moe_time_plan_hoist) against one plan launch per layer
+        from gpu_util import set_option
+        try:
+            set_option("moe_time_plan_hoist", 0)
+            assert torch.equal(model.forward_with_cfg(z, t, y, 4.0), got)
+        finally:
+            set_option("moe_time_plan_hoist", 1)
     # second call with RoPE scaling.  Per-token routing is discrete: which near-ties flip depends on sub-ulp details, and on this
     # 128-token model a handful of flipped tokens moves the rel-L2 a lot - the reference's bf16 choreography lands anywhere in
     # 0.16 .. 0.35 of its fp32 self when its weights are jittered by a fraction of a bf16 ulp.  Yardstick = the largest of a few
