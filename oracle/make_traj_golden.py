@@ -54,6 +54,14 @@ CASES = {
     # BASELINE configs[0] in its own form: class-conditional 256^2, "4-step Euler ODE" = 5 grid points, no time shift
     # (Next-DiT-ImageNet/sample.py defaults)
     "full_imagenet600m_traj_euler5": dict(base="full_imagenet600m", method="euler", num_steps=5, shift=None, points=[1, 2, 3, 4]),
+    # BASELINE configs[4]'s model (Next-DiT-MoE "Both", 16 layers, 4 time + 4 space experts) at the config's own 256^2: a 30-point Euler
+    # grid, no time shift (Next-DiT-MoE/sample.py:131-137 passes no shift; its default solver is the adaptive dopri5 of the absent
+    # torchdiffeq, so the fixed-grid solver of that package's own list stands in).  Routing is discrete: a flipped near-tie replaces a
+    # token's expert outright in either bf16 path, which the drift of BOTH legs carries
+    "full_moe600m_traj_euler30": dict(base="full_moe600m_256", method="euler", num_steps=30, shift=None, points=[1, 5, 10, 15, 20, 25, 29]),
+    # BASELINE configs[2]: Lumina-T2I 5B (Flag-DiT, 32 layers, d 3072, 4160 tokens incl. eol), CFG 4, proportional attention, time shift 4
+    # (lumina_t2i/demo.py:134-142): Euler over 10 grid points = 9 NFE (the CPU budget: ~3 min per fp32 evaluation in the authoring container)
+    "full_flag5b_traj_euler10": dict(base="full_flag5b", method="euler", num_steps=10, shift=4.0, points=[1, 3, 5, 7, 9]),
 }
 
 

@@ -297,3 +297,17 @@ def test_full_imagenet_600m_4_step_euler_trajectory_vs_reference(golden_dir):
     the unmodified Next-DiT-ImageNet sampler + model"""
     _traj_check("full_imagenet600m_traj_euler5", golden_dir,
                 lambda cfg: models.imagenet.DiT_Llama_600M_patch2(qk_norm=True, num_classes=cfg.num_classes))
+
+
+def test_full_moe_600m_30_point_euler_trajectory_vs_reference(golden_dir):
+    """BASELINE configs[4]'s model (Next-DiT-MoE "Both": 16 layers, 4 time + 4 space experts, top-2) at 256^2 over a 30-point Euler grid
+    (29 NFE), against the unmodified Next-DiT-MoE sampler + models2.DiT_Llama.  Routing is discrete - a flipped near-tie replaces a
+    token's expert outright in either bf16 path - so the trajectory drifts further than the dense models' (the floor ends at 0.35); the
+    gate is the same 1.5 x floor."""
+    _traj_check("full_moe600m_traj_euler30", golden_dir, lambda cfg: models.moe.DiT_Llama_600M_patch2_Both(qk_norm=True, num_classes=cfg.num_classes))
+
+
+def test_full_flag_dit_5b_10_point_euler_trajectory_vs_reference(golden_dir):
+    """BASELINE configs[2]: Lumina-T2I 5B (Flag-DiT, 32 layers, d 3072, 4160 tokens incl. eol), CFG 4, proportional attention, time shift
+    4 (lumina_t2i/demo.py:134-142), Euler over 10 grid points = 9 NFE, against the unmodified lumina_t2i sampler + model"""
+    _traj_check("full_flag5b_traj_euler10", golden_dir, lambda cfg: models.flag_dit.DiT_Llama_5B_patch2(qk_norm=True, cap_feat_dim=cfg.cap_feat_dim))

@@ -278,7 +278,8 @@ def test_fulldepth_16k_fixture_is_the_pinned_restatement(golden_dir):
         assert 5e-3 < float((floor - ora).norm() / ora.norm()) < 8e-2
 
 
-TRAJ = ["full_imagenet600m_traj_euler5", "full_2b_traj_euler30", "full_2b_traj_midpoint10", "full_2b_traj_midpoint30"]
+TRAJ = ["full_imagenet600m_traj_euler5", "full_2b_traj_euler30", "full_2b_traj_midpoint10", "full_2b_traj_midpoint30", "full_moe600m_traj_euler30",
+        "full_flag5b_traj_euler10"]
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -286,8 +287,8 @@ def test_trajectory_fixture_is_a_reference_trajectory_over_the_reference_grid(go
     """oracle/make_traj_golden.py: `ref_*` = the UNMODIFIED reference Sampler.sample_ode driving the unmodified
     model, fp32; `floor_*` = the reference's bf16 choreography with a bf16 state over the same grid.  Checked here: the stored grid is
     the reference's (integrators.py:97-99 = odeint_oracle.time_grid), the start state is the per-NFE fixture's draw, the floor's drift
-    starts at zero, stays finite and ends where a whole trajectory of the per-NFE noise can put it, and - for the 600M model, where a CPU
-    run takes seconds - the fp32 RESTATEMENT stepped over the same grid reproduces the reference's trajectory (the restatement and the
+    starts at zero, stays finite and ends where a whole trajectory of the per-NFE noise can put it, and - for the 600M models (dense and MoE), where a CPU
+    run takes seconds to a minute - the fp32 RESTATEMENT stepped over the same grid reproduces the reference's trajectory (the restatement and the
     restated odeint together equal the reference's sampler + model end to end)."""
     path = os.path.join(golden_dir, name + ".npz")
     if not os.path.exists(path):
@@ -315,16 +316,19 @@ def test_trajectory_fixture_is_a_reference_trajectory_over_the_reference_grid(go
         ins = synth.synth_inputs(cfg, latent_hw=hw, seed=int(g["seed_x"]), t_value=calls[0][1])
     z0 = ins[0].to(torch.bfloat16).float()[:1]
     np.testing.assert_array_equal(z0.numpy(), g["z0"])
-    if name != "full_imagenet600m_traj_euler5":
-        return  # a 2B trajectory on the CPU takes the better part of an hour: the per-NFE pin (full_2b) + the stepping pin (solver_kat) cover it
+    if name not in ("full_imagenet600m_traj_euler5", "full_moe600m_traj_euler30"):
+        return  # a 2B / 5B trajectory on the CPU takes the better part of an hour: the per-NFE pin (full_2b, full_flag5b) + the stepping pin (solver_kat) cover it
     from oracle import variants_oracle as V
     sd = synth.synth_state_dict(cfg, seed=int(g["seed_w"]), streams=True)
     kw = json.loads(str(g["model_kw"]))
+    # (the MoE model: the first ten intervals, against the stored grid point 10 - the python expert loops of the restatement are slow)
+    upto = n - 1 if name == "full_imagenet600m_traj_euler5" else 10
     with torch.no_grad():
-        traj = OD.odeint(lambda t, y: V.imagenet_forward_with_cfg(sd, cfg, y, torch.ones(y.size(0)) * t, ins[2], **kw), z0.repeat(2, 1, 1, 1), grid,
-                         method=method)
-    ref = torch.from_numpy(g["ref_final"])
-    assert float((traj[-1] - ref).norm() / ref.norm()) < 1e-5
+        traj = OD.odeint(lambda t, y: V.imagenet_forward_with_cfg(sd, cfg, y, torch.ones(y.size(0)) * t, ins[2], **kw), z0.repeat(2, 1, 1, 1),
+                         grid[:upto + 1], method=method)
+    ref = torch.from_numpy(g["ref_final"]) if upto == n - 1 else torch.from_numpy(g["ref_points"][pts.index(upto)])
+    got = traj[-1] if upto == n - 1 else traj[-1, 0]
+    assert float((got - ref).norm() / ref.norm()) < 1e-5
 
 
 def test_fulldepth_weight_draw_is_reproducible(golden_dir):
