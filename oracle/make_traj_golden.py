@@ -62,6 +62,12 @@ CASES = {
     # BASELINE configs[2]: Lumina-T2I 5B (Flag-DiT, 32 layers, d 3072, 4160 tokens incl. eol), CFG 4, proportional attention, time shift 4
     # (lumina_t2i/demo.py:134-142): Euler over 10 grid points = 9 NFE (the CPU budget: ~3 min per fp32 evaluation in the authoring container)
     "full_flag5b_traj_euler10": dict(base="full_flag5b", method="euler", num_steps=10, shift=4.0, points=[1, 3, 5, 7, 9]),
+    # BASELINE configs[3]'s model (Lumina-Next-SFT 2B, GQA 32 / 8 heads) with time-aware RoPE scaling (scale_factor 2, watershed 0.3: the
+    # linear-interpolation branch below t = 0.3, the NTK branch above - a trajectory crosses it), 4096 tokens on a 64 x 256 latent, Euler
+    # over 10 shifted grid points
+    # over 10 shifted grid points - driven by the mini fork's own flat `ODE` class (lumina_next_t2i_mini/transport.py:57-111, sample.py:204),
+    # whose grid runs to t = 1 exactly
+    "full_2b_gqa_ntk_traj_euler10": dict(base="full_2b_gqa_ntk", method="euler", num_steps=10, shift=4.0, points=[1, 3, 5, 7, 9], driver="mini"),
 }
 
 
@@ -126,15 +132,23 @@ def run_case(name):
     # ---- reference leg: unmodified transport + unmodified model; grid from the reference's own ode.__init__ ------------------
     os.environ["TORCHDYNAMO_DISABLE"] = "1"
     mod = F._fresh_import(base["pkg"], base["module"])
-    tmod = importlib.import_module("transport")
-    tr = tmod.create_transport("Linear", "velocity", None, None, None)
-    integ = importlib.import_module("transport.integrators")
-    okw = dict(drift=None, t0=0, t1=1, sampler_type=method, num_steps=num_steps, atol=1e-6, rtol=1e-3)
-    if shift is not None:
-        okw["time_shifting_factor"] = shift
-    t0s, t1s = tr.check_interval(tr.train_eps, tr.sample_eps, sde=False, eval=True, reverse=False, last_step_size=0.0)
-    okw["t0"], okw["t1"] = t0s, t1s
-    grid = integ.ode(**okw).t.clone()
+    driver = case.get("driver", "sampler")
+    if driver == "mini":  # the mini fork: one flat transport.py, loaded by path (needs only the torchdiffeq stub of oracle/stubs)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_mini_transport", os.path.join(F.R.REFERENCE_ROOT, "lumina_next_t2i_mini", "transport.py"))
+        tmod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(tmod)
+        grid = tmod.ODE(num_steps, method, shift).t.clone()
+    else:
+        tmod = importlib.import_module("transport")
+        tr = tmod.create_transport("Linear", "velocity", None, None, None)
+        integ = importlib.import_module("transport.integrators")
+        okw = dict(drift=None, t0=0, t1=1, sampler_type=method, num_steps=num_steps, atol=1e-6, rtol=1e-3)
+        if shift is not None:
+            okw["time_shifting_factor"] = shift
+        t0s, t1s = tr.check_interval(tr.train_eps, tr.sample_eps, sde=False, eval=True, reverse=False, last_step_size=0.0)
+        okw["t0"], okw["t1"] = t0s, t1s
+        grid = integ.ode(**okw).t.clone()
     assert len(grid) == num_steps
     done = all(os.path.exists(_ckpt_path(name, "ref", k)) for k in range(1, num_steps))
     if done:
@@ -148,10 +162,13 @@ def run_case(name):
         model = cls(**kw).eval()
         res = model.load_state_dict(sd, strict=True, assign=True)
         assert not res.missing_keys and not res.unexpected_keys
-        skw = dict(sampling_method=method, num_steps=num_steps)
-        if shift is not None:
-            skw["time_shifting_factor"] = shift
-        sample_fn = tmod.Sampler(tr).sample_ode(**skw)
+        if driver == "mini":
+            sample_fn = tmod.ODE(num_steps, method, shift).sample  # lumina_next_t2i_mini/sample.py:204
+        else:
+            skw = dict(sampling_method=method, num_steps=num_steps)
+            if shift is not None:
+                skw["time_shifting_factor"] = shift
+            sample_fn = tmod.Sampler(tr).sample_ode(**skw)
         t_start = time.time()
         with torch.no_grad():
             ref = sample_fn(z0, _Stepper(model.forward_with_cfg, name, "ref"), **model_kw)  # the reference's own call, sample.py:233
@@ -186,7 +203,7 @@ def run_case(name):
     out = {"config": np.array(json.dumps(cfg.to_dict())), "base": np.array(case["base"]), "seed_w": base["seed_w"], "seed_x": base["seed_x"],
            "latent_hw": np.array(base["latent_hw"]), "text_len": base["text_len"], "uncond_len": base["uncond_len"],
            "package": np.array(base["pkg"]), "wsum": wsum, "wprobe": wprobe, "wkeys": np.array(json.dumps(wkeys)),
-           "method": np.array(method), "num_steps": num_steps, "shift": np.float64(shift if shift is not None else 0.0),
+           "method": np.array(method), "driver": np.array(driver), "num_steps": num_steps, "shift": np.float64(shift if shift is not None else 0.0),
            "model_kw": np.array(json.dumps(ckw)), "grid": grid.numpy().astype(np.float32), "points": np.array(pts),
            "z0": z0[:1].numpy(),
            "ref_points": ref[pts][:, 0].float().numpy(), "floor_points": floor[pts][:, 0].float().numpy(),

@@ -250,10 +250,17 @@ def _traj_check(name, golden_dir, ctor, gate=1.5):
     ref_pts, floor_pts = torch.from_numpy(g["ref_points"]), torch.from_numpy(g["floor_points"])
     f_all, f_r0 = rel_l2(floor_final, ref_final), rel_l2(floor_final[0], ref_final[0])
     results = {}
+    driver = str(g["driver"]) if "driver" in g.files else "sampler"
     for t_round in (True, False):
-        fn = Sampler(create_transport()).sample_ode(sampling_method=method, num_steps=num_steps, time_shifting_factor=shift if shift > 0 else None)
-        assert np.array_equal(fn.__self__.t.numpy().astype(np.float32), g["grid"]), "time grid differs from the reference's"
-        fn.__self__.t_round_to_state_dtype = t_round
+        if driver == "mini":  # the mini fork's flat ODE class (transport/mini.py = lumina_next_t2i_mini/transport.py:57-111)
+            from lumina_t2x_amd.transport.mini import ODE
+            solver = ODE(num_steps, method, shift if shift > 0 else None)
+            fn = solver.sample
+        else:
+            fn = Sampler(create_transport()).sample_ode(sampling_method=method, num_steps=num_steps, time_shifting_factor=shift if shift > 0 else None)
+            solver = fn.__self__
+        assert np.array_equal(solver.t.numpy().astype(np.float32), g["grid"]), "time grid differs from the reference's"
+        solver.t_round_to_state_dtype = t_round
         traj = fn(z0, model.forward_with_cfg, **kw).float().cpu()
         assert traj.shape == (num_steps,) + tuple(z0.shape) and torch.isfinite(traj).all()
         assert model._engine.last_nfe() == (num_steps - 1) * {"euler": 1, "midpoint": 2}[method]
@@ -311,3 +318,10 @@ def test_full_flag_dit_5b_10_point_euler_trajectory_vs_reference(golden_dir):
     """BASELINE configs[2]: Lumina-T2I 5B (Flag-DiT, 32 layers, d 3072, 4160 tokens incl. eol), CFG 4, proportional attention, time shift
     4 (lumina_t2i/demo.py:134-142), Euler over 10 grid points = 9 NFE, against the unmodified lumina_t2i sampler + model"""
     _traj_check("full_flag5b_traj_euler10", golden_dir, lambda cfg: models.flag_dit.DiT_Llama_5B_patch2(qk_norm=True, cap_feat_dim=cfg.cap_feat_dim))
+
+
+def test_full_2b_gqa_time_aware_rope_10_point_euler_trajectory_vs_reference(golden_dir):
+    """BASELINE configs[3]'s model (Lumina-Next-SFT 2B, GQA 32 / 8 heads, 24 layers) with time-aware RoPE scaling (scale_factor 2, watershed
+    0.3): the trajectory starts on the linear-interpolation branch and crosses to the NTK branch between grid points 5 and 6 - decided on
+    the device from t inside ONE lt_sample_ode call; 4096 tokens on a 64 x 256 latent, against the unmodified mini fork's sampler + model"""
+    _traj_check("full_2b_gqa_ntk_traj_euler10", golden_dir, lambda cfg: models.NextDiT_2B_GQA_patch2(qk_norm=True, cap_feat_dim=cfg.cap_feat_dim))

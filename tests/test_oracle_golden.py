@@ -279,7 +279,7 @@ def test_fulldepth_16k_fixture_is_the_pinned_restatement(golden_dir):
 
 
 TRAJ = ["full_imagenet600m_traj_euler5", "full_2b_traj_euler30", "full_2b_traj_midpoint10", "full_2b_traj_midpoint30", "full_moe600m_traj_euler30",
-        "full_flag5b_traj_euler10"]
+        "full_flag5b_traj_euler10", "full_2b_gqa_ntk_traj_euler10"]
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -299,7 +299,11 @@ def test_trajectory_fixture_is_a_reference_trajectory_over_the_reference_grid(go
     assert int(g["seed_w"]) == int(base["seed_w"]) and np.allclose(g["wsum"], base["wsum"], rtol=1e-12, atol=0) and str(g["config"]) == str(base["config"])
     assert np.array_equal(g["wprobe"], base["wprobe"])
     n, method, shift = int(g["num_steps"]), str(g["method"]), float(g["shift"])
-    grid = OD.time_grid(n, shift if shift > 0 else None)
+    if "driver" in g.files and str(g["driver"]) == "mini":  # the mini fork's flat ODE class: linspace(0, 1, n), shifted (mini_ode.npz pins the mirror)
+        from lumina_t2x_amd.transport.mini import ODE
+        grid = ODE(n, method, shift if shift > 0 else None).t
+    else:
+        grid = OD.time_grid(n, shift if shift > 0 else None)
     np.testing.assert_array_equal(grid.numpy(), g["grid"])
     pts = [int(p) for p in g["points"]]
     assert pts[-1] == n - 1 and g["ref_points"].shape[0] == len(pts) == g["floor_points"].shape[0]
