@@ -269,6 +269,16 @@ int lt_op_gated_residual_norm(void* x_dev, const void* y_dev, const void* post_w
                               const void* next_shift_dev, int32_t next_mode, int32_t ld_mod,
                               void* h_dev, int32_t B, int32_t N, int32_t d, float eps,
                               float eps_next, int32_t scale_pre, void* stream);
+/* y = A W^T (A bf16 [B*N, K], W bf16 [d, K]; `wo` / `w2`, model.py:436-438, :502) followed by the sandwich-norm step on it with the
+ * engine's prepared vectors (gate = tanh(gate), next_scale = 1 + scale, both bf16 [B, ld_mod]):
+ *   x += gate * RMSNorm(y; post_w) ; h = RMSNorm(x; next_w) * next_scale          (model.py:597-610)
+ * use_ystat 1 (what the engine does by default): the projection's epilogue leaves every row's sum of squares in ystat_ws (fp32 [B*N, ystat_cap],
+ * ystat_cap >= 2 * ceil(d / 256)) and the row kernel streams; refused when the problem does not take the persistent GEMM kernel.
+ * use_ystat 0: the row kernel reduces y itself.  The two differ in the fp32 summation order of that statistic only. */
+int lt_op_proj_gated_residual_norm(const void* A_dev, const void* W_dev, void* y_dev, void* ystat_ws_dev, int32_t ystat_cap, int32_t K,
+                                   void* x_dev, const void* post_w_dev, const void* gate_dev, const void* next_w_dev,
+                                   const void* next_scale_dev, int32_t ld_mod, void* h_dev, int32_t B, int32_t N, int32_t d, float eps,
+                                   int32_t use_ystat, void* stream);
 /* adaLN vectors, in place (mod bf16 [B, ld_mod] = L layers x `chunks` chunks of d, then the final layer's chunks): chunk c of
  * every layer -> bf16(tanh(.)) if bit c of tanh_mask, bf16(1 + .) if bit c of scale_mask; final_scale_chunk >= 0: that chunk
  * of the final layer -> bf16(1 + .).  The row kernels then run with gate_mode 0 and scale_pre 1. */

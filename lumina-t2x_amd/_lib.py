@@ -117,6 +117,7 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_op_linear_small_m": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_rope_table_2d": (_i32, [_vp, _i32, _i32, _f32, _f32, _vp]),
     "lt_op_rope_table_2d_pair": (_i32, [_vp, _vp, _i32, _i32, _f32, _f32, _vp]),
+    "lt_op_proj_gated_residual_norm": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lt_op_qkv_qstat": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp]),
     "lt_op_attention_qraw": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
 }

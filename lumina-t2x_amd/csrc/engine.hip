@@ -147,6 +147,8 @@ struct lt_engine {
     int moe_rec_on = 0, moe_force_rows = 0, moe_rec_rows = 0;
     int qstat_slots = 32;
     float* qstat = nullptr;  // [rows][qstat_slots] float2: LayerNorm partial sums of the Q columns, written by the fused QKV GEMM (GemmArgs::qstat)
+    float* ystat = nullptr;  // [rows][ystat_cap] floats: per-row sum-of-squares partials of the O / W2 projection's output (GemmArgs::ystat -> GatedResArgs::ystat)
+    int ystat_cap = 0;
     float* qmr = nullptr;    // [rows] float2 (mean, rstd) of the Q rows, reduced from qstat by the K pass of qk_norm_rope (AttnArgs::q_stat)
     float* rope_tr = nullptr;  // the 2-D rotary table once more as [branch][freq][pos] (AttnArgs::rope_cs_t)
     // split-K workspace of the 512-row-class GEMMs (GemmArgs::splitk_*): 128 tiles = one round of half the CUs
@@ -242,12 +244,18 @@ void prefetch_rider(lt_engine* e, PrefetchRider* r, const u16* A, int lda, const
     if (!gemm_prefetch_rider(g, epi, r)) *r = PrefetchRider();
 }
 
+// ystat_slots (optional, out): > 0 when the launch left the rows' sum-of-squares partials in e->ystat (option grn_ystat; GemmArgs::ystat)
 int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int ldc, int M, int N, int K,
-         const u16* bias, int epi, hipStream_t s) {
+         const u16* bias, int epi, hipStream_t s, int* ystat_slots = nullptr) {
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.bias_dtype = bias ? 1 : -1;
     g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;  // (the launcher decides)
+    if (ystat_slots) {
+        *ystat_slots = 0;
+        const int ys = lt_opt(OPT_GRN_YSTAT) && !bias ? gemm_ystat_slots(g, epi) : 0;
+        if (ys > 0 && ys <= e->ystat_cap && ys % 4 == 0) { g.ystat = e->ystat; g.ystat_slots = ys; *ystat_slots = ys; }
+    }
     if (lt_opt(OPT_GEMM_PREFETCH) == 1 && M <= 1024 && launch_gemm_prefetch_w(g, epi, s)) return 1;
     ProfScope ps(e, 0, 2.0 * M * (double)N * K, s, true);
     return launch_gemm_bf16(g, epi, 0, s, ps.ev0(), ps.ev1());
@@ -717,10 +725,12 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             at.Nk = e->prompt_T; at.Nkpad = e->prompt_Tpad; at.scale = (float)(1.0 / std::sqrt((double)hd));
             if (attention(e, at, s)) return 1;
         }
-        if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s)) return 1;
+        int ys_o = 0, ys_f = 0;
+        if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s, &ys_o)) return 1;
         {   // x += gate' * post(attn) ; h = pre_ffn(x) * (1 + scale) [+ shift]
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
+            if (ys_o) { g.ystat = e->ystat; g.ystat_slots = ys_o; }
             g.x = e->x; g.y = e->o; g.post_w = v.post ? w.attn_norm2 : nullptr; g.gate = chunk(l, v.i_gate[0]);
             g.post_mode = post_mode; g.gate_mode = gate_mode;
             g.next_w = v.pre_w ? w.ffn_norm1 : nullptr; g.next_scale = chunk(l, v.i_scale[1]); g.next_shift = chunk(l, v.i_shift[1]);
@@ -732,7 +742,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         const u16 *last_post_w, *last_gate;
         if (e->E == 0) {
             if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s)) return 1;
-            if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s)) return 1;
+            if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s, &ys_f)) return 1;
             last_post_w = v.post ? w.ffn_norm2 : nullptr;
             last_gate = chunk(l, v.i_gate[1]);
         } else if (e->moe_mode != 0) {  // one MoE FFN in the ImageNet block (models.py:755-758: time-routed; models1.py: per token)
@@ -766,6 +776,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
             g.x = e->x; g.y = e->o; g.post_w = last_post_w; g.gate = last_gate;
+            if (ys_f) { g.ystat = e->ystat; g.ystat_slots = ys_f; }
             if (e->E != 0) moe_y(e, g, e->moe_mode == 1 ? l : -1);
             g.post_mode = post_mode; g.gate_mode = gate_mode; g.h = e->h;
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
@@ -1052,6 +1063,9 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         e->qstat = (float*)q;
         if (dev_alloc(e, &q, M * 2 * sizeof(float))) return fail();
         e->qmr = (float*)q;
+        e->ystat_cap = 2 * ((d + 255) / 256);  // two wave halves per 256- or 288-column tile of a d-wide projection
+        if (dev_alloc(e, &q, M * (size_t)e->ystat_cap * sizeof(float))) return fail();
+        e->ystat = (float*)q;
     }
     {   // split-K workspace (zeroed by dev_alloc: the counters must start at 0; every launch leaves them at 0)
         void* q;
@@ -1710,6 +1724,31 @@ extern "C" int lt_op_gated_residual_norm(void* x, const void* y, const void* pos
     g.h = (u16*)h; g.rows = B * N; g.rows_per_batch = N; g.d = d; g.ld_mod = ld_mod; g.post_mode = post_mode;
     g.gate_mode = gate_mode; g.next_mode = next_mode; g.eps = eps; g.eps_next = eps_next; g.scale_pre = scale_pre;
     return launch_gated_residual_norm(g, (hipStream_t)stream);
+}
+
+// The O / W2 projection followed by the sandwich-norm row step - exactly the two launches the engine makes per branch.  use_ystat 1: the
+// GEMM's epilogue leaves the rows' sum-of-squares partials in ystat_ws and the row kernel runs its streaming form on them (option grn_ystat's
+// path; refused when the problem does not take the persistent kernel's plain dense tiles); 0: the row kernel reduces y itself.
+extern "C" int lt_op_proj_gated_residual_norm(const void* A, const void* W, void* y, void* ystat_ws, int32_t ystat_cap, int32_t K, void* x,
+                                              const void* post_w, const void* gate, const void* next_w, const void* next_scale, int32_t ld_mod,
+                                              void* h, int32_t B, int32_t N, int32_t d, float eps, int32_t use_ystat, void* stream) {
+    LT_REQUIRE(A && W && y && x && post_w && gate && next_w && next_scale && h, "lt_op_proj_gated_residual_norm: null pointer");
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)y; g.bias = nullptr; g.M = B * N; g.N = d; g.K = K; g.lda = K; g.ldw = K; g.ldc = d;
+    g.bias_dtype = -1;
+    GatedResArgs r;
+    if (use_ystat) {
+        const int ys = gemm_ystat_slots(g, 0);
+        LT_REQUIRE(ys > 0 && ys % 4 == 0, "lt_op_proj_gated_residual_norm: this problem does not run on the persistent kernel's plain dense tiles (no ystat)");
+        LT_REQUIRE(ystat_ws && ystat_cap >= ys, "lt_op_proj_gated_residual_norm: ystat workspace of %d floats per row, the launch fills %d", ystat_cap, ys);
+        g.ystat = (float*)ystat_ws; g.ystat_slots = ys;
+        r.ystat = (const float*)ystat_ws; r.ystat_slots = ys;
+    }
+    if (int rc = launch_gemm_bf16(g, 0, 0, (hipStream_t)stream)) return rc;
+    r.x = (u16*)x; r.y = (const u16*)y; r.post_w = (const u16*)post_w; r.gate = (const u16*)gate; r.next_w = (const u16*)next_w;
+    r.next_scale = (const u16*)next_scale; r.next_shift = nullptr; r.h = (u16*)h; r.rows = B * N; r.rows_per_batch = N; r.d = d; r.ld_mod = ld_mod;
+    r.post_mode = 1; r.gate_mode = 0; r.next_mode = 1; r.eps = eps; r.eps_next = 1e-6f; r.scale_pre = 1;
+    return launch_gated_residual_norm(r, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_prep_mod(void* mod, int32_t B, int32_t ld_mod, int32_t L, int32_t chunks, int32_t d, uint32_t tanh_mask,

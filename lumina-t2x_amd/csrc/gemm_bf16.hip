@@ -81,7 +81,7 @@ int ensure_dynamic_lds(const void* fn, int bytes) {
 // a 32-row pair of V^T tiles inside one sample, at least one tile per CU, offsets that fit the buffer instructions' 32-bit arithmetic.
 // Returns the tile width (288 / 256) or 0.
 int gemm_qkv_fused_tile(const GemmArgs& a) {
-    if (a.tile_expert || a.trace || a.bias_dtype >= 0 || a.K % 64 != 0 || a.K < 128 || !a.VT) return 0;
+    if (a.tile_expert || a.trace || a.bias_dtype >= 0 || a.K % 64 != 0 || a.K < (LT_W4Q_PD == 4 ? 192 : 128) || !a.VT) return 0;
     if (a.vt_split <= 0 || a.N <= a.vt_split) return 0;
     int bn = 0;
     if (a.vt_split % 288 == 0 && (a.N - a.vt_split) % 288 == 0) bn = 288;
@@ -196,7 +196,7 @@ bool w4q_grouped_ok(const GemmArgs& a, int epilogue) {
 //          15 / 16 = persistent 4 waves on 16x16x32 MFMAs, 256x256 / 256x288 tiles;
 //          4, 5, 6, 9 .. 14, 17, 18 = study kernels of rounds 1-3, removed (git history)
 GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
-    const bool w4p_ok = !a.tile_expert && !a.trace && a.bias_dtype < 0 && a.K % 64 == 0 && a.K >= 128 &&
+    const bool w4p_ok = !a.tile_expert && !a.trace && a.bias_dtype < 0 && a.K % 64 == 0 && a.K >= (LT_W4Q_PD == 4 ? 192 : 128) &&
                         255LL * a.ldc * 2 + (long long)a.N * 2 < 0x7fffffffLL && epilogue != 2;
     if (epilogue == 3) { const int bn = gemm_qkv_fused_tile(a); return bn == 288 ? GK_W4Q288_QKV : bn == 256 ? GK_W4Q256_QKV : GK_NONE; }
     if (a.tile_expert && (variant == 15 || (variant == 0 && lt_opt(OPT_GEMM_VARIANT) == 0 && lt_opt(OPT_GEMM_W4Q) && lt_opt(OPT_GEMM_W4Q_GROUPED) &&
@@ -289,6 +289,11 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         LT_REQUIRE((k == GK_S128 || k == GK_S64) && epilogue == 0, "gemm: rowstat is written by the small-M tiles' plain epilogue only (this problem runs %s)", kGemmKernelName[k]);
         LT_REQUIRE(a.rowstat_slots >= (a.N + 127) / 128, "gemm: rowstat_slots %d < %d column tiles", a.rowstat_slots, (a.N + 127) / 128);
     }
+    if (a.ystat) {
+        LT_REQUIRE((k == GK_W4Q256 || k == GK_W4Q288) && epilogue == 0, "gemm: ystat is written by the persistent kernel's plain dense tiles only (this problem runs %s)", kGemmKernelName[k]);
+        const int want = 2 * ((a.N + (k == GK_W4Q288 ? 287 : 255)) / (k == GK_W4Q288 ? 288 : 256));
+        LT_REQUIRE(a.ystat_slots == want && (long long)a.M * want * 4 < 0x7fffffffLL, "gemm: ystat_slots %d, this launch fills %d per row (gemm_ystat_slots)", a.ystat_slots, want);
+    }
     if (a.a_row_map) {  // gather-on-load lives in the ping-pong kernels' staging (the grouped SwiGLU GEMM of the MoE layers)
         LT_REQUIRE(k == GK_PP256_SWIGLU || k == GK_PP256 || k == GK_S128 || k == GK_S128_SWIGLU || k == GK_S64 || k == GK_W4Q256_GROUPED ||
                    k == GK_W4Q256_SWIGLU_GROUPED,
@@ -332,6 +337,14 @@ __global__ __launch_bounds__(256) void gemm_prefetch_w_kernel(PrefetchRider r) {
 // lt_set_option "gemm_prefetch": 3 (default) = the W panels of the 512-row-class GEMMs are read by rider workgroups of the row kernel
 // that precedes the GEMM (cfg 1 -1.6 %, cfg 5 -1..3 % on a fast-class box, -6.5 % on a slow one); 0 = off; 1 = a prefetch launch right in
 // front of every small-M GEMM (same stream: the upper bound experiment); 2 = on a side stream beside the preceding kernel (loses 33 %)
+
+int gemm_ystat_slots(const GemmArgs& a, int epilogue) {
+    if (epilogue != 0) return 0;
+    const GemmKernel k = choose(a, epilogue, 0);
+    if (k == GK_W4Q288) return 2 * ((a.N + 287) / 288);
+    if (k == GK_W4Q256) return 2 * ((a.N + 255) / 256);
+    return 0;
+}
 
 bool gemm_is_small_m(const GemmArgs& a, int epilogue) {
     const GemmKernel k = choose(a, epilogue, 0);

@@ -868,8 +868,17 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 // of a tile is row a_row_map[m0 + r] of A (-1: reads as zero).  The A stream then goes through ONE descriptor over all of A with
 // per-tile lane offsets; the 256 map entries of the tile after next are fetched by a 4-byte LDS-DMA at every tile boundary (counted
 // in the hand-kept vmcnt like the slabs) and turned into lane offsets where the DMA stream crosses into that tile.  K >= 256.
+// LT_W4Q_PD (round 6): how many slabs ahead of the one being multiplied the LDS-DMA stream runs.  Body g multiplies slab g from
+// registers and reads slab g + 1's fragments, so slot g & 3 has been free since the barrier that ended body g - 1: the four-slot ring
+// carries a distance of 4 as well as the 3 it was built with (rounds 2-5), with one more body of cover for every fill (slab g + 2 must have
+// landed at the end of body g in both forms; 3: issued during body g - 1, 4: during body g - 2) and one more slab in flight.
+#ifndef LT_W4Q_PD
+#define LT_W4Q_PD 3
+#endif
 template <int EPI, int NW16, bool TRACE = false, bool GROUPED = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
+    constexpr int PD = LT_W4Q_PD;
+    static_assert(PD == 3 || PD == 4, "the DMA stream runs 3 or 4 slabs ahead (4 ring slots, fragments of slab g + 1 in registers during body g + 1)");
     constexpr int MT = 8, NT = NW16, NW = 4, BM = 256, BN = 2 * NW16 * 16;
     constexpr int PA = BM / 16, PW = BN / 16, NP = PA + PW;   // 1-KiB staging pieces (16 rows x 64 B) per slab
     constexpr int IP = (NP + NW - 1) / NW;                    // pieces per wave and slab (a surplus slot re-loads the wave's last piece)
@@ -877,7 +886,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     constexpr int NM = MT * NT, RD = MT + NT, EVERY = NM / IP, RS = NM / RD;
     constexpr int NST = EPI != 1 ? MT * (NT / 2) + (NT % 2 ? MT : 0) : MT * (NT / 4);  // store instructions per wave and tile
     constexpr int NST_V = (MT / 2) * NT;  // ... of a V^T tile (EPI 3)
-    constexpr int NST_Q = EPI == 3 ? MT : 0;  // EPI 3, plain tiles: + the LayerNorm partial-sum stores (one per row tile and wave, always issued)
+    constexpr bool YST = EPI == 0 && !GROUPED;  // round 6: the plain dense kernels can emit per-row sums of squares of their outputs (GemmArgs::ystat)
+    constexpr int NST_Q = (EPI == 3 || YST) ? MT : 0;  // plain tiles of EPI 3 / YST: + the partial-sum stores (one per row tile and wave, always issued)
     static_assert(NM % IP == 0 && RS >= 1 && (RD - 1) * RS + 4 <= NM, "one LDS-DMA per EVERY MFMAs, one fragment read per RS MFMAs, the last one >= 4 MFMAs before the wait");
     static_assert(EPI != 1 || NT % 4 == 0, "SwiGLU pairs 32-column groups");
     static_assert(PA % NW == 0, "A pieces first: slot i < PA / NW is an A piece for every wave");
@@ -1023,14 +1033,15 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     stage_from(0, 0, cur);
     stage_from(1, 1, cur);
     stage_from(2, 2, cur);
-    wait_vmcnt<2 * IP>();
+    if constexpr (PD == 4) stage_from(3, 3, cur);
+    wait_vmcnt<(PD - 1) * IP>();
     pp_barrier();
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(smem + w_row_off + nt * 1024);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf16x8*)(smem + a_row_off + mt * 1024);
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    wait_vmcnt<IP>();
+    wait_vmcnt<(PD - 2) * IP>();
     pp_barrier();
 
     int after_epilogue = 0;  // stores of the previous tile's epilogue still in the queue: 0 none, 1 NST, 2 NST_V (EPI 3: a V^T tile)
@@ -1040,8 +1051,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     // add.  (Round 2's first form rebuilt descriptors, slot offsets and the tile selects at the top of every body: ~25 dependent
     // scalar instructions per slab in front of an idle matrix pipe - profiles/r02/gemm_trace_w4q.log, 80-87 % main-loop duty.)
     int rd_off = SLAB;       // LDS offset of slab g + 1 (fragment reads of this body)
-    int wr_off = 3 * SLAB;   // LDS offset of slab g + 3 (LDS-DMA destination of this body)
-    int d_soff = 3 * 64;     // byte offset along K of the slab the DMA stream fetches next ...
+    int wr_off = (PD & 3) * SLAB;   // LDS offset of slab g + PD (LDS-DMA destination of this body)
+    int d_soff = PD * 64;     // byte offset along K of the slab the DMA stream fetches next ...
     __amdgpu_buffer_rsrc_t dA = __builtin_amdgcn_make_buffer_rsrc((void*)cur.a, 0, cur.a_bytes, 0x00020000);   // ... in this tile
     __amdgpu_buffer_rsrc_t dW = __builtin_amdgcn_make_buffer_rsrc((void*)cur.w, 0, cur.w_bytes, 0x00020000);
     const int kbytes = ns * 64;
@@ -1109,14 +1120,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): slab g+1's fragments are in registers
         // slab g+2 landed; still allowed in flight: this body's IP DMAs and, right after a tile boundary, the NST stores issued
         // between slab g+2's DMAs and them (loads and stores retire in issue order, one counter)
+        // (PD - 2 slabs of DMAs: slabs g + 3 .. g + PD; the counter has 6 bits - a smaller bound only waits for more than it needs)
+        constexpr int INF = (PD - 2) * IP;
+        constexpr auto cap = [](int n) constexpr { return n < 63 ? n : 63; };
         if constexpr (FIRST) {
-            if (GROUPED && after_epilogue == 1 && gather) wait_vmcnt<IP + NST + 1>();  // + the map LDS-DMA issued behind the stores
-            else if (after_epilogue == 1) wait_vmcnt<IP + NST + NST_Q>();
-            else if (EPI == 3 && after_epilogue == 2) wait_vmcnt<IP + NST_V>();
-            else wait_vmcnt<IP>();
+            if (GROUPED && after_epilogue == 1 && gather) wait_vmcnt<cap(INF + NST + 1)>();  // + the map LDS-DMA issued behind the stores
+            else if (after_epilogue == 1) wait_vmcnt<cap(INF + NST + NST_Q)>();
+            else if (EPI == 3 && after_epilogue == 2) wait_vmcnt<cap(INF + NST_V)>();
+            else wait_vmcnt<INF>();
             after_epilogue = 0;
         } else {
-            wait_vmcnt<IP>();
+            wait_vmcnt<INF>();
         }
         pp_barrier();
     };
@@ -1135,12 +1149,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         // EPI 3: LayerNorm partial sums of the Q columns (GemmArgs::qstat) - v_dot2_f32_bf16 of each packed output pair with (1, 1) and
         // with itself: the sums run over the ROUNDED values, which is what the reference normalises (nn.LayerNorm of the bf16 Linear output)
         const bool stats = EPI == 3 && p.qstat != nullptr && t.n0 < p.qstat_cols;
+        const bool ystats = YST && p.ystat != nullptr;
         typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
         const bf2_t ones2 = __builtin_bit_cast(bf2_t, 0x3F803F80u);
         float st1[MT], st2[MT];
         auto stat_add = [&](int mt, unsigned w) __attribute__((always_inline)) {
             const bf2_t v = __builtin_bit_cast(bf2_t, w);
             st1[mt] = __builtin_amdgcn_fdot2_f32_bf16(v, ones2, st1[mt], false);
+            st2[mt] = __builtin_amdgcn_fdot2_f32_bf16(v, v, st2[mt], false);
+        };
+        auto stat_sq = [&](int mt, unsigned w) __attribute__((always_inline)) {
+            const bf2_t v = __builtin_bit_cast(bf2_t, w);
             st2[mt] = __builtin_amdgcn_fdot2_f32_bf16(v, v, st2[mt], false);
         };
 #pragma unroll
@@ -1154,6 +1173,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
                     const unsigned a0 = pack2bf_pk(a[0], a[1]), a1 = pack2bf_pk(a[2], a[3]);
                     const unsigned b0 = pack2bf_pk(b[0], b[1]), b1 = pack2bf_pk(b[2], b[3]);
                     if constexpr (EPI == 3) { if (stats) { stat_add(mt, a0); stat_add(mt, a1); stat_add(mt, b0); stat_add(mt, b1); } }
+                    if constexpr (YST) { if (ystats) { stat_sq(mt, a0); stat_sq(mt, a1); stat_sq(mt, b0); stat_sq(mt, b1); } }
                     auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                     auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                     // lane rows 0 / 2 hold tile 2 np, columns 0..7 / 8..15; lane rows 1 / 3 tile 2 np + 1
@@ -1166,6 +1186,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
                     const f32x4 a = acc[mt][NT - 1];
                     const u32x2_t o = {pack2bf_pk(a[0], a[1]), pack2bf_pk(a[2], a[3])};
                     if constexpr (EPI == 3) { if (stats) { stat_add(mt, o[0]); stat_add(mt, o[1]); } }
+                    if constexpr (YST) { if (ystats) { stat_sq(mt, o[0]); stat_sq(mt, o[1]); } }
                     const int col = nbase + (NT - 1) * 16 + 4 * q4;
                     const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b64(o, rC, off, 0, 0);
@@ -1206,6 +1227,23 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
                 const u32x2_t o = {__float_as_uint(a), __float_as_uint(b)};
                 const int off = (q4 == 0 && row < p.M) ? (row * p.qstat_slots + slot) * 8 : (int)0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b64(o, rS, off, 0, 0);
+            }
+        }
+        if constexpr (YST) {
+            // GemmArgs::ystat: sum of squares of this wave's ROUNDED outputs of every row of the tile -> ystat[row][2 * column tile + wn]
+            // (what the RMSNorm of the consuming row kernel needs of the row before it can start: norm.hip, GatedResArgs::ystat).  Always
+            // MT store instructions per wave and tile, like EPI 3's (NST_Q)
+            const long long y_all = (long long)p.M * p.ystat_slots * 4;
+            const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.ystat, 0, ystats ? (int)(y_all > 0x7fffffffLL ? 0x7fffffffLL : y_all) : 0, 0x00020000);
+            const int slot = 2 * (t.n0 / BN) + wn;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float b = st2[mt];
+                b += __shfl_xor(b, 16, 64);
+                b += __shfl_xor(b, 32, 64);
+                const int row = t.m0 + wm * (MT * 16) + mt * 16 + l15;
+                const int off = (q4 == 0 && row < p.M) ? (row * p.ystat_slots + slot) * 4 : (int)0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b), rS, off, 0, 0);
             }
         }
     };
@@ -1259,7 +1297,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             }
         }
     };
-    // one tile: slab s prefetches slab s + 3 (the last three: the next tile's slabs 0, 1, 2)
+    // one tile: slab s prefetches slab s + PD (the last PD: the next tile's first slabs)
     auto run_tile = [&](auto swap_tag) __attribute__((always_inline)) {
         body(std::true_type{}, swap_tag, wf, af, wf2, af2);
         body(std::false_type{}, swap_tag, wf2, af2, wf, af);

@@ -49,6 +49,12 @@ struct GemmArgs {
     // attention kernel (AttnSmallArgs) reduces; the launcher refuses it on any other kernel
     float* rowstat = nullptr;
     int rowstat_slots = 0;
+    // round 6 (the persistent 16x16x32 kernel's plain dense instantiations only; gemm_ystat_slots() says whether a launch takes one):
+    // ystat[row][slot] = sum of squares of the bf16-ROUNDED outputs of the row in column tile n0 / BN, wave column-half wn
+    // (slot = 2 * (n0 / BN) + wn; ystat_slots = 2 * ceil(N / BN) floats per row) - the RMSNorm statistic of the row kernel that
+    // consumes C (GatedResArgs::ystat), which can then start on a row's first bytes instead of after its last
+    float* ystat = nullptr;
+    int ystat_slots = 0;
     int group_rows = 0;  // experiment knob (lt_set_option "gemm_group"): tile rows per group of the XCD-aware tile order (0 = 4)
     int stagger = 0;  // experiment knob of the 4-wave kernels (lt_set_option "gemm_stagger"), filled by the launcher
 };
@@ -64,6 +70,7 @@ struct PrefetchRider {
     int first = 0x7fffffff, blocks = 0;
 };
 bool gemm_prefetch_rider(const GemmArgs& a, int epilogue, PrefetchRider* r);
+int gemm_ystat_slots(const GemmArgs& a, int epilogue);  // > 0: launch_gemm_bf16 would run this problem on a kernel that can fill GemmArgs::ystat, with this many slots per row
 bool gemm_is_small_m(const GemmArgs& a, int epilogue);  // launch_gemm_bf16 would run this problem on the 128 x 128 / 64 x 128 small-M tiles (GemmArgs::rowstat needs them)
 int launch_gemm_prefetch_w(const GemmArgs& a, int epilogue, hipStream_t stream);  // experiment: W panels of a small-M GEMM -> the L2 of the XCDs that will stage them
 bool gemm_qkv_fusable(const GemmArgs& a);
@@ -112,6 +119,12 @@ struct GatedResArgs {
     int* route_sel = nullptr;
     u16* route_wts = nullptr;
     const int* route_forced = nullptr;
+    // round 6: the sum of squares of every row of y, in ystat_slots partial sums per row, left behind by the GEMM that wrote y
+    // (GemmArgs::ystat).  With it the first RMSNorm needs nothing of the row but the element at hand: the dense post_mode 1 / gate_mode 0 /
+    // next_mode 1 combination then runs a streaming kernel (8-byte steps, 64 registers, eight waves per SIMD: all rows of a 8192-row
+    // launch resident at once) instead of "load the row, reduce, apply".  Ignored (the kernel reduces y itself) by every other combination.
+    const float* ystat = nullptr;
+    int ystat_slots = 0;
 };
 int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream);
 

@@ -244,6 +244,84 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
     }
 }
 
+// ---- round 6: the streaming form of the dense sandwich-norm step (post_mode 1, gate_mode 0, next_mode 1) ---------------------------
+// rocprofv3 had the kernel above at 33.9 us for 151 MB at cfg 2 (4.45 TB/s) with ~600 VALU instructions per row on the hot path: not
+// issue-bound any more (round 2's 1257 were), but 80 VGPRs = six waves per SIMD for eight rows per SIMD - the launch runs as 1.33
+// rounds of latency-bound waves, each of which loads its whole row, reduces it and only then starts to work.  With the row's sum of
+// squares known beforehand (GatedResArgs::ystat: the O / W2 GEMM's epilogue leaves it behind) nothing in the first half needs more than
+// the element at hand: every lane walks its NH 8-byte steps (d = 256 NH: 4 bf16 per lane and step, 64 lanes x NH steps cover the row
+// exactly - the 16-byte layout above idles half the wave in its fifth chunk at d = 2304), keeps only the packed new residual for the
+// second norm, and the kernel fits 64 registers.  Same statements in the same order as the kernel above; the one difference is the
+// summation order of sum(y^2) (per GEMM tile and wave half, then over the slots).
+typedef __attribute__((ext_vector_type(2))) unsigned nt_u32x2;
+// (launcher: next_w and next_scale present, scale_pre 1, no next_shift - Next-DiT's block; everything else takes the kernel above)
+template <int NH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void gated_residual_norm_ys_kernel(GatedResArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row >= p.rows) return;
+    const int b = row / p.rows_per_batch;
+    u16* xrow = p.x + (size_t)row * p.d + lane * 4;
+    const u16* yrow = p.y + (size_t)row * p.d + lane * 4;
+    const u16* gate = p.gate + (size_t)b * p.ld_mod + lane * 4;
+    const u16* postw = p.post_w + lane * 4;
+    // the whole row of y and x in flight at once (2 NH eight-byte loads per lane; x' overwrites x's registers), the per-sample vectors
+    // one step ahead of their use (they come from the L1 / L2)
+    nt_u32x2 yv[NH], xv[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        yv[i] = *(const nt_u32x2*)(yrow + 256 * i);
+        xv[i] = *(const nt_u32x2*)(xrow + 256 * i);
+    }
+    nt_u32x2 wv = *(const nt_u32x2*)postw, gv = *(const nt_u32x2*)gate;
+    const float* ys = p.ystat + (size_t)row * p.ystat_slots;
+    float ss = 0.f;
+    for (int s = 0; s < p.ystat_slots; s += 4) {  // wave-uniform address: scalar loads
+        const f32x4 v = *(const f32x4*)(ys + s);
+        ss += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float rinv = rsqrtf(ss / (float)p.d + p.eps);
+    const f32x2 rv = {rinv, rinv};
+    // x' = bfr(x + bfr(g * bfr(bfr(y * rinv) * w)))
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        nt_u32x2 wn = wv, gn = gv;
+        if (i + 1 < NH) { wn = *(const nt_u32x2*)(postw + 256 * (i + 1)); gn = *(const nt_u32x2*)(gate + 256 * (i + 1)); }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x2 yn = bfr2(bfr2(unpk_bf(yv[i][k]) * rv) * unpk_bf(wv[k]));
+            yn = bfr2(unpk_bf(gv[k]) * yn);
+            xv[i][k] = pk_bf(unpk_bf(xv[i][k]) + yn);
+        }
+        __builtin_nontemporal_store(xv[i], (nt_u32x2*)(xrow + 256 * i));  // (see the kernel above: the residual stream is not read again soon)
+        wv = wn; gv = gn;
+    }
+    const u16* nw = p.next_w + lane * 4;
+    const u16* nscale = p.next_scale + (size_t)b * p.ld_mod + lane * 4;
+    nt_u32x2 w2 = *(const nt_u32x2*)nw, s2 = *(const nt_u32x2*)nscale;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bf16x2_t v = __builtin_bit_cast(bf16x2_t, xv[i][k]);
+            s4[(2 * i + k) & 3] = __builtin_amdgcn_fdot2_f32_bf16(v, v, s4[(2 * i + k) & 3], false);
+        }
+    const float r2 = rsqrtf(wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) / (float)p.d + p.eps);
+    const f32x2 r2v = {r2, r2};
+    u16* hrow = p.h + (size_t)row * p.d + lane * 4;
+    // h = bfr(bfr(bfr(x' * r2) * w) * (1 + scale)) with (1 + scale) prepared in bf16: apply_rms_mod_store, 8 bytes at a time
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        nt_u32x2 wn = w2, sn = s2, o;
+        if (i + 1 < NH) { wn = *(const nt_u32x2*)(nw + 256 * (i + 1)); sn = *(const nt_u32x2*)(nscale + 256 * (i + 1)); }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) o[k] = pk_bf(bfr2(bfr2(unpk_bf(xv[i][k]) * r2v) * unpk_bf(w2[k])) * unpk_bf(s2[k]));
+        *(nt_u32x2*)(hrow + 256 * i) = o;
+        w2 = wn; s2 = sn;
+    }
+}
+
 }  // namespace
 
 #define LT_DISPATCH_CHUNKS(kernel, grid, args)                                                          \
@@ -309,6 +387,17 @@ int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
         }
         LT_CHECK_HIP(hipGetLastError());
         return 0;
+    }
+    // the streaming kernel (GatedResArgs::ystat): dense, weighted post-norm, prepared gate, next pre-norm; d = 256 NH; no riders (large-M launches)
+    if (a.ystat && lt_opt(OPT_NORM_SPECIALIZE) && !a.apex && a.gate_mode == 0 && a.post_mode == 1 && a.next_mode == 1 && a.pf.blocks == 0 &&
+        a.next_w && a.next_scale && a.scale_pre && !a.next_shift && a.y && a.d % 256 == 0 && a.ystat_slots > 0 && a.ystat_slots % 4 == 0) {
+        const int nh = a.d / 256;
+        if (nh == 6 || nh == 9) {  // (d = 3072 / 4096 do not fit the 64 registers of eight waves per SIMD: the kernel above)
+            if (nh == 6) hipLaunchKernelGGL(gated_residual_norm_ys_kernel<6>, grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(gated_residual_norm_ys_kernel<9>, grid, dim3(256), 0, stream, a);
+            LT_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
     }
     if (lt_opt(OPT_NORM_SPECIALIZE) && !a.apex && a.gate_mode == 0 && (a.post_mode == 0 || a.post_mode == 1) && (a.next_mode == 1 || a.next_mode == 2)) {
         const int nch64 = ((a.d >> 3) + 63) / 64;

@@ -149,6 +149,119 @@ def reference_calls(case, sd, make_inputs):
     return outs
 
 
+def _record_routing(model, n_layers):
+    """forward hooks on the routers of the reference's TimeMoeLayer / SpaceMoeLayer (Next-DiT-MoE/models/models2.py:459-506): the top-k
+    ids each MoE layer selects, in oracle.variants_oracle.MoeRouting's table format ([L][time, space][rows][k], ascending per row)."""
+    rec, hooks = {}, []
+    for name, m in model.named_modules():
+        kind = type(m).__name__
+        if kind not in ("TimeMoeLayer", "SpaceMoeLayer"):
+            continue
+        layer = int(name.split(".")[1])
+        where = (layer, 0 if kind == "TimeMoeLayer" else 1)
+
+        def hook(mod, args, out, where=where, k=m.num_experts_per_tok):
+            rec[where] = torch.sort(torch.topk(out, k).indices, dim=1).values.to(torch.int32).numpy().copy()
+
+        hooks.append(m.gate.register_forward_hook(hook))
+    return rec, hooks
+
+
+def reference_bf16_calls(case, sd, make_inputs):
+    """The yardstick's pin: the UNMODIFIED reference module moved to bfloat16 - `model.eval().to(dtype)` as
+    lumina_next_t2i/sample.py:129 does - with flash_attn replaced by oracle/stubs/flash_attn (fp32-accumulate SDPA, one cast back),
+    run once plain and once under torch.autocast (sample.py:173 wraps the sampling loop in it; on CPU: autocast("cpu", bfloat16)).
+    The mini fork's `use_flash_attn=True` branch (lumina_next_t2i_mini/models/nextdit.py:328-357) never builds the N x N mask, so the
+    16 384-token case runs here too.  Returns {tag: (plain, autocast, routing-or-None)}."""
+    os.environ["TORCHDYNAMO_DISABLE"] = "1"
+    cfg = case["cfg"]
+    mod = _fresh_import(case["pkg"], case["module"])
+    cls = getattr(mod, case["cls"])
+    kw = cfg.ctor_kwargs()
+    if "use_flash_attn" in cls.__init__.__code__.co_varnames:
+        kw["use_flash_attn"] = True
+    model = cls(**kw).eval()
+    res = model.load_state_dict(sd, strict=True, assign=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.to(torch.bfloat16)   # new bf16 parameters; the fp32 draw `sd` is untouched
+    gc.collect()
+    outs = {}
+    with torch.no_grad():
+        for tag, tv, ckw in case["calls"]:
+            got = []
+            routing = None
+            for ac in (False, True):
+                ins = make_inputs(tv)
+                ckw2 = dict(ckw)
+                scale = ckw2.pop("cfg_scale")
+                rec, hooks = _record_routing(model, cfg.n_layers)
+                t0 = time.time()
+                with torch.autocast("cpu", torch.bfloat16, enabled=ac):
+                    if cfg.has_text:
+                        z, t, cap, mask = ins
+                        o = model.forward_with_cfg(z.to(torch.bfloat16), t, cap.to(torch.bfloat16), mask, scale, **ckw2)
+                    else:
+                        z, t, y = ins
+                        o = model.forward_with_cfg(z.to(torch.bfloat16), t, y, scale, **ckw2)
+                for h in hooks:
+                    h.remove()
+                assert o.dtype == torch.bfloat16, o.dtype
+                got.append(o.float().numpy().copy())
+                if rec and not ac:
+                    rows = max(v.shape[0] for v in rec.values())
+                    routing = np.full((cfg.n_layers, 2, rows, 2), -1, dtype=np.int32)
+                    for (l, b), v in rec.items():
+                        routing[l, b] = v if v.shape[0] == rows else np.repeat(v, rows // v.shape[0], axis=0)  # time router: one row per sample
+                print(f"  reference in bf16 ({'autocast' if ac else 'plain'}) call {tag}: {time.time() - t0:.0f} s", flush=True)
+            outs[tag] = (got[0], got[1], routing)
+    del model
+    gc.collect()
+    return outs
+
+
+def add_refbf16(name):
+    """`--refbf16 case`: adds refbf16_* / refbf16ac_* (+ refbf16_agree_* for MoE) to an EXISTING fixture; nothing else is recomputed."""
+    case = CASES[name]
+    cfg = case["cfg"]
+    path = os.path.join(OUT, f"{name}.npz")
+    old = dict(np.load(path, allow_pickle=False))
+    sd = synth.synth_state_dict(cfg, seed=case["seed_w"], streams=True)
+    wsum, wprobe, _ = weight_checksum(sd)
+    assert np.array_equal(wsum, old["wsum"]) and np.array_equal(wprobe, old["wprobe"]), "the draw is not the fixture's"
+
+    def make_inputs(tv):
+        if cfg.has_text:
+            ins = list(synth.synth_inputs(cfg, latent_hw=case["latent_hw"], text_len=case["text_len"], uncond_len=case["uncond_len"],
+                                          seed=case["seed_x"], t_value=tv))
+            ins[2] = ins[2].to(torch.bfloat16).float()
+        else:
+            ins = list(synth.synth_inputs(cfg, latent_hw=case["latent_hw"], seed=case["seed_x"], t_value=tv))
+        ins[0] = ins[0].to(torch.bfloat16).float()
+        return tuple(ins)
+
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    for tag, (plain, ac, routing) in reference_bf16_calls(case, sd, make_inputs).items():
+        old[f"refbf16_{tag}"], old[f"refbf16ac_{tag}"] = plain, ac
+        base = old[f"ref_{tag}"] if f"ref_{tag}" in old else old[f"oracle_{tag}"]
+        fl = old[f"floor_{tag}"]
+        print(f"[{name}] {tag}: vs {'reference' if f'ref_{tag}' in old else 'restatement'} fp32: reference-in-bf16 {rel(plain, base):.3e} "
+              f"(autocast {rel(ac, base):.3e}; ch3 {rel(plain[:, 3], base[:, 3]):.3e} / {rel(ac[:, 3], base[:, 3]):.3e}), "
+              f"floor {rel(fl, base):.3e} (ch3 {rel(fl[:, 3], base[:, 3]):.3e}); floor vs reference-in-bf16 {rel(fl, plain):.3e}", flush=True)
+        if routing is not None:
+            table = old[f"route_{tag}"].astype(np.int32)
+            ran = table >= 0
+            agree = float((((routing == table) | ~ran).all(axis=-1)).mean())
+            old[f"refbf16_agree_{tag}"] = np.float64(agree)
+            print(f"[{name}] {tag}: the reference module in bf16 selects the fp32 run's experts on {agree * 100:.2f} % of (layer, branch, "
+                  f"row) slots; the bf16 choreography: {float(old[f'floor_agree_{tag}']) * 100:.2f} %", flush=True)
+    if not case.get("reference", True):
+        old["pinned_by"] = np.array("refbf16_*: output of the UNMODIFIED reference module in bf16 (flash branch, oracle/stubs/flash_attn) at this "
+                                    "size; oracle_* / floor_*: the restatement, pinned bit for bit on the same weights at 4096 tokens by "
+                                    "full_2b_gqa_ntk (the fp32 reference cannot run this size)")
+    np.savez_compressed(path, **old)
+    print(f"[{name}] refbf16 added", flush=True)
+
+
 def run_case(name):
     case = CASES[name]
     cfg = case["cfg"]
@@ -229,8 +342,12 @@ def run_case(name):
 
 def main():
     torch.set_grad_enabled(False)
-    names = sys.argv[1:] or list(CASES)
-    for n in names:
+    args = sys.argv[1:]
+    if args and args[0] == "--refbf16":
+        for n in args[1:]:
+            add_refbf16(n)
+        return
+    for n in args or list(CASES):
         run_case(n)
 
 

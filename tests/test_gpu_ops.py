@@ -592,6 +592,47 @@ def test_gated_residual_norm_specialised_is_bit_identical(d, post_mode, next_mod
     assert torch.isfinite(outs[1][1].float()).all()
 
 
+@pytest.mark.parametrize("d,K,N", [(2304, 2304, 4096), (2304, 6144, 4096), (1536, 1536, 4160)])
+def test_proj_gated_residual_norm_ystat(d, K, N):
+    """round 6 (option grn_ystat): the O / W2 projection leaves the rows' sum-of-squares partials behind (GemmArgs::ystat) and the row kernel
+    streams on them.  Against the same two launches without it (the row kernel reduces y itself: same statements, only the fp32 summation
+    order of the statistic differs -> equal up to rare one-ulp flips) and against an fp32 restatement with the reference's rounding points
+    (model.py:597-610, components.py:40-54)."""
+    B = 2
+    M = B * N
+    g = torch.Generator().manual_seed(d + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(d, K, generator=g) * K ** -0.5)
+    x = bf(torch.randn(M, d, generator=g))
+    pw, nw = bf(1 + 0.1 * torch.randn(d, generator=g)), bf(1 + 0.1 * torch.randn(d, generator=g))
+    ld = 3 * d
+    mod = bf(torch.randn(B, ld, generator=g) * 0.3)
+    cap = 2 * ((d + 255) // 256)
+    outs = []
+    for use in (0, 1):
+        xs, hs, ys = x.clone(), torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+        ws = torch.full((M, cap), float("nan"), device="cuda", dtype=torch.float32)
+        ok(lib().lt_op_proj_gated_residual_norm(P(A), P(W), P(ys), P(ws), cap, K, P(xs), P(pw), P(mod[:, :d]), P(nw), P(mod[:, d:]), ld, P(hs),
+                                                B, N, d, 1e-5, use, stream()))
+        torch.cuda.synchronize()
+        outs.append((ys, xs, hs, ws))
+    (y0, x0, h0, _), (y1, x1, h1, ws) = outs
+    assert torch.equal(y0, y1)  # the GEMM's outputs do not change
+    yf = y1.float()
+    ns = 2 * (d // 288 if d % 288 == 0 else (d + 255) // 256)  # the launch packs its ns partials per row densely: [M][ns] inside the workspace
+    slots = ws.flatten()[: M * ns].view(M, ns)
+    assert torch.isfinite(slots).all()
+    assert rel_l2(slots.sum(-1), yf.pow(2).sum(-1)) < 1e-5  # the partials are the row's sum of squares
+    assert rel_l2(x1, x0) < 2e-4 and rel_l2(h1, h0) < 2e-4
+    assert (x1 != x0).float().mean() < 2e-3 and (h1 != h0).float().mean() < 2e-3
+    gate = mod[:, :d].float().repeat_interleave(N, dim=0)
+    scale = mod[:, d:2 * d].float().repeat_interleave(N, dim=0)
+    yn = r16(r16(yf * torch.rsqrt(yf.pow(2).mean(-1, keepdim=True) + 1e-5)) * pw.float())
+    xn = r16(x.float() + r16(gate * yn))
+    hn = r16(r16(r16(xn * torch.rsqrt(xn.pow(2).mean(-1, keepdim=True) + 1e-5)) * nw.float()) * scale)
+    assert rel_l2(x1, xn) < 2e-3 and rel_l2(h1, hn) < 3e-3, (rel_l2(x1, xn), rel_l2(h1, hn))
+
+
 @pytest.mark.parametrize("heads,hd,qk_norm", [(8, 72, True), (2, 72, True), (32, 72, False), (32, 48, True)])
 def test_qk_norm_rope(heads, hd, qk_norm):
     from oracle import nextdit_oracle as O
