@@ -48,9 +48,9 @@ WORKLOADS = {
     "cfg4": dict(ctor="NextDiT_2B_GQA_patch2", gqa=True, res=2048, scale_factor=2.0, scale_watershed=0.3,
                  desc="BASELINE configs[3]: Lumina-Next-SFT 2B (NextDiT_2B_GQA_patch2), 2048x2048 any-resolution (16384 latent tokens, "
                       "NTK-aware / time-aware RoPE scale_factor 2, watershed 0.3)",
-                 parity="tests/golden/full_2b_gqa_16k.npz is pinned by the RESTATEMENT, not by the reference: the reference module cannot run 16 384 "
-                        "tokens on the 62 GB authoring host (fp32 N x N mask = 69 GB); the restatement equals the reference bit for bit on the same "
-                        "weights at 4096 tokens (full_2b_gqa_ntk)"),
+                 parity="tests/golden/full_2b_gqa_16k.npz: refbf16_* = outputs of the UNMODIFIED reference module in bf16 at 16 384 tokens (its flash "
+                        "branch, round 6); the fp32 side is the restatement (the fp32 reference needs a 69 GB N x N mask), which equals the reference "
+                        "bit for bit on the same weights at 4096 tokens (full_2b_gqa_ntk)"),
 }
 
 
@@ -186,16 +186,37 @@ class PowerSampler:
         return out
 
 
-def pmc_traffic():
-    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes of this same command (scripts/gpu_prof.sh ->
-    profiles/rNN/pmc_gemm.json; PMC passes are separate runs by construction).  None when no summary is committed."""
+def pmc_summary(name):
+    """A committed rocprofv3 --pmc summary of this same command (scripts/gpu_prof.sh -> profiles/rNN/<name>; PMC passes are separate runs by
+    construction).  Returns (summary dict or None, provenance dict): the summary carries the sha256 of the kernel sources it was taken on
+    (scripts/summarize_pmc.py) and the commit (scripts/stamp_profile.py); it is REFUSED - traffic null, reason stated - when one of those
+    sources has changed since, so a stale counter can never sit beside a live timing."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_gemm.json")))
+    import hashlib
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", name)))
     if not files:
-        return None, None
+        return None, {"file": None, "status": "no committed summary"}
     with open(files[-1]) as f:
         d = json.load(f)
-    return float(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], REPO)
+    prov = {"file": os.path.relpath(files[-1], REPO), "git_head": d.get("git_head"), "measured_in_this_run": False,
+            "box": "builder's profiling box (a committed file), NOT this run's box"}
+    stamps = d.get("source_sha256")
+    if not stamps:
+        prov["status"] = "refused: the summary carries no source stamp (taken before round 6)"
+        return None, prov
+    changed = []
+    for fn, want in stamps.items():
+        try:
+            with open(os.path.join(REPO, "lumina-t2x_amd", "csrc", fn), "rb") as f:
+                if hashlib.sha256(f.read()).hexdigest() != want:
+                    changed.append(fn)
+        except OSError:
+            changed.append(fn)
+    if changed:
+        prov["status"] = "refused: " + ", ".join(changed) + " changed since the counters were collected"
+        return None, prov
+    prov["status"] = "sources unchanged since the counters were collected"
+    return d, prov
 
 
 def rocprof_gemm_time_per_nfe():
@@ -479,6 +500,10 @@ def main():
         model = getattr(models, wl["ctor"])(qk_norm=True, cap_feat_dim=2048).to(torch.bfloat16)
     random_init_(model, seed=0)
     model.eval()
+    # every rank has drawn its 4 GB of weights before the first collective: start-up skew between ranks (random init, first import of
+    # torch on a cold box) ends HERE, two barriers and the warm-up's weight upload away from the timed region
+    torch.cuda.synchronize()
+    parallel.barrier()
 
     # text features: rank 0 "runs the text encoder" (synthetic), one RCCL broadcast, each rank keeps its image
     n_img = world
@@ -560,7 +585,17 @@ def main():
                                   ffn=model.ffn_hidden, cap_feat_dim=model.cap_feat_dim, n_tokens=n_tokens, text_len=TEXT_LEN, batch=2)
         gemm_ms, gemm_n, gemm_fl = gemm_prof
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic()
+        pmc_g, traffic_src = pmc_summary("pmc_gemm.json")
+        traffic = None if pmc_g is None else float(pmc_g["hbm_bytes_per_launch"])
+        pmc_a, attn_src = pmc_summary("pmc_attn.json")
+        attn_tf = attn_fl_b / (attn_ms_b * 1e-3) / 1e12 if attn_ms_b > 0 else 0.0
+        attn_launches = model.n_layers * nb
+        # hd 72 on 32x32x16 MFMAs (csrc/attention_v4.hip): QK^T runs 5 k-steps = 80 of depth for 72 (the 8 pad slots carry the running max and
+        # the text mask), P V writes 96 rows of O^T for 72 + the row of ones (row sum): executed / useful = (80 + 96) / (2 x 72)
+        attn_exec = (80.0 + 96.0) / (2.0 * 72.0)
+        rows_attn, dkv_attn = 2 * n_tokens, model.n_kv_heads * hd
+        # bf16: q read + out written ([rows, d] each), k + v read ([rows, dkv] each), the text keys / values of the pair
+        attn_alg_bytes = 2.0 * (2 * rows_attn * model.dim + 2 * rows_attn * dkv_attn + 2 * 2 * TEXT_LEN * dkv_attn)
         rp_ms, rp_src = rocprof_gemm_time_per_nfe()
         gemm_fl_per_nfe = gemm_fl / args.steps
         out = {
@@ -602,8 +637,27 @@ def main():
                     "frac": gemm_fl_per_nfe / (rp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "source": rp_src,
                     "box": "builder's profiling box (a committed file), NOT this run's box"}),
             },
+            # the kernel furthest below its roof: the fused self + text attention launch, 24 per NFE
+            "roofline_attention": {
+                "bound": "mfma",
+                "kernel": "attn_fwd_kernel_v4<72>: flash_attn_varlen_func + the gated text SDPA of model.py:392-434 in one launch, q_norm + RoPE of the queries in its prologue",
+                "achieved": attn_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_tf / MFMA_BF16_PEAK_TFLOPS,
+                "achieved_is": "ALGORITHMIC flops 4 B H N (N + T) hd per launch / average launch duration from HIP events around every launch of an "
+                               f"untimed pass of {nb} NFE right after the timed region (events around every launch cost the timed region 4 %)",
+                "executed_over_algorithmic_mfma": attn_exec,
+                "executed_mfma_frac": attn_tf * attn_exec / MFMA_BF16_PEAK_TFLOPS,
+                "padding": "head_dim 72: QK^T at depth 80 (5 x 16; pad slots = running max + text mask), P V on 96 O^T rows (72 + the row of ones + zeros)",
+                "launches": attn_launches, "avg_launch_ms": attn_ms_b / max(attn_launches, 1),
+                "algorithmic_flops_per_launch": attn_fl_b / max(attn_launches, 1),
+                "algorithmic_bytes_per_launch": attn_alg_bytes,
+                "traffic": None if pmc_a is None else float(pmc_a["hbm_bytes_per_launch"]),
+                "traffic_over_algorithmic": None if pmc_a is None else float(pmc_a["hbm_bytes_per_launch"]) / attn_alg_bytes,
+                "mfma_duty_pmc": None if pmc_a is None else pmc_a.get("mfma_duty"),
+                "traffic_unit": "bytes/launch on the L2's fabric side, as in `roofline`",
+                "traffic_source": attn_src,
+            },
             "kernel_time_ms_per_step": dict(breakdown, note=f"untimed pass of {nb} NFE with events around every launch"),
-            "attention_tflops_per_s": attn_fl_b / (attn_ms_b * 1e-3) / 1e12 if attn_ms_b > 0 else 0.0,
+            "attention_tflops_per_s": attn_tf,
             "kernel_variants": {"attention": args.attn_variant or 4, "gemm": args.gemm_variant or 0},
             "hip_graph_replays": eng.graph_replays(),
             "power": power.report(dt, nfe_flops * args.steps / 1e12),

@@ -98,7 +98,8 @@ const char* lt_version(void);
  *   lt_set_option          sets the PROCESS DEFAULT of an option: what engines without an override of their own, and the lt_op_*
  *                          operator entry points, use
  *   lt_engine_set_option   overrides an option for ONE engine (every later call on that engine, from any thread; nothing else).
- *                          value LT_OPTION_INHERIT drops the override again
+ *                          value LT_OPTION_INHERIT drops the override again.  Thread-safe against calls running on the same engine: every
+ *                          engine entry point takes one snapshot of all options when it starts and finishes on that snapshot
  *   lt_engine_get_option   the value in effect for an engine (e == NULL: the process default)
  * Unknown names and out-of-range values are errors (lt_last_error names the range).  There is no other mutable state outside an
  * lt_engine. */

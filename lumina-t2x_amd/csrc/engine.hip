@@ -843,7 +843,7 @@ int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* ou
     const size_t cap_bytes = (size_t)e->cfg.max_batch * e->cfg.in_channels * e->cfg.max_tokens * e->cfg.patch_size * e->cfg.patch_size * 4;
     if (sbytes > cap_bytes) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
     // (both option generations: the process defaults' and this engine's overrides' - kernel selection is baked into a captured graph)
-    const int extra[9] = {use_cfg, e->prompt_B, e->prompt_T, e->prompt_Tpad, e->reg_Y, e->reg_h, e->reg_w, lt_opt_generation(), e->opts.gen};
+    const int extra[9] = {use_cfg, e->prompt_B, e->prompt_T, e->prompt_Tpad, e->reg_Y, e->reg_h, e->reg_w, lt_opt_generation(), lt_opt_engine_generation()};
     std::vector<char> key(sizeof(lt_step_args) + sizeof(extra));
     memcpy(key.data(), a, sizeof(lt_step_args));
     memcpy(key.data() + sizeof(lt_step_args), extra, sizeof(extra));
@@ -1561,8 +1561,8 @@ extern "C" int lt_engine_set_option(lt_engine* e, const char* name, int32_t valu
         if (id == -2) return 2;
         if (id < 0) return 0;
     }
-    e->opts.v[id] = inherit ? LT_OPT_INHERIT : v;
-    ++e->opts.gen;  // new HIP-graph keys: kernel selection is baked into a captured graph
+    e->opts.v[id].store(inherit ? LT_OPT_INHERIT : v, std::memory_order_relaxed);
+    e->opts.gen.fetch_add(1, std::memory_order_release);  // new HIP-graph keys: kernel selection is baked into a captured graph
     return 0;
 }
 

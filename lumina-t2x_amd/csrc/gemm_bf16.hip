@@ -23,6 +23,7 @@
 #include "gemm_device.h"
 #include "options.h"
 #include <mutex>
+#include <map>
 #include <set>
 #include <utility>
 
@@ -65,15 +66,18 @@ int num_cus() {
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per (device, function): a process that drives several devices must set it on each.
 // The (device, function) pair is recorded only AFTER the call succeeded (a failed first attempt used to mark the pair as done,
 // every later launch then died with too little dynamic LDS and the original error was lost), keyed by the real device id.
+// The pair remembers the LARGEST size it was raised to (attn_small_fused_kernel's LDS need grows with the token count - 55 KB at
+// 256, 110 KB at 512 tokens - and a process that ran the small shape first never raised the attribute again): a larger request re-sets it.
 int ensure_dynamic_lds(const void* fn, int bytes) {
     static std::mutex mu;
-    static std::set<std::pair<int, const void*>> done;
+    static std::map<std::pair<int, const void*>, int> done;
     int dev = 0;
     LT_CHECK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    if (done.count({dev, fn})) return 0;
+    auto it = done.find({dev, fn});
+    if (it != done.end() && it->second >= bytes) return 0;
     LT_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    done.insert({dev, fn});
+    done[{dev, fn}] = bytes;
     return 0;
 }
 
@@ -246,9 +250,32 @@ GemmKernel choose(const GemmArgs& a, int epilogue, int variant) {
     }
     return variant == 2 ? GK_TN288 : GK_TN256;
 }
+
+// The ONE place that decides what a launch runs: the kernel choose() names, then the split-K overrides (the launcher, the
+// weight-panel riders and lt_gemm_describe each modelled the split on their own, and the four-way split's kernel change was missed by two).
+struct GemmPlan { GemmKernel k; int split_k; };
+GemmPlan plan(const GemmArgs& a, int epilogue, int variant) {
+    GemmPlan p{choose(a, epilogue, variant), 0};
+    // split-K: dense plain-epilogue problems on the 64 x 128 tiles whose two halves still fit one round of the CUs, K >= 1024
+    if (p.k == GK_S64 && lt_opt(OPT_GEMM_SPLITK) && (variant == 0 || variant == 8) && a.splitk_part && a.splitk_cnt && !a.tile_expert && !a.a_row_map && a.bias_dtype < 0 &&
+        a.K >= 1024 && a.K % 512 == 0) {
+        const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
+        if ((2 * tiles <= num_cus() || lt_opt(OPT_GEMM_SPLITK) == 2) && tiles <= a.splitk_tiles) p.split_k = 2;
+    }
+    // ... and four ways on the 128 x 128 tile where K is long (round 5, option gemm_splitk4; the 512-row w2 projection of the 600M models:
+    // K = 4096): a 64 x 128 half stages (64 + 128) x 2048 x 2 = 786 KB through its CU, a quarter of a 128 x 128 tile (128 + 128) x 1024 x 2 =
+    // 524 KB - the same 192 workgroups, a third less per workgroup (NOTEBOOK.md 9.3 priced it at 4 us per layer).  The last arriver sums
+    // the four partials in K order, so the result is independent of the arrival order here too.
+    if ((p.k == GK_S64 || p.k == GK_S128) && epilogue == 0 && variant == 0 && lt_opt(OPT_GEMM_SPLITK) && lt_opt(OPT_GEMM_SPLITK4) && a.splitk_part && a.splitk_cnt &&
+        !a.tile_expert && !a.a_row_map && a.bias_dtype < 0 && !a.rowstat && a.K >= 4096 && a.K % 1024 == 0) {
+        const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+        if (4 * t128 <= num_cus() && 4 * t128 <= a.splitk_tiles) { p.k = GK_S128; p.split_k = 4; }  // (a 128 x 128 part takes two [2][64 x 128] slots, four parts per tile)
+    }
+    return p;
+}
 }  // namespace
 
-const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant) { return kGemmKernelName[choose(a, epilogue, variant)]; }
+const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant) { return kGemmKernelName[plan(a, epilogue, variant).k]; }
 
 int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     GemmArgs a = a0;
@@ -268,23 +295,9 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
     }
     LT_REQUIRE(epilogue != 1 || (a.N % 64 == 0 && a.bias_dtype < 0), "gemm: swiglu epilogue needs N %% 64 == 0, no bias");
     LT_REQUIRE(variant >= 0 && variant <= 18, "gemm: unknown variant %d", variant);
-    GemmKernel k = choose(a, epilogue, variant);
-    // split-K: dense plain-epilogue problems on the 64 x 128 tiles whose two halves still fit one round of the CUs, K >= 1024
-    a.split_k = 0;
-    if (k == GK_S64 && lt_opt(OPT_GEMM_SPLITK) && (variant == 0 || variant == 8) && a.splitk_part && a.splitk_cnt && !a.tile_expert && !a.a_row_map && a.bias_dtype < 0 &&
-        a.K >= 1024 && a.K % 512 == 0) {
-        const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
-        if ((2 * tiles <= num_cus() || lt_opt(OPT_GEMM_SPLITK) == 2) && tiles <= a.splitk_tiles) a.split_k = 2;
-    }
-    // ... and four ways on the 128 x 128 tile where K is long (round 5, option gemm_splitk4; the 512-row w2 projection of the 600M models:
-    // K = 4096): a 64 x 128 half stages (64 + 128) x 2048 x 2 = 786 KB through its CU, a quarter of a 128 x 128 tile (128 + 128) x 1024 x 2 =
-    // 524 KB - the same 192 workgroups, a third less per workgroup (NOTEBOOK.md 9.3 priced it at 4 us per layer).  The last arriver sums
-    // the four partials in K order, so the result is independent of the arrival order here too.
-    if ((k == GK_S64 || k == GK_S128) && epilogue == 0 && variant == 0 && lt_opt(OPT_GEMM_SPLITK) && lt_opt(OPT_GEMM_SPLITK4) && a.splitk_part && a.splitk_cnt &&
-        !a.tile_expert && !a.a_row_map && a.bias_dtype < 0 && !a.rowstat && a.K >= 4096 && a.K % 1024 == 0) {
-        const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-        if (4 * t128 <= num_cus() && 4 * t128 <= a.splitk_tiles) { k = GK_S128; a.split_k = 4; }  // (a 128 x 128 part takes two [2][64 x 128] slots, four parts per tile)
-    }
+    const GemmPlan pl = plan(a, epilogue, variant);
+    GemmKernel k = pl.k;
+    a.split_k = pl.split_k;
     if (a.rowstat) {
         LT_REQUIRE((k == GK_S128 || k == GK_S64) && epilogue == 0, "gemm: rowstat is written by the small-M tiles' plain epilogue only (this problem runs %s)", kGemmKernelName[k]);
         LT_REQUIRE(a.rowstat_slots >= (a.N + 127) / 128, "gemm: rowstat_slots %d < %d column tiles", a.rowstat_slots, (a.N + 127) / 128);
@@ -340,33 +353,30 @@ __global__ __launch_bounds__(256) void gemm_prefetch_w_kernel(PrefetchRider r) {
 
 int gemm_ystat_slots(const GemmArgs& a, int epilogue) {
     if (epilogue != 0) return 0;
-    const GemmKernel k = choose(a, epilogue, 0);
+    const GemmKernel k = plan(a, epilogue, 0).k;
     if (k == GK_W4Q288) return 2 * ((a.N + 287) / 288);
     if (k == GK_W4Q256) return 2 * ((a.N + 255) / 256);
     return 0;
 }
 
 bool gemm_is_small_m(const GemmArgs& a, int epilogue) {
-    const GemmKernel k = choose(a, epilogue, 0);
+    const GemmKernel k = plan(a, epilogue, 0).k;
     return k == GK_S64 || k == GK_S128;
 }
 
 bool gemm_prefetch_rider(const GemmArgs& a0, int epilogue, PrefetchRider* r) {
     GemmArgs a = a0;
-    const GemmKernel k = choose(a, epilogue, 0);
+    const GemmPlan pl = plan(a, epilogue, 0);  // the kernel AND the split the launch will really use
+    const GemmKernel k = pl.k;
     int BM = 0;
     if (k == GK_S64) BM = 64;
     else if (k == GK_S128 || k == GK_S128_SWIGLU) BM = 128;
     else return false;  // not a small-M launch: nothing to do
     if (a.tile_expert || a.a_row_map) return false;
-    int split = 0;
-    if (k == GK_S64 && lt_opt(OPT_GEMM_SPLITK) && a.splitk_part && a.bias_dtype < 0 && a.K >= 1024 && a.K % 512 == 0) {
-        const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
-        if (2 * tiles <= num_cus() && tiles <= a.splitk_tiles) split = 2;
-    }
+    const int split = pl.split_k;
     r->W = a.W; r->N = a.N; r->K = a.K; r->ldw = a.ldw; r->BN = 128;
     r->TM = (a.M + BM - 1) / BM; r->TN = (a.N + 127) / 128; r->split = split;
-    r->blocks = r->TM * r->TN * (split == 2 ? 2 : 1);
+    r->blocks = r->TM * r->TN * (split >= 2 ? split : 1);
     r->first = 0;
     return true;
 }

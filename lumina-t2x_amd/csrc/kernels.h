@@ -239,7 +239,7 @@ int launch_attention_v4_hd48(const AttnArgs& a, hipStream_t stream);  // hd 48, 
 int launch_attention_v4_hd96(const AttnArgs& a, hipStream_t stream);  // hd 96, the same structure without pad slots (attention_v4_96.hip)
 bool attention_takes_raw_q(const AttnArgs& a);  // launch_attention would run this call on attn_fwd_kernel_v4<72> (the kernel with the q_raw prologue)
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
-int ensure_dynamic_lds(const void* fn, int bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel); marks the pair only on success
+int ensure_dynamic_lds(const void* fn, int bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) per (device, kernel), raised whenever a larger size is asked for; records the pair only on success
 const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant);  // name of the kernel launch_gemm_bf16 would run
 
 // ---- mixture-of-experts routing (moe.hip; Next-DiT-MoE/models/models2.py:451-506) --------------------------------

@@ -368,6 +368,9 @@ int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
     const dim3 grid(nblk);
     if (a.moe_pos) {  // y = top-2 combine of the experts' outputs (MoE families: d = 1536 ... 4096)
         LT_REQUIRE(a.moe_ys && a.moe_wts, "gated_residual_norm: incomplete MoE combine arguments");
+        // (the MoE instantiations compile the vanilla rounding order in; with the option on, the model's first pre-norm - rmsnorm_mod -
+        //  would take the apex order and every later norm the vanilla one, silently)
+        LT_REQUIRE(!a.apex, "gated_residual_norm: option rmsnorm_apex is not implemented for the MoE families' combine-on-load row kernel");
         // the 600M MoE's combination (d = 1536, weighted post-norm, prepared gate, next pre-norm or the final LayerNorm) with its mode switches
         // fixed at compile time, like the dense instantiations below (round 5; same statements in the same order: bit-identical)
         if (lt_opt(OPT_NORM_SPECIALIZE) && !a.apex && a.gate_mode == 0 && a.post_mode == 1 && (a.next_mode == 1 || a.next_mode == 2) && ((a.d >> 3) + 63) / 64 == 3) {

@@ -7,6 +7,7 @@
 // for the duration of an entry point, so two engines with different settings can be driven from two threads ("no
 // hidden global state").
 #pragma once
+#include <atomic>
 #include <climits>
 
 enum LtOpt {
@@ -27,20 +28,28 @@ extern const LtOptDesc kLtOptDesc[LT_OPT_COUNT];
 
 int lt_opt_find(const char* name);                 // index into kLtOptDesc, -1 = unknown
 int lt_opt(int id);                                // effective value on this thread
-int lt_opt_generation();                           // bumped by every change of a process default (HIP-graph cache key, beside LtEngineOptions::gen)
+int lt_opt_generation();                           // bumped by every change of a process default (HIP-graph cache key); inside an LtOptScope: the value the scope saw at entry
+int lt_opt_engine_generation();                    // LtEngineOptions::gen as the running scope saw it at entry (0 outside a scope / without an engine)
 int lt_opt_validate(int id, int* value);           // 0 ok (booleans normalised), else lt_set_error was called
 void lt_opt_set_process(int id, int value);
 void lt_opt_reset_process();
 
-// engine-side storage: v[i] == LT_OPT_INHERIT -> the process default applies
+// engine-side storage: v[i] == LT_OPT_INHERIT -> the process default applies.  Atomics: lt_engine_set_option may run on one thread while
+// another thread is inside an entry point of the same engine - the running call keeps the snapshot it took at entry.
 struct LtEngineOptions {
-    int v[LT_OPT_COUNT];
-    int gen = 0;
-    LtEngineOptions() { for (int i = 0; i < LT_OPT_COUNT; ++i) v[i] = LT_OPT_INHERIT; }
+    std::atomic<int> v[LT_OPT_COUNT];
+    std::atomic<int> gen{0};
+    LtEngineOptions() { for (int i = 0; i < LT_OPT_COUNT; ++i) v[i].store(LT_OPT_INHERIT, std::memory_order_relaxed); }
 };
-// RAII: the calling thread's lookups see `o` until the scope ends (nests; restores the previous engine)
+// RAII: takes ONE snapshot of the effective values (engine override, else process default) at entry; the calling thread's lookups see that
+// snapshot until the scope ends, so one evaluation runs on one consistent set whatever other threads set meanwhile (nests; restores the
+// previous scope).
 struct LtOptScope {
-    const LtEngineOptions* prev;
+    int v[LT_OPT_COUNT];
+    int process_gen, engine_gen;
+    const LtOptScope* prev;
     explicit LtOptScope(const LtEngineOptions* o);
     ~LtOptScope();
+    LtOptScope(const LtOptScope&) = delete;
+    LtOptScope& operator=(const LtOptScope&) = delete;
 };

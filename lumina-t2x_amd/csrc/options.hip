@@ -41,7 +41,7 @@ ProcessOptions& process() {
     static ProcessOptions p;
     return p;
 }
-thread_local const LtEngineOptions* tl_engine = nullptr;
+thread_local const LtOptScope* tl_scope = nullptr;
 }  // namespace
 
 int lt_opt_find(const char* name) {
@@ -52,11 +52,12 @@ int lt_opt_find(const char* name) {
 }
 
 int lt_opt(int id) {
-    if (tl_engine && tl_engine->v[id] != LT_OPT_INHERIT) return tl_engine->v[id];
+    if (tl_scope) return tl_scope->v[id];
     return process().v[id].load(std::memory_order_relaxed);
 }
 
-int lt_opt_generation() { return process().gen.load(std::memory_order_relaxed); }
+int lt_opt_generation() { return tl_scope ? tl_scope->process_gen : process().gen.load(std::memory_order_relaxed); }
+int lt_opt_engine_generation() { return tl_scope ? tl_scope->engine_gen : 0; }
 
 int lt_opt_validate(int id, int* value) {
     const LtOptDesc& d = kLtOptDesc[id];
@@ -78,7 +79,7 @@ int lt_opt_validate(int id, int* value) {
 
 void lt_opt_set_process(int id, int value) {
     process().v[id].store(value, std::memory_order_relaxed);
-    process().gen.fetch_add(1, std::memory_order_relaxed);
+    process().gen.fetch_add(1, std::memory_order_release);
 }
 
 void lt_opt_reset_process() {
@@ -86,5 +87,15 @@ void lt_opt_reset_process() {
     process().gen.fetch_add(1, std::memory_order_relaxed);
 }
 
-LtOptScope::LtOptScope(const LtEngineOptions* o) : prev(tl_engine) { tl_engine = o; }
-LtOptScope::~LtOptScope() { tl_engine = prev; }
+LtOptScope::LtOptScope(const LtEngineOptions* o) : prev(tl_scope) {
+    // generations first: a setter stores the value, then bumps the generation - a snapshot can carry a newer value under an older
+    // generation (the next call then re-captures its graph), never an older value under a newer one
+    process_gen = process().gen.load(std::memory_order_acquire);
+    engine_gen = o ? o->gen.load(std::memory_order_acquire) : 0;
+    for (int i = 0; i < LT_OPT_COUNT; ++i) {
+        const int ov = o ? o->v[i].load(std::memory_order_relaxed) : LT_OPT_INHERIT;
+        v[i] = ov != LT_OPT_INHERIT ? ov : process().v[i].load(std::memory_order_relaxed);
+    }
+    tl_scope = this;
+}
+LtOptScope::~LtOptScope() { tl_scope = prev; }

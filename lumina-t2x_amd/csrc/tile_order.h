@@ -25,13 +25,14 @@ __device__ __forceinline__ void tile_coords(int bid, int nwg, int TM, int TN, in
 // workgroup will stage from.  The workgroups of a tile column inside a tile-row group share the panel's rows.  Loads only.
 __device__ __forceinline__ void prefetch_w_block(const PrefetchRider& r, int blk) {
     const int ntile = r.TM * r.TN;
-    const int ks = r.split == 2 ? blk / ntile : 0;
+    const int S = r.split >= 2 ? r.split : 1;  // K parts per tile (GemmArgs::split_k: 2 or 4); part ks of a tile is workgroup tile + ntile * ks
+    const int ks = blk / ntile;
     const int bid = blk - ks * ntile;
     int tm, tn;
     tile_coords(bid, ntile, r.TM, r.TN, tm, tn);
     const int first_m = (tm / 4) * 4, gsz = min(4, r.TM - first_m), part = tm - first_m;
     const int n0 = tn * r.BN, n1 = min(r.N, n0 + r.BN);
-    const int k0 = r.split == 2 ? ks * (r.K / 2) : 0, kw = r.split == 2 ? r.K / 2 : r.K;  // elements
+    const int k0 = ks * (r.K / S), kw = r.K / S;  // elements
     // ONE 4-byte load per 128-byte line and lane: a wave instruction touches 64 lines (8 KB of panel), so a 128 x 1536 panel is three
     // instructions for each of the 16 waves that share it, all in flight at once - one memory round trip.  (First form: a linear
     // 16-byte-chunk index per thread, one dependent load and one integer division at a time - 12.5 us for a 14-25 MB panel set, longer

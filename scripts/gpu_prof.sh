@@ -18,5 +18,5 @@ echo "pmc1 exit $?"; tail -2 $OUT/pmc1.log
 timeout 900 rocprofv3 --pmc WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_pmc2 -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc2.log 2>&1
 echo "pmc2 exit $?"; tail -2 $OUT/pmc2.log
 find /tmp/prof_pmc1 /tmp/prof_pmc2 -type f | head
-python scripts/summarize_pmc.py /tmp/prof_pmc1 /tmp/prof_pmc2 --json $OUT/pmc_gemm.json > $OUT/pmc_summary.txt 2>&1; head -40 $OUT/pmc_summary.txt | cut -c1-220
+python scripts/summarize_pmc.py /tmp/prof_pmc1 /tmp/prof_pmc2 --json $OUT/pmc_gemm.json --json-attn $OUT/pmc_attn.json > $OUT/pmc_summary.txt 2>&1; head -40 $OUT/pmc_summary.txt | cut -c1-220
 du -sh $OUT

@@ -5,16 +5,31 @@ per launch of the dominant kernel class (every gemm_bf16_* dispatch), bytes = (2
 show exactly half their bytes - MI355X_MICROARCH.md 'HBM')."""
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 from collections import defaultdict
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "lumina-t2x_amd", "csrc")
+
+
+def source_stamp(names):
+    """sha256 of the kernel sources a counter summary belongs to: bench.py refuses a committed summary whose sources have changed since
+    (VERDICT r5 item 6); `git_head` is added by scripts/stamp_profile.py when the file is copied into profiles/ (the GPU box has no .git)"""
+    return {n: hashlib.sha256(open(os.path.join(CSRC, n), "rb").read()).hexdigest() for n in names}
+
+
 args = sys.argv[1:]
-out_json = None
+out_json = out_attn = None
 if "--json" in args:
     i = args.index("--json")
     out_json = args[i + 1]
+    args = args[:i] + args[i + 2:]
+if "--json-attn" in args:
+    i = args.index("--json-attn")
+    out_attn = args[i + 1]
     args = args[:i] + args[i + 2:]
 
 tot = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -50,5 +65,27 @@ if out_json:
                    "fetch_size_kib_avg": fk, "write_size_kib_avg": wk,
                    "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
                    "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024; gfx950 FETCH_SIZE counts wide reads at half (MI355X_MICROARCH.md)",
+                   "source_sha256": source_stamp(["gemm_device.h", "gemm_bf16.hip"]),
                    "per_kernel": per_kernel}, open(out_json, "w"), indent=1)
         print("wrote", out_json)
+
+if out_attn:
+    # the hd-72 self-attention kernel of the headline step (bench.py `roofline_attention`): fabric traffic and matrix-pipe duty per launch
+    for k, cs in tot.items():
+        if "attn_fwd_kernel_v4<72>" not in k:
+            continue
+        avg = {c: a[0] / max(a[1], 1) for c, a in cs.items()}
+        if "FETCH_SIZE" not in avg or "WRITE_SIZE" not in avg:
+            continue
+        d = {"kernel": k[:80], "launches": max(a[1] for a in cs.values()),
+             "fetch_size_kib_avg": avg["FETCH_SIZE"], "write_size_kib_avg": avg["WRITE_SIZE"],
+             "hbm_bytes_per_launch": (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0,
+             "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024; gfx950 FETCH_SIZE counts wide reads at half (MI355X_MICROARCH.md)",
+             "source_sha256": source_stamp(["attention_v4.hip", "attention_v4_asm.inc"])}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
+            # MFMA-busy cycles are summed over the chip's 1024 SIMDs, GRBM_GUI_ACTIVE over its 8 XCDs (PMC passes serialise the kernels)
+            d["mfma_busy_cycles_avg"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"]
+            d["grbm_gui_active_avg"] = avg["GRBM_GUI_ACTIVE"]
+            d["mfma_duty"] = (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (avg["GRBM_GUI_ACTIVE"] / 8.0)
+        json.dump(d, open(out_attn, "w"), indent=1)
+        print("wrote", out_attn)

@@ -73,6 +73,13 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
+    # pre-flight of the driver's scaling run: WITHOUT --share-device the collectives are RCCL's, every rank took part in
+    # one, and the two ranks sit on two different devices
+    comm = rec["comm"]
+    assert comm["backend"] == "nccl" and comm["rccl_version"], comm
+    assert comm["world"] == 2 and comm["ranks_seen"] == 2 and len(comm["ms_per_step_per_rank"]) == 2, comm
+    assert len(set(comm["devices"])) == 2 and all("cuda:" in d for d in comm["devices"]), comm["devices"]
+    assert comm["collective_in_timed_region"] is False and "shared_device" not in rec
 
 
 # ---- the same N > 1 code on ONE GPU: both ranks drive device 0, collectives over gloo with a host hop (parallel.init_distributed

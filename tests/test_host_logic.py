@@ -649,3 +649,33 @@ def test_weight_watch_sees_every_kind_of_weight_change():
     n0 = len(list(m.layers[0].parameters()))
     m.layers._modules.pop("0")                   # a direct edit of the dict
     assert len(m._signature()) == len(s10) - n0
+
+
+def test_bench_refuses_counter_summaries_whose_kernel_sources_changed(tmp_path, monkeypatch):
+    """roofline.traffic comes from a COMMITTED rocprofv3 --pmc summary (PMC passes are separate runs); the summary carries the
+    sha256 of the kernel sources it was collected on and bench.py hands out its numbers only while those files are unchanged."""
+    import hashlib
+    import importlib.util
+    import json as _json
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    csrc = os.path.join(REPO, "lumina-t2x_amd", "csrc")
+    good = {n: hashlib.sha256(open(os.path.join(csrc, n), "rb").read()).hexdigest() for n in ("gemm_device.h", "gemm_bf16.hip")}
+    root = tmp_path / "repo"
+    (root / "profiles" / "r99").mkdir(parents=True)
+    (root / "lumina-t2x_amd").mkdir()
+    os.symlink(csrc, root / "lumina-t2x_amd" / "csrc")
+    monkeypatch.setattr(bench, "REPO", str(root))
+    f = root / "profiles" / "r99" / "pmc_gemm.json"
+    f.write_text(_json.dumps({"hbm_bytes_per_launch": 1.0e8, "source_sha256": good, "git_head": "abc"}))
+    d, prov = bench.pmc_summary("pmc_gemm.json")
+    assert d is not None and prov["status"].startswith("sources unchanged") and prov["git_head"] == "abc" and prov["measured_in_this_run"] is False
+    f.write_text(_json.dumps({"hbm_bytes_per_launch": 1.0e8, "source_sha256": dict(good, **{"gemm_device.h": "0" * 64})}))
+    d, prov = bench.pmc_summary("pmc_gemm.json")
+    assert d is None and "gemm_device.h" in prov["status"] and prov["status"].startswith("refused")
+    f.write_text(_json.dumps({"hbm_bytes_per_launch": 1.0e8}))  # a summary from before the stamps existed
+    d, prov = bench.pmc_summary("pmc_gemm.json")
+    assert d is None and "no source stamp" in prov["status"]
+    assert bench.pmc_summary("pmc_attn.json")[0] is None

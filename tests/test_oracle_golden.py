@@ -261,6 +261,32 @@ def test_fulldepth_oracle_is_pinned_to_the_reference(golden_dir, name):
             assert (route[..., 0] < route[..., 1]).all() and 0.5 < float(g[f"floor_agree_{tag}"]) < 1.0
 
 
+@pytest.mark.parametrize("name", FULL + ["full_2b_gqa_16k"])
+def test_bf16_yardstick_is_pinned_to_the_reference_module_in_bf16(golden_dir, name):
+    """VERDICT r5 item 2 / "what's weak" 1: every full-depth GPU gate is "engine <= 1.5 x floor", and `floor_*` is the builder's own bf16
+    emulation (oracle/*.py with bf16=True).  `refbf16_*` / `refbf16ac_*` are the UNMODIFIED reference module moved to bfloat16
+    (`model.to(bfloat16)`, lumina_next_t2i/sample.py:129; flash_attn = oracle/stubs/flash_attn: fp32-accumulate SDPA, one cast back), run
+    plain and under torch.autocast (sample.py:173), stored by `oracle/make_fulldepth_golden.py --refbf16`.  The yardstick must sit where the
+    reference's own bf16 run sits: within 10 % of the autocast run (the choreography the floor emulates and the sampler uses) on all
+    channels and on the unguided channel 3, and within 15 % of the plain-bf16 run (MoE at 256 tokens: two realisations of a discretely routed
+    model, 2.04e-1 / 1.80e-1 / 1.81e-1).  MoE: the reference-in-bf16's expert selections agree with the fp32 run's as often as the emulation's."""
+    g = _load(golden_dir, name)
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    for tag, _, _ in json.loads(str(g["calls"])):
+        base = g[f"ref_{tag}"] if f"ref_{tag}" in g.files else g[f"oracle_{tag}"]
+        fl, plain, ac = g[f"floor_{tag}"], g[f"refbf16_{tag}"], g[f"refbf16ac_{tag}"]
+        assert plain.shape == ac.shape == base.shape and np.isfinite(plain).all() and np.isfinite(ac).all()
+        assert np.array_equal(plain[0, :3], plain[1, :3])  # CFG rows of the reference's own bf16 output
+        for sl in (np.s_[:], np.s_[:, 3]):
+            f, p, a = rel(fl[sl], base[sl]), rel(plain[sl], base[sl]), rel(ac[sl], base[sl])
+            assert abs(f - a) / a <= 0.10, (name, tag, f, a)
+            assert abs(f - p) / p <= 0.15, (name, tag, f, p)
+        if "moe" in name:
+            assert abs(float(g[f"refbf16_agree_{tag}"]) - float(g[f"floor_agree_{tag}"])) < 0.01
+    if name == "full_2b_gqa_16k":
+        assert "refbf16_*: output of the UNMODIFIED reference module" in str(g["pinned_by"])
+
+
 def test_fulldepth_16k_fixture_is_the_pinned_restatement(golden_dir):
     """full_2b_gqa_16k (BASELINE configs[3] at its own 16 384 tokens, round 4): the unmodified reference cannot run this size on the
     authoring host (its SDPA fallback wants an fp32 [B, H, N, N] mask = 69 GB), so the fixture holds the RESTATEMENT's output - and
@@ -268,7 +294,7 @@ def test_fulldepth_16k_fixture_is_the_pinned_restatement(golden_dir):
     4096 tokens on both RoPE branches (full_2b_gqa_ntk, test above)."""
     g = _load(golden_dir, "full_2b_gqa_16k")
     pinned = _load(golden_dir, "full_2b_gqa_ntk")
-    assert "restatement only" in str(g["pinned_by"]) and not any(k.startswith("ref_") for k in g.files)
+    assert "restatement" in str(g["pinned_by"]) and not any(k.startswith("ref_") for k in g.files)  # (round 6: + refbf16_*, the reference module's own bf16 output at this size)
     assert int(g["seed_w"]) == int(pinned["seed_w"]) and np.array_equal(g["wsum"], pinned["wsum"]) and str(g["config"]) == str(pinned["config"])
     assert tuple(g["latent_hw"]) == (256, 256)  # 128 x 128 patches = 16 384 tokens
     for tag, _, kw in json.loads(str(g["calls"])):
