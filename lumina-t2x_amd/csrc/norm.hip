@@ -304,7 +304,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int i = 0; i < NH; ++i)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const bf16x2_t v = __builtin_bit_cast(bf16x2_t, xv[i][k]);
+            // (through a scalar: __builtin_bit_cast applied to an ext-vector ELEMENT drops the element index with hipcc 7.2 - every k read
+            //  element 0, caught by tests/test_gpu_ops.py::test_proj_gated_residual_norm_ystat)
+            const unsigned u = xv[i][k];
+            const bf16x2_t v = __builtin_bit_cast(bf16x2_t, u);
             s4[(2 * i + k) & 3] = __builtin_amdgcn_fdot2_f32_bf16(v, v, s4[(2 * i + k) & 3], false);
         }
     const float r2 = rsqrtf(wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) / (float)p.d + p.eps);
