@@ -68,9 +68,10 @@ extern "C" {
  *                       are written by one launch at the top of the evaluation - the time router's logits depend on the timestep embedding
  *                       only and are already computed there for every layer (round 5: one launch less per layer); not used while routing is
  *                       forced by the parity hook or with more than 64 samples | 0: one plan launch per layer
- *   "grn_ystat"         (0..1, 1): the O and W2 projections (persistent kernel, plain dense tiles) leave the per-row sum of squares of their
+ *   "grn_ystat"         (0..2, 1): the O and W2 projections (persistent kernel, plain dense tiles) leave the per-row sum of squares of their
  *                       outputs behind, in partial sums per column tile and wave half, and the sandwich-norm row kernel that follows runs
- *                       its streaming form on it (64 registers, all rows resident; round 6) | 0: the row kernel loads the row, reduces, applies
+ *                       its streaming form on it (64 registers, all rows resident; round 6) | 2: the same with two rows per wave (the second row's loads
+ *                       in flight under the first row's arithmetic and stores) | 0: the row kernel loads the row, reduces, applies
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

@@ -254,7 +254,7 @@ int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int
     if (ystat_slots) {
         *ystat_slots = 0;
         const int ys = lt_opt(OPT_GRN_YSTAT) && !bias ? gemm_ystat_slots(g, epi) : 0;
-        if (ys > 0 && ys <= e->ystat_cap && ys % 4 == 0) { g.ystat = e->ystat; g.ystat_slots = ys; *ystat_slots = ys; }
+        if (ys > 0 && ys <= e->ystat_cap) { g.ystat = e->ystat; g.ystat_slots = ys; *ystat_slots = ys; }
     }
     if (lt_opt(OPT_GEMM_PREFETCH) == 1 && M <= 1024 && launch_gemm_prefetch_w(g, epi, s)) return 1;
     ProfScope ps(e, 0, 2.0 * M * (double)N * K, s, true);
@@ -1739,7 +1739,7 @@ extern "C" int lt_op_proj_gated_residual_norm(const void* A, const void* W, void
     GatedResArgs r;
     if (use_ystat) {
         const int ys = gemm_ystat_slots(g, 0);
-        LT_REQUIRE(ys > 0 && ys % 4 == 0, "lt_op_proj_gated_residual_norm: this problem does not run on the persistent kernel's plain dense tiles (no ystat)");
+        LT_REQUIRE(ys > 0, "lt_op_proj_gated_residual_norm: this problem does not run on the persistent kernel's plain dense tiles (no ystat)");
         LT_REQUIRE(ystat_ws && ystat_cap >= ys, "lt_op_proj_gated_residual_norm: ystat workspace of %d floats per row, the launch fills %d", ystat_cap, ys);
         g.ystat = (float*)ystat_ws; g.ystat_slots = ys;
         r.ystat = (const float*)ystat_ws; r.ystat_slots = ys;

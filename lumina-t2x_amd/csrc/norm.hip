@@ -255,73 +255,84 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
 // summation order of sum(y^2) (per GEMM tile and wave half, then over the slots).
 typedef __attribute__((ext_vector_type(2))) unsigned nt_u32x2;
 // (launcher: next_w and next_scale present, scale_pre 1, no next_shift - Next-DiT's block; everything else takes the kernel above)
-template <int NH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void gated_residual_norm_ys_kernel(GatedResArgs p) {
+// RPW rows per wave (1 or 2).  With one row per wave and eight waves per SIMD the whole 8192-row launch is resident at once and runs in
+// lock step - every wave loads, then every wave computes, then every wave stores - so reads and writes never overlap (32.6 us = 4.6 TB/s,
+// profiles/r06).  RPW 2: half as many waves, each with its SECOND row's loads in flight while it computes and stores the first.
+template <int NH, int RPW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RPW == 1 ? 8 : 4, RPW == 1 ? 8 : 5))) void gated_residual_norm_ys_kernel(GatedResArgs p) {
     const int lane = threadIdx.x & 63;
-    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (row >= p.rows) return;
-    const int b = row / p.rows_per_batch;
-    u16* xrow = p.x + (size_t)row * p.d + lane * 4;
-    const u16* yrow = p.y + (size_t)row * p.d + lane * 4;
-    const u16* gate = p.gate + (size_t)b * p.ld_mod + lane * 4;
+    const int row0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW);
+    if (row0 >= p.rows) return;
     const u16* postw = p.post_w + lane * 4;
+    const u16* nw = p.next_w + lane * 4;
     // the whole row of y and x in flight at once (2 NH eight-byte loads per lane; x' overwrites x's registers), the per-sample vectors
     // one step ahead of their use (they come from the L1 / L2)
-    nt_u32x2 yv[NH], xv[NH];
+    nt_u32x2 yv[RPW][NH], xv[RPW][NH];
 #pragma unroll
-    for (int i = 0; i < NH; ++i) {
-        yv[i] = *(const nt_u32x2*)(yrow + 256 * i);
-        xv[i] = *(const nt_u32x2*)(xrow + 256 * i);
-    }
-    nt_u32x2 wv = *(const nt_u32x2*)postw, gv = *(const nt_u32x2*)gate;
-    const float* ys = p.ystat + (size_t)row * p.ystat_slots;
-    float ss = 0.f;
-    for (int s = 0; s < p.ystat_slots; s += 4) {  // wave-uniform address: scalar loads
-        const f32x4 v = *(const f32x4*)(ys + s);
-        ss += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    const float rinv = rsqrtf(ss / (float)p.d + p.eps);
-    const f32x2 rv = {rinv, rinv};
-    // x' = bfr(x + bfr(g * bfr(bfr(y * rinv) * w)))
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r < p.rows ? row0 + r : p.rows - 1;
 #pragma unroll
-    for (int i = 0; i < NH; ++i) {
-        nt_u32x2 wn = wv, gn = gv;
-        if (i + 1 < NH) { wn = *(const nt_u32x2*)(postw + 256 * (i + 1)); gn = *(const nt_u32x2*)(gate + 256 * (i + 1)); }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            f32x2 yn = bfr2(bfr2(unpk_bf(yv[i][k]) * rv) * unpk_bf(wv[k]));
-            yn = bfr2(unpk_bf(gv[k]) * yn);
-            xv[i][k] = pk_bf(unpk_bf(xv[i][k]) + yn);
+        for (int i = 0; i < NH; ++i) {
+            yv[r][i] = *(const nt_u32x2*)(p.y + (size_t)row * p.d + lane * 4 + 256 * i);
+            xv[r][i] = *(const nt_u32x2*)(p.x + (size_t)row * p.d + lane * 4 + 256 * i);
         }
-        __builtin_nontemporal_store(xv[i], (nt_u32x2*)(xrow + 256 * i));  // (see the kernel above: the residual stream is not read again soon)
-        wv = wn; gv = gn;
     }
-    const u16* nw = p.next_w + lane * 4;
-    const u16* nscale = p.next_scale + (size_t)b * p.ld_mod + lane * 4;
-    nt_u32x2 w2 = *(const nt_u32x2*)nw, s2 = *(const nt_u32x2*)nscale;
-    float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NH; ++i)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            // (through a scalar: __builtin_bit_cast applied to an ext-vector ELEMENT drops the element index with hipcc 7.2 - every k read
-            //  element 0, caught by tests/test_gpu_ops.py::test_proj_gated_residual_norm_ystat)
-            const unsigned u = xv[i][k];
-            const bf16x2_t v = __builtin_bit_cast(bf16x2_t, u);
-            s4[(2 * i + k) & 3] = __builtin_amdgcn_fdot2_f32_bf16(v, v, s4[(2 * i + k) & 3], false);
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        if (row >= p.rows) break;  // wave-uniform
+        const int b = row / p.rows_per_batch;
+        u16* xrow = p.x + (size_t)row * p.d + lane * 4;
+        const u16* gate = p.gate + (size_t)b * p.ld_mod + lane * 4;
+        nt_u32x2 wv = *(const nt_u32x2*)postw, gv = *(const nt_u32x2*)gate;
+        const float* ys = p.ystat + (size_t)row * p.ystat_slots;
+        float ss = 0.f;
+        for (int s = 0; s < p.ystat_slots; s += 2) {  // wave-uniform address: scalar loads (two wave halves per column tile: an even count)
+            const f32x2 v = *(const f32x2*)(ys + s);
+            ss += v[0] + v[1];
         }
-    const float r2 = rsqrtf(wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) / (float)p.d + p.eps);
-    const f32x2 r2v = {r2, r2};
-    u16* hrow = p.h + (size_t)row * p.d + lane * 4;
-    // h = bfr(bfr(bfr(x' * r2) * w) * (1 + scale)) with (1 + scale) prepared in bf16: apply_rms_mod_store, 8 bytes at a time
+        const float rinv = rsqrtf(ss / (float)p.d + p.eps);
+        const f32x2 rv = {rinv, rinv};
+        // x' = bfr(x + bfr(g * bfr(bfr(y * rinv) * w)))
 #pragma unroll
-    for (int i = 0; i < NH; ++i) {
-        nt_u32x2 wn = w2, sn = s2, o;
-        if (i + 1 < NH) { wn = *(const nt_u32x2*)(nw + 256 * (i + 1)); sn = *(const nt_u32x2*)(nscale + 256 * (i + 1)); }
+        for (int i = 0; i < NH; ++i) {
+            nt_u32x2 wn = wv, gn = gv;
+            if (i + 1 < NH) { wn = *(const nt_u32x2*)(postw + 256 * (i + 1)); gn = *(const nt_u32x2*)(gate + 256 * (i + 1)); }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) o[k] = pk_bf(bfr2(bfr2(unpk_bf(xv[i][k]) * r2v) * unpk_bf(w2[k])) * unpk_bf(s2[k]));
-        *(nt_u32x2*)(hrow + 256 * i) = o;
-        w2 = wn; s2 = sn;
+            for (int k = 0; k < 2; ++k) {
+                f32x2 yn = bfr2(bfr2(unpk_bf(yv[r][i][k]) * rv) * unpk_bf(wv[k]));
+                yn = bfr2(unpk_bf(gv[k]) * yn);
+                xv[r][i][k] = pk_bf(unpk_bf(xv[r][i][k]) + yn);
+            }
+            __builtin_nontemporal_store(xv[r][i], (nt_u32x2*)(xrow + 256 * i));  // (see the kernel above: the residual stream is not read again soon)
+            wv = wn; gv = gn;
+        }
+        const u16* nscale = p.next_scale + (size_t)b * p.ld_mod + lane * 4;
+        nt_u32x2 w2 = *(const nt_u32x2*)nw, s2 = *(const nt_u32x2*)nscale;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                // (through a scalar: __builtin_bit_cast applied to an ext-vector ELEMENT drops the element index with hipcc 7.2 - every k read
+                //  element 0, caught by tests/test_gpu_ops.py::test_proj_gated_residual_norm_ystat)
+                const unsigned u = xv[r][i][k];
+                const bf16x2_t v = __builtin_bit_cast(bf16x2_t, u);
+                s4[(2 * i + k) & 3] = __builtin_amdgcn_fdot2_f32_bf16(v, v, s4[(2 * i + k) & 3], false);
+            }
+        const float r2 = rsqrtf(wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) / (float)p.d + p.eps);
+        const f32x2 r2v = {r2, r2};
+        u16* hrow = p.h + (size_t)row * p.d + lane * 4;
+        // h = bfr(bfr(bfr(x' * r2) * w) * (1 + scale)) with (1 + scale) prepared in bf16: apply_rms_mod_store, 8 bytes at a time
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            nt_u32x2 wn = w2, sn = s2, o;
+            if (i + 1 < NH) { wn = *(const nt_u32x2*)(nw + 256 * (i + 1)); sn = *(const nt_u32x2*)(nscale + 256 * (i + 1)); }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) o[k] = pk_bf(bfr2(bfr2(unpk_bf(xv[r][i][k]) * r2v) * unpk_bf(w2[k])) * unpk_bf(s2[k]));
+            *(nt_u32x2*)(hrow + 256 * i) = o;
+            w2 = wn; s2 = sn;
+        }
     }
 }
 
@@ -396,11 +407,15 @@ int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
     }
     // the streaming kernel (GatedResArgs::ystat): dense, weighted post-norm, prepared gate, next pre-norm; d = 256 NH; no riders (large-M launches)
     if (a.ystat && lt_opt(OPT_NORM_SPECIALIZE) && !a.apex && a.gate_mode == 0 && a.post_mode == 1 && a.next_mode == 1 && a.pf.blocks == 0 &&
-        a.next_w && a.next_scale && a.scale_pre && !a.next_shift && a.y && a.d % 256 == 0 && a.ystat_slots > 0 && a.ystat_slots % 4 == 0) {
+        a.next_w && a.next_scale && a.scale_pre && !a.next_shift && a.y && a.d % 256 == 0 && a.ystat_slots > 0 && a.ystat_slots % 2 == 0) {
         const int nh = a.d / 256;
         if (nh == 6 || nh == 9) {  // (d = 3072 / 4096 do not fit the 64 registers of eight waves per SIMD: the kernel above)
-            if (nh == 6) hipLaunchKernelGGL(gated_residual_norm_ys_kernel<6>, grid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL(gated_residual_norm_ys_kernel<9>, grid, dim3(256), 0, stream, a);
+            if (lt_opt(OPT_GRN_YSTAT) == 2) {  // two rows per wave: the second row's loads fly under the first row's arithmetic and stores
+                const dim3 grid2((a.rows + 7) / 8);
+                if (nh == 6) hipLaunchKernelGGL((gated_residual_norm_ys_kernel<6, 2>), grid2, dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((gated_residual_norm_ys_kernel<9, 2>), grid2, dim3(256), 0, stream, a);
+            } else if (nh == 6) hipLaunchKernelGGL((gated_residual_norm_ys_kernel<6, 1>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((gated_residual_norm_ys_kernel<9, 1>), grid, dim3(256), 0, stream, a);
             LT_CHECK_HIP(hipGetLastError());
             return 0;
         }

@@ -28,7 +28,7 @@ const LtOptDesc kLtOptDesc[LT_OPT_COUNT] = {
     {"moe_route_fused", 0, 1, 1, true},
     {"gemm_splitk4", 0, 1, 1, true},
     {"moe_time_plan_hoist", 0, 1, 1, true},
-    {"grn_ystat", 0, 1, 1, true},
+    {"grn_ystat", 0, 2, 1, false},
 };
 
 namespace {

@@ -592,13 +592,14 @@ def test_gated_residual_norm_specialised_is_bit_identical(d, post_mode, next_mod
     assert torch.isfinite(outs[1][1].float()).all()
 
 
-@pytest.mark.parametrize("d,K,N", [(2304, 2304, 4096), (2304, 6144, 4096), (1536, 1536, 8192)])
-def test_proj_gated_residual_norm_ystat(d, K, N):
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("d,K,N", [(2304, 2304, 4096), (2304, 6144, 4096), (1536, 1536, 8192), (2304, 2304, 4099)])
+def test_proj_gated_residual_norm_ystat(d, K, N, form):
     """round 6 (option grn_ystat): the O / W2 projection leaves the rows' sum-of-squares partials behind (GemmArgs::ystat) and the row kernel
     streams on them.  Against the same two launches without it (the row kernel reduces y itself: same statements, only the fp32 summation
     order of the statistic differs -> equal up to rare one-ulp flips) and against an fp32 restatement with the reference's rounding points
     (model.py:597-610, components.py:40-54)."""
-    B = 2
+    B = 3 if N % 2 else 2  # (an odd row count: the last wave of the two-rows-per-wave form holds one row)
     M = B * N
     g = torch.Generator().manual_seed(d + K)
     A = bf(torch.randn(M, K, generator=g))
@@ -612,14 +613,22 @@ def test_proj_gated_residual_norm_ystat(d, K, N):
     for use in (0, 1):
         xs, hs, ys = x.clone(), torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
         ws = torch.full((M, cap), float("nan"), device="cuda", dtype=torch.float32)
-        ok(lib().lt_op_proj_gated_residual_norm(P(A), P(W), P(ys), P(ws), cap, K, P(xs), P(pw), P(mod[:, :d]), P(nw), P(mod[:, d:]), ld, P(hs),
-                                                B, N, d, 1e-5, use, stream()))
+        set_option("grn_ystat", form)  # 1: one row per wave; 2: two rows per wave (odd row counts end on a half-filled wave)
+        try:
+            ok(lib().lt_op_proj_gated_residual_norm(P(A), P(W), P(ys), P(ws), cap, K, P(xs), P(pw), P(mod[:, :d]), P(nw), P(mod[:, d:]), ld, P(hs),
+                                                    B, N, d, 1e-5, use, stream()))
+        finally:
+            set_option("grn_ystat", 1)
         torch.cuda.synchronize()
         outs.append((ys, xs, hs, ws))
     (y0, x0, h0, _), (y1, x1, h1, ws) = outs
     assert torch.equal(y0, y1)  # the GEMM's outputs do not change
     yf = y1.float()
-    ns = 2 * (d // 288 if d % 288 == 0 else (d + 255) // 256)  # the launch packs its ns partials per row densely: [M][ns] inside the workspace
+    # the launch packs its ns partials per row densely, [M][ns] at the front of the workspace; ns = 2 x column tiles of the tile width the
+    # dispatcher picked for this shape (288 or 256): the NaN fill says how many were written
+    nfin = int(torch.isfinite(ws).sum())
+    ns = nfin // M
+    assert nfin == M * ns and ns in (2 * ((d + 287) // 288), 2 * ((d + 255) // 256)), (nfin, M, ns)
     slots = ws.flatten()[: M * ns].view(M, ns)
     assert torch.isfinite(slots).all()
     assert rel_l2(slots.sum(-1), yf.pow(2).sum(-1)) < 1e-5  # the partials are the row's sum of squares
