@@ -46,8 +46,17 @@ def load_checkpoint(ckpt_dir: str, ema: bool) -> dict:
         return load_file(stem + ".safetensors", device="cpu")
     if os.path.exists(stem + ".pth"):
         return torch.load(stem + ".pth", map_location="cpu", weights_only=True)
-    raise FileNotFoundError(f"{stem}.safetensors / .pth not found (model-parallel shards > 1 are not supported: the MI355X "
-                            "engine keeps the whole 2B model on one GPU)")
+    import glob
+    shards = sorted(glob.glob(os.path.join(ckpt_dir, f"consolidated{'_ema' if ema else ''}.*-of-*.*")))
+    if shards:
+        # train.py:625-634 writes one file per model-parallel rank.  They are not a split of ONE model: with qk_norm the reference builds
+        # q_norm / k_norm as nn.LayerNorm(n_LOCAL_heads * head_dim) (models/model.py:211-215) - each rank normalises over ITS heads only, so an
+        # MP = k checkpoint computes k grouped LayerNorms where the MP = 1 model (every released checkpoint) computes one over the full width.
+        # Concatenating the Column / RowParallelLinear shards would load, and sample something else.
+        raise FileNotFoundError(f"{ckpt_dir} holds model-parallel shards ({', '.join(os.path.basename(f) for f in shards)}); this engine loads "
+                                "model-parallel size 1 only: with qk_norm the reference's q / k LayerNorms span the LOCAL heads of each rank "
+                                "(models/model.py:211-215), so an MP > 1 checkpoint is a different function from the concatenation of its shards")
+    raise FileNotFoundError(f"{stem}.safetensors / .pth not found")
 
 
 def make_text_encoder(path: str, dtype, device, add_eos: bool = True) -> Tuple[Callable[[List[str]], Tuple[torch.Tensor, torch.Tensor]], int]:

@@ -269,6 +269,13 @@ def test_sample_driver_cli_and_io(tmp_path):
     assert S.load_train_args(str(tmp_path)).model == "NextDiT_2B_patch2"
     with pytest.raises(FileNotFoundError):
         S.load_checkpoint(str(tmp_path / "nope"), True)
+    # model-parallel shards (train.py:625-634) are refused BY NAME with the reason: the q / k LayerNorms of an MP > 1 run span local heads
+    mp = tmp_path / "mp2"
+    mp.mkdir()
+    for r in range(2):
+        torch.save(sd, str(mp / f"consolidated_ema.{r:02d}-of-02.pth"))
+    with pytest.raises(FileNotFoundError, match="model-parallel shards .*00-of-02.*LOCAL heads"):
+        S.load_checkpoint(str(mp), True)
     img = torch.rand(3, 5, 7)
     S.save_png(img, str(tmp_path / "a.png"))
     raw = (tmp_path / "a.png").read_bytes()
