@@ -72,6 +72,12 @@ extern "C" {
  *                       outputs behind, in partial sums per column tile and wave half, and the sandwich-norm row kernel that follows runs
  *                       its streaming form on it (64 registers, all rows resident; round 6) | 2: the same with two rows per wave (the second row's loads
  *                       in flight under the first row's arithmetic and stores) | 0: the row kernel loads the row, reduces, applies
+ *   "qk_wg_per_cu"      (1..8, 3): persistent 4-wave workgroups per CU of the stand-alone q / k post-processing launch (LayerNorm + RoPE + head-major
+ *                       view; at cfg 2 the K rows of a layer: 8192 rows over 3 x 256 x 4 waves = 2.67 rows per wave)
+ *   "prologue_fused"    (0..7, 0): bit mask - 1: the timestep features are formed inside the first t_embedder GEMV, 2: temb + caption / label
+ *                       embedding inside the adaLN GEMV, 4: the per-NFE gate / scale preparation as that GEMV's epilogue; each removes one launch
+ *                       and is bit-identical to the separate kernel, and each measured SLOWER than the launch it removes (round 6,
+ *                       profiles/r06/bench_ab_prologue_merges_cfg1_cfg5_all_lose.log) | 0 (default): the separate kernels
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

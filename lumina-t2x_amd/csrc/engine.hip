@@ -572,8 +572,15 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
     // conditioning: t_embedder (model.py:84-87) + caption / label embedding (hoisted) -> adaLN vectors of every layer + final
     {
         ProfScope ps(e, 2, 0, s);
-        if (launch_timestep_features(t_dev, 0, e->tfeat, B, 256, s)) return 1;
-        if (launch_linear_small_m(e->tfeat, e->t0_w, e->t0_b, e->t1, B, A, 256, 0, s)) return 1;
+        const int fused_pro = lt_opt(OPT_PROLOGUE_FUSED);  // round 6, bit mask: 1 timestep features, 2 temb + embedding, 4 prep_mod - each one launch less, bit-identical (LinearSmallMExtra)
+        if (fused_pro & 1) {
+            LinearSmallMExtra x;
+            x.t = t_dev;
+            if (launch_linear_small_m_ext(nullptr, e->t0_w, e->t0_b, e->t1, B, A, 256, 0, x, s)) return 1;
+        } else {
+            if (launch_timestep_features(t_dev, 0, e->tfeat, B, 256, s)) return 1;
+            if (launch_linear_small_m(e->tfeat, e->t0_w, e->t0_b, e->t1, B, A, 256, 0, s)) return 1;
+        }
         if (launch_linear_small_m(e->t1, e->t2_w, e->t2_b, e->temb, B, A, A, 1, s)) return 1;
         if (e->gate_t_all && launch_linear_small_m(e->temb, e->gate_t_all, nullptr, e->moe_logits, B, L * e->E, A, 0, s)) return 1;  // every layer's time-router logits
         e->moe_tp_live = e->gate_t_all && e->moe_tp_sel && lt_opt(OPT_MOE_TIME_PLAN_HOIST) && !e->moe_force_rows && B <= LT_MOE_PLAN_TIME_MAX_SAMPLES;
@@ -587,8 +594,6 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             m.layer_stride_tiles = e->moe_tiles;
             if (launch_moe_plan(m, s)) return 1;
         }
-        if (launch_add_bf16(e->temb, e->cap_emb, e->adaln_in, (long long)B * A, s)) return 1;
-        if (launch_linear_small_m(e->adaln_in, e->adaln_w, e->adaln_b, e->mod, B, e->ld_mod, A, 1, s)) return 1;
         // once per (sample, channel) instead of once per token inside the row kernels: tanh of the gate chunks (where the
         // family has it) and bf16(1 + scale) of every scale chunk
         unsigned tanh_mask = 0, scale_mask = 0;
@@ -597,7 +602,19 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             if (v.i_scale[i] >= 0) scale_mask |= 1u << v.i_scale[i];
         }
         if (c.variant == LT_VARIANT_NEXT_MOE) { tanh_mask |= 1u << 5; scale_mask |= 1u << 4; }  // the space branch's chunks
-        if (launch_prep_mod(e->mod, B, e->ld_mod, L, e->chunks, e->d, tanh_mask, scale_mask, v.final_chunks == 2 ? 1 : 0, s)) return 1;
+        if (fused_pro & 6) {
+            LinearSmallMExtra x;
+            const u16* in = e->temb;
+            if (fused_pro & 2) x.a2 = e->cap_emb;
+            else { if (launch_add_bf16(e->temb, e->cap_emb, e->adaln_in, (long long)B * A, s)) return 1; in = e->adaln_in; }
+            if (fused_pro & 4) { x.pm_L = L; x.pm_chunks = e->chunks; x.pm_d = e->d; x.pm_final = v.final_chunks == 2 ? 1 : 0; x.pm_tanh = tanh_mask; x.pm_scale = scale_mask; }
+            if (launch_linear_small_m_ext(in, e->adaln_w, e->adaln_b, e->mod, B, e->ld_mod, A, 1, x, s)) return 1;
+            if (!(fused_pro & 4) && launch_prep_mod(e->mod, B, e->ld_mod, L, e->chunks, e->d, tanh_mask, scale_mask, v.final_chunks == 2 ? 1 : 0, s)) return 1;
+        } else {
+            if (launch_add_bf16(e->temb, e->cap_emb, e->adaln_in, (long long)B * A, s)) return 1;
+            if (launch_linear_small_m(e->adaln_in, e->adaln_w, e->adaln_b, e->mod, B, e->ld_mod, A, 1, s)) return 1;
+            if (launch_prep_mod(e->mod, B, e->ld_mod, L, e->chunks, e->d, tanh_mask, scale_mask, v.final_chunks == 2 ? 1 : 0, s)) return 1;
+        }
     }
     auto chunk = [&](int layer, int idx) -> const u16* { return idx < 0 ? nullptr : e->mod + (size_t)layer * cd + (size_t)idx * d; };
     // first pre-norm: modulate(attention_norm(x), [shift,] scale) (model.py:599 / models.py:785 / lumina_t2i model.py:600)

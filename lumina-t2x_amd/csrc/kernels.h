@@ -271,6 +271,20 @@ int launch_moe_plan(const MoeArgs& a, hipStream_t stream);     // counts -> tile
 // ---- small kernels (misc.hip) ------------------------------------------------------------------
 int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int M, int N, int K, int act_in,
                           hipStream_t stream);
+// round 6 (option prologue_fused): the three element-wise launches around the conditioning GEMVs folded into them,
+// each with the stand-alone kernel's own statements so that the results are bit-identical:
+//   t        the input rows are the sinusoidal timestep features of t[m] (launch_timestep_features: K = feature dim; `a` is not read)
+//   a2       a := bf16(a + a2) before the activation (launch_add_bf16: temb + caption / label embedding)
+//   pm_*     launch_prep_mod's transform applied to the rounded output: column n lies in chunk (n / d) % chunks of layer n / (chunks d)
+//            (tanh / one-plus by the masks) or, past the layers, in the final layer's vector (chunk pm_final -> one-plus)
+struct LinearSmallMExtra {
+    const float* t = nullptr;
+    const u16* a2 = nullptr;
+    int pm_L = 0, pm_chunks = 0, pm_d = 0, pm_final = -1;
+    unsigned pm_tanh = 0, pm_scale = 0;
+};
+int launch_linear_small_m_ext(const u16* a, const u16* w, const u16* b, u16* y, int M, int N, int K, int act_in,
+                              const LinearSmallMExtra& x, hipStream_t stream);
 // weights upload: cast src (f32/bf16/f16) to bf16 rows at dst (+ row offset handled by caller)
 int launch_cast_to_bf16(const void* src, int dtype, u16* dst, long long n, hipStream_t stream);
 // x [B,C,H,W] (bf16/f32) -> patch rows [B*N, kpad] bf16, (c,ph,pw) order, zero padded (model.py:777)

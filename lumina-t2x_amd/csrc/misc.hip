@@ -15,10 +15,11 @@ constexpr int SM_MAXM = 8;
 // activated inputs of a chunk are formed once per SM_NC columns and SM_NC independent weight loads are in flight per chunk.  Every
 // output is still the same lane-strided partial sums followed by the same wave reduction: bit-identical results.
 constexpr int SM_NC = 8;
-template <int MM>  // rows held in registers: 2 (a CFG pair), 4 or 8
+// EXT: LinearSmallMExtra (kernels.h) - inputs formed on load, launch_prep_mod's transform on the way out
+template <int MM, bool EXT = false>  // rows held in registers: 2 (a CFG pair), 4 or 8
 __global__ __launch_bounds__(256) void linear_small_m_kernel(const u16* __restrict__ a, const u16* __restrict__ w,
                                                              const u16* __restrict__ bias, u16* __restrict__ y, int M,
-                                                             int N, int K, int act_in) {
+                                                             int N, int K, int act_in, LinearSmallMExtra x = LinearSmallMExtra()) {
     const int lane = threadIdx.x & 63;
     const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SM_NC;
     if (n0 >= N) return;
@@ -39,7 +40,24 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const u16* __restri
 #pragma unroll
         for (int m = 0; m < MM; ++m) {
             if (m < M) {
-                unpack8(*(const bf8_t*)(a + (size_t)m * K + c * 8), af[m]);
+                if (EXT && x.t) {  // timestep_features_kernel's statements (below), feature k = 8 c + e of t[m]
+                    const int half = K / 2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = c * 8 + e, kk = k < half ? k : k - half;
+                        const float freq = expf(-9.210340371976184f * (float)kk / (float)half);
+                        const float arg = x.t[m] * freq;
+                        af[m][e] = bfr(k < half ? cosf(arg) : sinf(arg));
+                    }
+                } else {
+                    unpack8(*(const bf8_t*)(a + (size_t)m * K + c * 8), af[m]);
+                }
+                if (EXT && x.a2) {  // add_bf16_kernel: bf16(a + a2)
+                    float bf_[8];
+                    unpack8(*(const bf8_t*)(x.a2 + (size_t)m * K + c * 8), bf_);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) af[m][e] = bfr(af[m][e] + bf_[e]);
+                }
                 if (act_in == 1) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) af[m][e] = bfr(silu_f(af[m][e]));
@@ -68,7 +86,20 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const u16* __restri
                     float s = wave_sum(acc[j][m]);
                     if (lane == 0) {
                         if (bias) s += bf2f(bias[n0 + j]);
-                        y[(size_t)m * N + n0 + j] = f2bf(s);
+                        u16 o = f2bf(s);
+                        if (EXT && x.pm_d > 0) {  // prep_mod_kernel's transform of this column (on the ROUNDED value, as the separate pass reads it)
+                            const int n = n0 + j, layers = x.pm_L * x.pm_chunks * x.pm_d;
+                            int mode = 0;  // 1 tanh, 2 one-plus
+                            if (n < layers) {
+                                const int ch = (n / x.pm_d) % x.pm_chunks;
+                                mode = ((x.pm_tanh >> ch) & 1u) ? 1 : (((x.pm_scale >> ch) & 1u) ? 2 : 0);
+                            } else if (x.pm_final >= 0 && n >= layers + x.pm_final * x.pm_d && n < layers + (x.pm_final + 1) * x.pm_d) {
+                                mode = 2;
+                            }
+                            if (mode == 1) o = f2bf(tanhf(bf2f(o)));
+                            else if (mode == 2) o = f2bf(1.0f + bf2f(o));
+                        }
+                        y[(size_t)m * N + n0 + j] = o;
                     }
                 }
             }
@@ -378,9 +409,23 @@ int launch_linear_small_m(const u16* a, const u16* w, const u16* b, u16* y, int 
     LT_REQUIRE(M >= 1 && M <= SM_MAXM, "linear_small_m: M=%d out of range 1..%d", M, SM_MAXM);
     LT_REQUIRE(K % 8 == 0, "linear_small_m: K=%d must be a multiple of 8", K);
     const dim3 grid(((N + SM_NC - 1) / SM_NC + 3) / 4);
-    if (M <= 2) hipLaunchKernelGGL(linear_small_m_kernel<2>, grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in);
-    else if (M <= 4) hipLaunchKernelGGL(linear_small_m_kernel<4>, grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in);
-    else hipLaunchKernelGGL(linear_small_m_kernel<8>, grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in);
+    if (M <= 2) hipLaunchKernelGGL((linear_small_m_kernel<2, false>), grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in, LinearSmallMExtra());
+    else if (M <= 4) hipLaunchKernelGGL((linear_small_m_kernel<4, false>), grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in, LinearSmallMExtra());
+    else hipLaunchKernelGGL((linear_small_m_kernel<8, false>), grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in, LinearSmallMExtra());
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_linear_small_m_ext(const u16* a, const u16* w, const u16* b, u16* y, int M, int N, int K, int act_in, const LinearSmallMExtra& x,
+                              hipStream_t stream) {
+    LT_REQUIRE(M >= 1 && M <= SM_MAXM, "linear_small_m: M=%d out of range 1..%d", M, SM_MAXM);
+    LT_REQUIRE(K % 8 == 0 && (!x.t || K % 16 == 0), "linear_small_m: K=%d must be a multiple of 8 (16 with timestep features)", K);
+    LT_REQUIRE(a || x.t, "linear_small_m: no input");
+    LT_REQUIRE(x.pm_d == 0 || (x.pm_L > 0 && x.pm_chunks > 0 && x.pm_chunks <= 32), "linear_small_m: bad prep_mod geometry");
+    const dim3 grid(((N + SM_NC - 1) / SM_NC + 3) / 4);
+    if (M <= 2) hipLaunchKernelGGL((linear_small_m_kernel<2, true>), grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in, x);
+    else if (M <= 4) hipLaunchKernelGGL((linear_small_m_kernel<4, true>), grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in, x);
+    else hipLaunchKernelGGL((linear_small_m_kernel<8, true>), grid, dim3(256), 0, stream, a, w, b, y, M, N, K, act_in, x);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -29,6 +29,8 @@ const LtOptDesc kLtOptDesc[LT_OPT_COUNT] = {
     {"gemm_splitk4", 0, 1, 1, true},
     {"moe_time_plan_hoist", 0, 1, 1, true},
     {"grn_ystat", 0, 2, 1, false},
+    {"qk_wg_per_cu", 1, 8, 3, false},
+    {"prologue_fused", 0, 7, 0, false},
 };
 
 namespace {

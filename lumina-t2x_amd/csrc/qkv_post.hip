@@ -13,6 +13,7 @@
 //                 values, so the PV MFMA needs no cross-lane exchange (see attention.hip).
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
 #include "tile_order.h"
 #include <algorithm>
 
@@ -389,7 +390,7 @@ int launch_qk_norm_rope(const QkPostArgs& a, hipStream_t stream) {
     // persistent grid: ~2 workgroups (16 waves) per CU, never more workgroups than rows / 8
     const int cus = num_cus();
     const int max_blocks = (rows + QK_WAVES - 1) / QK_WAVES;
-    const dim3 grid(std::min(max_blocks, QK_WG_PER_CU * cus));
+    const dim3 grid(std::min(max_blocks, lt_opt(OPT_QK_WG_PER_CU) * cus));
     const size_t smem = (size_t)width * 4 + (size_t)QK_WAVES * (a.hd >> 1) * 8;
     switch (((width >> 3) + 63) / 64) {
         case 1: hipLaunchKernelGGL(qk_norm_rope_persistent_kernel<1>, grid, dim3(64 * QK_WAVES), smem, stream, a); break;

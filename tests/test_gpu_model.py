@@ -21,7 +21,7 @@ from oracle import nextdit_oracle as O
 from oracle import odeint_oracle as OD
 from oracle import synth
 
-from gpu_util import max_abs, rel_l2
+from gpu_util import max_abs, rel_l2, set_option
 
 pytestmark = pytest.mark.gpu
 
@@ -71,6 +71,13 @@ def test_engine_matches_reference_golden(golden_dir, name):
         assert torch.equal(got[0, :3], got[1, :3]), key
         # the unguided channel 3 is a clean probe of the un-amplified network error
         assert rel_l2(got[:, 3], ref[:, 3]) < TOL_FWD, key
+        # round 6 (option prologue_fused: measured slower than the launches it removes, so off by default): the conditioning prologue as three launches less, the separate kernels' own statements
+        set_option("prologue_fused", 7)
+        try:
+            fused = model.forward_with_cfg(z, tt, cap, mask, **kw)
+        finally:
+            set_option("prologue_fused", 0)
+        assert torch.equal(fused, got), key
 
 
 @pytest.mark.parametrize("name", ["nextdit_tiny", "nextdit_tiny_gqa"])
