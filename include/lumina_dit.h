@@ -245,6 +245,12 @@ int lt_op_gemm_splitk_auto(const void* A_dev, const void* W_dev, void* C_dev, in
  * marks a padding segment whose output rows are left untouched.  M % 256 == 0; tile_expert_dev: int32 [M / 256]. */
 int lt_op_gemm_grouped(const void* A_dev, const void* W_dev, const void* tile_expert_dev, int64_t w_expert_stride,
                        void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* stream);
+/* lt_op_gemm_grouped (plain epilogue) on the persistent kernel with its tail split: when the valid tiles are not a whole number of rounds of the
+ * CUs, the tiles of the partial last round are cut along K into 2 / 4 parts; parts hand fp32 accumulators through tail_part_f32_dev
+ * ([cap_parts][256 x 256] floats) and count in on counters_u32_dev ([number of CUs] words, zero before the first launch and after every
+ * launch); the last part of a tile to arrive sums the parts in K order, so the result does not depend on the arrival order. */
+int lt_op_gemm_grouped_tail(const void* A_dev, const void* W_dev, const void* tile_expert_dev, int64_t w_expert_stride, void* C_dev,
+                            int32_t M, int32_t N, int32_t K, void* tail_part_f32_dev, void* counters_u32_dev, int32_t cap_parts, void* stream);
 /* the same with gather-on-load (round 3: how the engine runs the experts' W1 | W3 GEMM - no gather pass, no expert-sorted copy of
  * the FFN input): row m of the problem is row row_map_dev[m] (int32 [M]) of A_dev [a_rows, K]; -1 = a padding row that reads as
  * zero.  Ping-pong tile kernels (explicit 3 / 7 / 8) and the grouped mode of the persistent 16x16x32 kernel (explicit 15; K >= 256, all of A

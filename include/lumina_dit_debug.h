@@ -78,6 +78,11 @@ extern "C" {
  *                       embedding inside the adaLN GEMV, 4: the per-NFE gate / scale preparation as that GEMV's epilogue; each removes one launch
  *                       and is bit-identical to the separate kernel, and each measured SLOWER than the launch it removes (round 6,
  *                       profiles/r06/bench_ab_prologue_merges_cfg1_cfg5_all_lose.log) | 0 (default): the separate kernels
+ *   "gemm_tail_split"   (0..2, 0): 1: the experts' W2 GEMM on the grouped persistent kernel cuts the tiles of a partial last round of its walk
+ *                       along K into 2 / 4 parts (the MoE at 1024^2: 1.5-1.6 rounds of 256 x 256 tiles run as 2); the last part of a tile to
+ *                       arrive sums the fp32 parts in K order | 2: two-way splits only | 0 (default): whole tiles only.  Built for VERDICT r5
+ *                       item 5b and measured SLOWER (cfg5-1024: 24.73 -> 26.8 ms four-way, 24.95 two-way): a 256 x 256 fp32 part is 256 KB
+ *                       through a CU that moves ~50-100 GB/s - the hand-off costs what the split saves (profiles/r06)
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

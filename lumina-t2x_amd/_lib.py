@@ -103,6 +103,7 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_op_gemm_splitk": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "lt_op_gemm_splitk_auto": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "lt_op_gemm_grouped": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "lt_op_gemm_grouped_tail": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "lt_op_gemm_grouped_gather": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_pack_w13": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "lt_op_rmsnorm_mod": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),

@@ -154,6 +154,10 @@ struct lt_engine {
     // split-K workspace of the 512-row-class GEMMs (GemmArgs::splitk_*): 128 tiles = one round of half the CUs
     float* splitk_part = nullptr;
     unsigned* splitk_cnt = nullptr;
+    // tail split of the grouped persistent GEMM (GemmArgs::tail_*; MoE engines with >= 4096 rows): fp32 parts + arrival counters
+    float* tail_part = nullptr;
+    unsigned* tail_cnt = nullptr;
+    long long tail_cap_parts = 0;
     int splitk_tiles = 0;
     u16 *capb = nullptr, *capn = nullptr, *kvy = nullptr;
     float* txt_bias = nullptr;
@@ -461,6 +465,7 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
     }
     {
         g.A = e->moe_us; g.a_row_map = nullptr; g.a_map_rows = 0; g.W = branch == 0 ? w.w2_t : w.w2_s; g.C = e->moe_ys; g.M = P; g.N = d; g.K = F;
+        if (lt_opt(OPT_GEMM_TAIL_SPLIT) && e->tail_part) { g.tail_part = e->tail_part; g.tail_cnt = e->tail_cnt; g.tail_cap_parts = e->tail_cap_parts; g.tail_max_parts = lt_opt(OPT_GEMM_TAIL_SPLIT) == 2 ? 2 : 4; }
         g.lda = F; g.ldw = F; g.ldc = d; g.w_expert_stride = (long long)d * F;
         ProfScope ps(e, 0, 2.0 * (2.0 * M) * (double)d * F, s, true);
         if (launch_gemm_bf16(g, 0, 0, s, ps.ev0(), ps.ev1())) return 1;
@@ -1092,6 +1097,14 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         if (dev_alloc(e, &q, (size_t)e->splitk_tiles * sizeof(unsigned))) return fail();
         e->splitk_cnt = (unsigned*)q;
     }
+    if (e->E > 0 && M >= 8192) {  // tail split of the experts' W2 GEMM (GemmArgs::tail_*): only where the grouped persistent kernel can run (>= 1.5 tiles per CU)
+        void* q;
+        e->tail_cap_parts = 4LL * num_cus();  // up to 4 parts for each of the < #CUs tiles of a partial round: 256 KB each
+        if (dev_alloc(e, &q, (size_t)e->tail_cap_parts * 256 * 256 * sizeof(float))) return fail();
+        e->tail_part = (float*)q;
+        if (dev_alloc(e, &q, (size_t)num_cus() * sizeof(unsigned))) return fail();
+        e->tail_cnt = (unsigned*)q;
+    }
     A16(e->patches, M * e->kpad); A16(e->frows, M * e->nfinal); A16(e->mod, Bm * e->ld_mod);
     A16(e->tfeat, Bm * 256); A16(e->t1, Bm * A); A16(e->temb, Bm * A);
     A16(e->cap_emb, Bm * A); A16(e->adaln_in, Bm * A);
@@ -1701,6 +1714,21 @@ extern "C" int lt_op_gemm_grouped(const void* A, const void* W, const void* tile
     g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = -1;
     g.tile_expert = (const int*)tile_expert; g.w_expert_stride = w_expert_stride;
     return launch_gemm_bf16(g, epilogue, variant, (hipStream_t)stream);
+}
+
+// lt_op_gemm_grouped on the persistent kernel (variant 15) with the tail split of round 6: the tiles of a partial last round of the walk are cut
+// along K into 2 / 4 parts that hand fp32 accumulators through tail_part_f32 ([cap_parts][256 x 256] floats) and count in on counters_u32
+// ([number of CUs] words, zero before the first launch; every launch leaves them zero)
+extern "C" int lt_op_gemm_grouped_tail(const void* A, const void* W, const void* tile_expert, int64_t w_expert_stride, void* C, int32_t M, int32_t N,
+                                       int32_t K, void* tail_part_f32, void* counters_u32, int32_t cap_parts, void* stream) {
+    LT_REQUIRE(A && W && C && tile_expert && tail_part_f32 && counters_u32 && cap_parts > 0, "lt_op_gemm_grouped_tail: null pointer");
+    LT_REQUIRE(M > 0 && M % 256 == 0, "lt_op_gemm_grouped_tail: M=%d must be a positive multiple of 256 (expert segments)", M);
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = N; g.bias_dtype = -1;
+    g.tile_expert = (const int*)tile_expert; g.w_expert_stride = w_expert_stride;
+    g.tail_part = (float*)tail_part_f32; g.tail_cnt = (unsigned*)counters_u32; g.tail_cap_parts = cap_parts;
+    return launch_gemm_bf16(g, 0, 15, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_gemm_grouped_gather(const void* A, int32_t a_rows, const void* row_map, const void* W, const void* tile_expert,

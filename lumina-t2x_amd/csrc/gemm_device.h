@@ -886,6 +886,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     constexpr int NM = MT * NT, RD = MT + NT, EVERY = NM / IP, RS = NM / RD;
     constexpr int NST = EPI != 1 ? MT * (NT / 2) + (NT % 2 ? MT : 0) : MT * (NT / 4);  // store instructions per wave and tile
     constexpr int NST_V = (MT / 2) * NT;  // ... of a V^T tile (EPI 3)
+    // round 6: the grouped W2 launch of the MoE at 1024^2 is 1.5-1.6 rounds of 256 x 256 tiles - the second round a
+    // third to two thirds empty.  TSPLIT: the tiles of a partial LAST round are cut along K into S parts (GemmArgs::tail_*; S picked on the
+    // device from the number of valid tiles), every part is one item of the persistent walk, parks its fp32 accumulators in a workspace and
+    // reports in; the last arriver of a tile sums the S parts in K order and runs the normal epilogue (the small-M kernels' hand-off).
+    constexpr bool TSPLIT = GROUPED && EPI == 0;
     constexpr bool YST = EPI == 0 && !GROUPED;  // round 6: the plain dense kernels can emit per-row sums of squares of their outputs (GemmArgs::ystat)
     constexpr int NST_Q = (EPI == 3 || YST) ? MT : 0;  // plain tiles of EPI 3 / YST: + the partial-sum stores (one per row tile and wave, always issued)
     static_assert(NM % IP == 0 && RS >= 1 && (RD - 1) * RS + 4 <= NM, "one LDS-DMA per EVERY MFMAs, one fragment read per RS MFMAs, the last one >= 4 MFMAs before the wait");
@@ -921,6 +926,21 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     }
     const int ntiles = TM * TN;
     const int ns = p.K / 32;
+    // virtual items of the walk: the whole rounds' tiles as they are, then S parts per tile of the partial last round
+    int nv = ntiles, tail0 = ntiles, tsl = 0;  // tsl: log2 of the parts per tail tile
+    if constexpr (TSPLIT) {
+        const int G = (int)gridDim.x, R = ntiles % G;
+        if (p.tail_part && ntiles > G && R != 0) {
+            int best = 8;  // eighths of a tile time the partial round costs: ceil(R S / G) / S, unsplit = 1
+#pragma unroll
+            for (int S = 2; S <= (p.tail_max_parts >= 4 ? 4 : 2); S *= 2) {  // (8 parts: 32 registers of partials in flight per accumulator tile - the epilogue spilled)
+                if (ns % (2 * S) != 0 || ns / S < 8 || (long long)R * S > p.tail_cap_parts) continue;
+                const int c = ((R * S + G - 1) / G) * (8 / S);
+                if (c < best) { best = c; tsl = S == 2 ? 1 : 2; }
+            }
+            if (tsl) { tail0 = ntiles - R; nv = tail0 + (R << tsl); }
+        }
+    }
     unsigned long long tr_entry = 0, tr_pro = 0, tr_loop = 0, tr_epi = 0, tr_clk = 0;
     if constexpr (TRACE) tr_entry = __builtin_amdgcn_s_memrealtime();
 
@@ -939,9 +959,19 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         ldsoff[i] = q * 1024;
     }
     const int ncols_out = EPI == 1 ? p.N / 2 : p.N;
-    struct Tile { const u16* a; const u16* w; u16* c; int a_bytes, w_bytes, c_bytes, n0, m0; };
+    struct Tile { const u16* a; const u16* w; u16* c; int a_bytes, w_bytes, c_bytes, n0, m0, part; };
+    // bytes along K an item multiplies: everything (part < 0), or part `part & (parts - 1)` of its tail tile
+    auto kbeg_of = [&](int part) __attribute__((always_inline)) { return part < 0 ? 0 : (part & ((1 << tsl) - 1)) * ((ns >> tsl) * 64); };
+    auto kend_of = [&](int part) __attribute__((always_inline)) { return part < 0 ? ns * 64 : ((part & ((1 << tsl) - 1)) + 1) * ((ns >> tsl) * 64); };
     auto setup = [&](int v) __attribute__((always_inline)) {
         int tm, tn;
+        int part_ = -1;  // >= 0: part `part_ & (parts - 1)` of tail tile `part_ >> tsl`
+        if constexpr (TSPLIT) {
+            if (v >= tail0) {
+                part_ = v - tail0;
+                v = tail0 + (part_ >> tsl);
+            }
+        }
         tile_coords(v, ntiles, TM, TN, tm, tn, p.group_rows > 0 ? p.group_rows : 4);
         const u16* wbase = p.W;
         if constexpr (GROUPED) {
@@ -964,9 +994,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         t.c_bytes = (int)(c_left > 0x7fffffffLL ? 0x7fffffffLL : c_left);
         t.n0 = n0_;
         t.m0 = m0;
+        t.part = part_;
         return t;
     };
-    const Tile t_null = {p.A, p.W, p.C, 0, 0, 0, 0, 0};  // no next tile: the last bodies' DMAs read nothing (all lanes out of range)
+    const Tile t_null = {p.A, p.W, p.C, 0, 0, 0, 0, 0, -1};  // no next tile: the last bodies' DMAs read nothing (all lanes out of range)
 
     // fragment reads: lane -> row l15 of the 16-row tile, chunk q4 (swizzled)
     const int csw = (q4 ^ (((l15 >> 3) & 1) * 3)) << 4;
@@ -977,10 +1008,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     bf16x8 wf[NT], af[MT], wf2[NT], af2[MT];
 
     int v = blockIdx.x;
-    if (v >= ntiles) return;  // uniform
-    const int my_tiles = (ntiles - 1 - v) / (int)gridDim.x + 1;
+    if (v >= nv) return;  // uniform
+    const int my_tiles = (nv - 1 - v) / (int)gridDim.x + 1;
     Tile cur = setup(v);
-    bool has_next = v + (int)gridDim.x < ntiles;
+    bool has_next = v + (int)gridDim.x < nv;
     Tile nxt = has_next ? setup(v + gridDim.x) : t_null;
 
     // GROUPED: byte offsets of this lane's four A-piece rows in the tile the DMA stream is in (ga) - dense: voff[0..3], tile-invariant
@@ -1023,7 +1054,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         const __amdgpu_buffer_rsrc_t rA = GROUPED ? gA : __builtin_amdgcn_make_buffer_rsrc((void*)t.a, 0, t.a_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)t.w, 0, t.w_bytes, 0x00020000);
         char* base = smem + (g & 3) * SLAB;
-        const int soff = slab_in_tile * 64;
+        const int soff = (TSPLIT ? kbeg_of(t.part) : 0) + slab_in_tile * 64;
 #pragma unroll
         for (int i = 0; i < IP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, i < NGA ? ga[i] : voff[i], soff, 0, 0);
@@ -1052,10 +1083,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     // scalar instructions per slab in front of an idle matrix pipe - profiles/r02/gemm_trace_w4q.log, 80-87 % main-loop duty.)
     int rd_off = SLAB;       // LDS offset of slab g + 1 (fragment reads of this body)
     int wr_off = (PD & 3) * SLAB;   // LDS offset of slab g + PD (LDS-DMA destination of this body)
-    int d_soff = PD * 64;     // byte offset along K of the slab the DMA stream fetches next ...
+    int d_soff = (TSPLIT ? kbeg_of(cur.part) : 0) + PD * 64;     // byte offset along K of the slab the DMA stream fetches next ...
+    int d_kend = TSPLIT ? kend_of(cur.part) : ns * 64;    // ... and where the stream's tile ends along K
     __amdgpu_buffer_rsrc_t dA = __builtin_amdgcn_make_buffer_rsrc((void*)cur.a, 0, cur.a_bytes, 0x00020000);   // ... in this tile
     __amdgpu_buffer_rsrc_t dW = __builtin_amdgcn_make_buffer_rsrc((void*)cur.w, 0, cur.w_bytes, 0x00020000);
-    const int kbytes = ns * 64;
     // one slab: MFMAs of slab g from (wc, ac) | fragment reads of slab g+1 into (wn_, an) | LDS-DMA of the slab three ahead.
     // FIRST (a tile's slab 0): C = 0 forms, no accumulator clears.  Accumulator tiles 0..63 live in AGPRs, the rest (NT = 9: 8 tiles)
     // in arch VGPRs; inline assembly gives each ONE home (the builtin bounced tiles through spare AGPRs: 272 us instead of 216 us on
@@ -1066,7 +1097,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         constexpr bool FIRST = decltype(first_tag)::value, SWAP = decltype(swap_tag)::value;
         const char* sb = smem + rd_off;
         char* db = smem + wr_off;
-        int n_rd = rd_off, n_wr = wr_off, n_soff = d_soff;
+        int n_rd = rd_off, n_wr = wr_off, n_soff = d_soff, n_kend = d_kend;
         __amdgpu_buffer_rsrc_t nA = dA, nW = dW;
         int n_ga[NGA];
 #pragma unroll
@@ -1101,8 +1132,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             if (i == NM - 4) { n_rd = rd_off + SLAB; n_rd = n_rd == 4 * SLAB ? 0 : n_rd; }
             if (i == NM - 3) { n_wr = wr_off + SLAB; n_wr = n_wr == 4 * SLAB ? 0 : n_wr; n_soff = d_soff + 64; }
             if (i == NM - 2) {
-                if (n_soff == kbytes) {  // the DMA stream moves on to the next tile (its last three slabs ride in this tile's bodies)
-                    n_soff = 0;
+                if (n_soff == d_kend) {  // the DMA stream moves on to the next tile (its last three slabs ride in this tile's bodies)
+                    n_soff = TSPLIT ? kbeg_of(nxt.part) : 0; n_kend = TSPLIT ? kend_of(nxt.part) : ns * 64;
                     if constexpr (!GROUPED) nA = __builtin_amdgcn_make_buffer_rsrc((void*)nxt.a, 0, nxt.a_bytes, 0x00020000);
                     nW = __builtin_amdgcn_make_buffer_rsrc((void*)nxt.w, 0, nxt.w_bytes, 0x00020000);
                     // GROUPED: the next tile's lane offsets (its map entries landed in LDS >= 2 barriers ago: K >= 256, launcher)
@@ -1112,7 +1143,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
-        rd_off = n_rd; wr_off = n_wr; d_soff = n_soff; dA = nA; dW = nW;
+        rd_off = n_rd; wr_off = n_wr; d_soff = n_soff; d_kend = n_kend; dA = nA; dW = nW;
         if constexpr (GROUPED) {
 #pragma unroll
             for (int i = 0; i < NGA; ++i) ga[i] = n_ga[i];
@@ -1287,7 +1318,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         if (has_next) {
             cur = nxt;
             v += gridDim.x;
-            has_next = v + (int)gridDim.x < ntiles;
+            has_next = v + (int)gridDim.x < nv;
             nxt = has_next ? setup(v + gridDim.x) : t_null;
         }
         if constexpr (GROUPED) {
@@ -1301,7 +1332,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     auto run_tile = [&](auto swap_tag) __attribute__((always_inline)) {
         body(std::true_type{}, swap_tag, wf, af, wf2, af2);
         body(std::false_type{}, swap_tag, wf2, af2, wf, af);
-        for (int s = 2; s < ns; s += 2) {
+        const int ns_t = (TSPLIT && cur.part >= 0) ? ns >> tsl : ns;  // slabs of this item
+        for (int s = 2; s < ns_t; s += 2) {
             body(std::false_type{}, swap_tag, wf, af, wf2, af2);
             body(std::false_type{}, swap_tag, wf2, af2, wf, af);
         }
@@ -1311,12 +1343,61 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     // scratch: 68 VGPRs stored after every plain tile's second body and re-loaded - with an s_waitcnt vmcnt(0) behind them - before
     // every V^T tile, profiles/r03 VERDICT.  Now a reconciliation can only sit on the edge between two runs; at cfg 2 a
     // workgroup's tiles are Q, K, V in this order: one edge per launch.)
+    // TSPLIT: a part's accumulators -> the workspace (written through to the memory side), the workgroup reports in; true for the LAST part
+    // of the tile to arrive, whose accumulators then hold the sum of all TS parts in K order (independent of the arrival order).  The
+    // small-M kernels' hand-off (gemm_bf16_pp above: sc0 sc1 payload, asm vmcnt(0), workgroup barrier, system-scope counter).  vmcnt(0)
+    // also waits for the next item's slabs in flight - once per tail part, not per tile.
+    auto handoff = [&](const Tile& tl) __attribute__((always_inline)) -> bool {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+        constexpr int PART_BYTES = BM * BN * 4, CP = 17;  // aux bits: sc0 | sc1
+        const int TS = 1 << tsl, tile = tl.part >> tsl, mine = tl.part & (TS - 1);
+        const int lane_e = lane_now(), tid_e = wave * 64 + lane_e;
+        const __amdgpu_buffer_rsrc_t rAll = __builtin_amdgcn_make_buffer_rsrc((void*)(p.tail_part + (size_t)tile * TS * (BM * BN)), 0, TS * PART_BYTES, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, acc[mt][nt]), rAll, ((mt * NT + nt) * 256 + tid_e) * 16, mine * PART_BYTES, CP);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's partial has reached the memory side ...
+        __syncthreads();                                   // ... before the workgroup reports in
+        int* flag = g_list + 1026;  // (behind the tile list and its count; the slab ring holds the next item's slabs)
+        if (tid_e == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.tail_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (old == (unsigned)(TS - 1)) __hip_atomic_store(p.tail_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // all arrived: free for the next launch
+            *flag = (int)old;
+        }
+        __syncthreads();
+        const bool last = __builtin_amdgcn_readfirstlane(*flag) == TS - 1;
+        __syncthreads();  // (the flag word is free again before a later part of this workgroup writes it)
+        if (!last) return false;
+        // parts in K order: ((p0 + p1) + p2) + p3, the own part re-read like the others (a select "own part from its registers at its own
+        // position" made the compiler hold all 64 accumulator tiles in VGPRs: 151 spilled registers), a part past TS reads out of range =
+        // zeros.  Six accumulator tiles' loads (24 x 16 bytes per lane) in flight between fences: two made the sum latency-bound (+47 us
+        // per launch, the first form of this code)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 o[4];
+#pragma unroll
+                for (int part = 0; part < 4; ++part) {
+                    const int off = ((mt * NT + nt) * 256 + tid_e) * 16 + (part < TS ? 0 : (int)0x40000000);
+                    o[part] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rAll, off, part * PART_BYTES, CP));
+                }
+                acc[mt][nt] = ((o[0] + o[1]) + o[2]) + o[3];
+                asm volatile("" : "+a"(acc[mt][nt]));  // back to its AGPR home right away (GROUPED: NT = 8, all 64 tiles live in AGPRs): as plain values the 64 sums sat in VGPRs and spilled
+                if ((mt * NT + nt) % 6 == 5) __builtin_amdgcn_sched_barrier(0);
+            }
+        return true;
+    };
     int t = 0;
     auto plain_tile = [&]() __attribute__((always_inline)) {
         run_tile(std::false_type{});
         if constexpr (TRACE) { tr_loop = __builtin_amdgcn_s_memrealtime(); if (t == 0) tr_clk = __builtin_amdgcn_s_memtime() - tr_clk; }
-        store_out(cur);
-        after_epilogue = 1;
+        bool emit = true;
+        if constexpr (TSPLIT) { if (cur.part >= 0) emit = handoff(cur); }
+        if (emit) store_out(cur);
+        after_epilogue = emit ? 1 : 0;
         if constexpr (TRACE) tr_epi = __builtin_amdgcn_s_memrealtime();
         advance();
         ++t;

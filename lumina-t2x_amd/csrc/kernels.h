@@ -55,6 +55,13 @@ struct GemmArgs {
     // consumes C (GatedResArgs::ystat), which can then start on a row's first bytes instead of after its last
     float* ystat = nullptr;
     int ystat_slots = 0;
+    // round 6, the grouped persistent kernel's plain epilogue (the MoE experts' W2): the tiles of a partial LAST round of the persistent walk
+    // are cut along K into 2 / 4 parts (picked on the device from the number of valid tiles), parts hand fp32 accumulators through
+    // tail_part ([tail tile][part][256 x 256] floats, tail_cap_parts parts in all) and count in on tail_cnt ([tail tile], zero between launches)
+    float* tail_part = nullptr;
+    unsigned* tail_cnt = nullptr;
+    long long tail_cap_parts = 0;
+    int tail_max_parts = 4;  // 2: two-way splits only
     int group_rows = 0;  // experiment knob (lt_set_option "gemm_group"): tile rows per group of the XCD-aware tile order (0 = 4)
     int stagger = 0;  // experiment knob of the 4-wave kernels (lt_set_option "gemm_stagger"), filled by the launcher
 };

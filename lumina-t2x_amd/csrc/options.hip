@@ -31,6 +31,7 @@ const LtOptDesc kLtOptDesc[LT_OPT_COUNT] = {
     {"grn_ystat", 0, 2, 1, false},
     {"qk_wg_per_cu", 1, 8, 3, false},
     {"prologue_fused", 0, 7, 0, false},
+    {"gemm_tail_split", 0, 2, 0, false},
 };
 
 namespace {

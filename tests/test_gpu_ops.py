@@ -377,6 +377,52 @@ def test_gemm_grouped_persistent_kernel(K, N, ntile, gather, epilogue):
             assert rel_l2(copy[rows], y) < 6e-3, (t_, ex, rel_l2(copy[rows], y))
 
 
+@pytest.mark.parametrize("K,N,ntile,holes", [(4096, 1536, 68, 2), (4096, 1536, 64, 0), (1024, 768, 100, 3), (512, 256, 300, 5)])
+def test_gemm_grouped_tail_split(K, N, ntile, holes):
+    """round 6: the grouped persistent kernel cuts the tiles of a partial LAST round of its walk along K (2 / 4 parts,
+    picked on the device from the number of valid tiles) and the last part of a tile to arrive sums the fp32 parts in K order.  Shapes: the
+    MoE W2 launch at 1024^2 (66 / 64 valid row tiles x 6 = 1.55 / 1.5 rounds of 256 CUs: 4 / 2 parts), three column tiles with 97 valid row
+    tiles (291 = 1.14 rounds: 35 tail tiles), one column tile and 295 row tiles.  Against the same kernel without the split (another
+    summation order along K: equal to fp32 rounding), an fp32 reference, twice on one workspace (bit-identical: the order of arrival
+    does not enter; the counters are back at zero) and with padding segments left untouched."""
+    E = 4
+    g = torch.Generator().manual_seed(K + N + ntile)
+    te = torch.randint(0, E, (ntile,), generator=g).tolist()
+    for h in range(holes):
+        te[(h * 37 + 1) % ntile] = -1
+    M = 256 * ntile
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(E, N, K, generator=g) / math.sqrt(K))
+    tile_expert = torch.tensor(te, dtype=torch.int32, device="cuda")
+    cap = 4 * 256
+    ws = torch.full((cap, 256 * 256), float("nan"), device="cuda", dtype=torch.float32)
+    cnt = torch.zeros(256, device="cuda", dtype=torch.int32)
+    fill = lambda: torch.full((M, N), 3.0, device="cuda", dtype=torch.bfloat16)
+    plain, split, again = fill(), fill(), fill()
+    ok(lib().lt_op_gemm_grouped(P(A), P(W), P(tile_expert), N * K, P(plain), M, N, K, 0, 15, stream()), "grouped w4q")
+    ok(lib().lt_op_gemm_grouped_tail(P(A), P(W), P(tile_expert), N * K, P(split), M, N, K, P(ws), P(cnt), cap, stream()), "grouped tail")
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0
+    used = int(torch.isfinite(ws[:, 0]).sum())
+    valid = sum(1 for x in te if x >= 0) * ((N + 255) // 256)
+    tail = valid % 256 if valid > 256 else 0
+    assert used in ((0,) if tail == 0 else (2 * tail, 4 * tail)), (used, tail)  # parts written = tail tiles x the split the device picked
+    ok(lib().lt_op_gemm_grouped_tail(P(A), P(W), P(tile_expert), N * K, P(again), M, N, K, P(ws), P(cnt), cap, stream()), "grouped tail again")
+    torch.cuda.synchronize()
+    assert torch.equal(again, split) and int(cnt.abs().sum()) == 0
+    for t_, ex in enumerate(te):
+        rows = slice(256 * t_, 256 * t_ + 256)
+        if ex < 0:
+            assert torch.all(split[rows] == 3.0), "padding segment was written"
+            continue
+        assert rel_l2(split[rows], plain[rows]) < 3e-3, (t_, ex, rel_l2(split[rows], plain[rows]))
+        if t_ % 9 == 0 or t_ >= ntile - 3:
+            y = A[rows].float() @ W[ex].float().t()
+            assert rel_l2(split[rows], y) < 4e-3, (t_, ex, rel_l2(split[rows], y))
+    if tail:
+        assert not torch.equal(split, plain)  # (the split really ran: another summation order along K)
+
+
 @pytest.mark.parametrize("tokens,B,kvh,hd,K,variant", [(4096, 2, 32, 72, 2304, 0), (64, 3, 2, 72, 128, 1), (128, 2, 8, 72, 576, 2),
                                                        (4160, 2, 32, 96, 3072, 0), (1024, 2, 32, 48, 1536, 0), (64, 1, 4, 72, 64, 2)])
 def test_gemm_vt_epilogue_matches_gemm_plus_transpose(tokens, B, kvh, hd, K, variant):
