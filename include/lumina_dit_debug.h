@@ -83,6 +83,13 @@ extern "C" {
  *                       arrive sums the fp32 parts in K order | 2: two-way splits only | 0 (default): whole tiles only.  Built for VERDICT r5
  *                       item 5b and measured SLOWER (cfg5-1024: 24.73 -> 26.8 ms four-way, 24.95 two-way): a 256 x 256 fp32 part is 256 KB
  *                       through a CU that moves ~50-100 GB/s - the hand-off costs what the split saves (profiles/r06)
+ *   "attn_text_skip"    (0..1, 1): the one-wave attention kernels (head_dim 72 / 96) do not run text tiles behind a sample's last valid text
+ *                       key (the unconditional half of a CFG pair: 8 valid keys of 128 -> one 64-key tile instead of two); the skipped keys
+ *                       are all masked, so results are bit-identical (round 6) | 0: every text tile up to Tk
+ *   "attn_tail_split"   (0..4, 4): head_dim 96 one-wave kernel, sequences with a partial last query block of 64 or 128 rows (Flag-DiT at
+ *                       1024^2: 4160 tokens = 16 x 256 + 64, the 64 workgroups of a fifth round with one live wave each): that block runs as
+ *                       this many workgroups over disjoint key ranges ((O^T, m, l) partials in fp32) and a merge launch writes its rows
+ *                       (round 6) | 0, 1: one workgroup per block as before
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

@@ -149,6 +149,8 @@ struct lt_engine {
     float* qstat = nullptr;  // [rows][qstat_slots] float2: LayerNorm partial sums of the Q columns, written by the fused QKV GEMM (GemmArgs::qstat)
     float* ystat = nullptr;  // [rows][ystat_cap] floats: per-row sum-of-squares partials of the O / W2 projection's output (GemmArgs::ystat -> GatedResArgs::ystat)
     int ystat_cap = 0;
+    float* attn_tail_ws = nullptr;  // hd 96 only: partials of the attention launch's split last query block (AttnArgs::tail_ws)
+    size_t attn_tail_ws_bytes = 0;
     float* qmr = nullptr;    // [rows] float2 (mean, rstd) of the Q rows, reduced from qstat by the K pass of qk_norm_rope (AttnArgs::q_stat)
     float* rope_tr = nullptr;  // the 2-D rotary table once more as [branch][freq][pos] (AttnArgs::rope_cs_t)
     // split-K workspace of the 512-row-class GEMMs (GemmArgs::splitk_*): 128 tiles = one round of half the CUs
@@ -652,6 +654,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         at.B = B; at.H = H; at.Hkv = Hkv; at.N = N; at.Nk = N; at.Nkpad = Npad; at.hd = hd; at.scale = sm_scale;
         at.k_prescaled = 1;
         at.nk_batch = ntok_dev;
+        at.tail_ws = e->attn_tail_ws; at.tail_ws_bytes = e->attn_tail_ws_bytes;
         if (fuse_text) {  // zero-init gated text cross-attention (model.py:420-434) inside the same launch
             at.tk = w.ky; at.tvt = w.vty; at.tbias = e->txt_bias; at.tgate = w.gate; at.Tk = e->prompt_T; at.Tkpad = e->prompt_Tpad;
         }
@@ -1088,6 +1091,12 @@ extern "C" int lt_create(const lt_config* cfg, lt_engine** out) {
         e->ystat_cap = 2 * ((d + 255) / 256);  // two wave halves per 256- or 288-column tile of a d-wide projection
         if (dev_alloc(e, &q, M * (size_t)e->ystat_cap * sizeof(float))) return fail();
         e->ystat = (float*)q;
+    }
+    if (hd == 96) {  // tail split of the one-wave attention kernel (launch_attention_v4_hd96): up to 4 parts of <= 128 rows per head
+        void* q;
+        e->attn_tail_ws_bytes = attention_tail_ws_floats((int)Bm * H, 4, 128) * sizeof(float);
+        if (dev_alloc(e, &q, e->attn_tail_ws_bytes)) return fail();
+        e->attn_tail_ws = (float*)q;
     }
     {   // split-K workspace (zeroed by dev_alloc: the counters must start at 0; every launch leaves them at 0)
         void* q;

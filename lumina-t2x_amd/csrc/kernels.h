@@ -193,6 +193,16 @@ struct AttnArgs {
     const float* tbias = nullptr; // [B, Tkpad] 0 / -inf (padded with -inf)
     const u16* tgate = nullptr;   // [H] bf16
     int Tk = 0, Tkpad = 0;
+    // one-wave kernels (hd 72 / 96), set by their launchers from option attn_text_skip: text tiles behind a sample's last valid key are
+    // not run (all their keys are masked: bit-identical results)
+    int text_skip = 0;
+    // hd-96 one-wave kernel, set by its launcher (option attn_tail_split; attention_v4_96.hip): the partial last query block of every head
+    // (N % 256 = 64 or 128 rows: one or two live waves of four) is run as tail_split workgroups over disjoint key ranges that leave
+    // (O^T, m, l) partials in tail_ws; launch_attention_v4_hd96 follows with the merge kernel.  tail_ws == nullptr at the op-level
+    // entries: the launcher's own per-device workspace.
+    int tail_split = 0, tail_rows = 0;
+    float* tail_ws = nullptr;
+    size_t tail_ws_bytes = 0;
     unsigned long long* trace = nullptr;  // diagnostics only (lt_op_attention_trace)
     // round 4 (attn_fwd_kernel_v4<72> only; attention_takes_raw_q() says whether a call qualifies): q == nullptr and the workgroup
     // makes its 256 query rows itself from the QKV projection's row-major output - q_norm (full-width affine LayerNorm in fp32; the
@@ -244,6 +254,7 @@ int launch_attention_small(const AttnSmallArgs& a, hipStream_t stream);
 int launch_attention_v4(const AttnArgs& a, hipStream_t stream);  // hd 72, 4 waves x 64 query rows (attention_v4.hip)
 int launch_attention_v4_hd48(const AttnArgs& a, hipStream_t stream);  // hd 48, the same structure, softmax-bound (attention_v4_48.hip)
 int launch_attention_v4_hd96(const AttnArgs& a, hipStream_t stream);  // hd 96, the same structure without pad slots (attention_v4_96.hip)
+size_t attention_tail_ws_floats(int heads, int parts, int rows);  // AttnArgs::tail_ws of launch_attention_v4_hd96's tail split, in floats
 bool attention_takes_raw_q(const AttnArgs& a);  // launch_attention would run this call on attn_fwd_kernel_v4<72> (the kernel with the q_raw prologue)
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
 int ensure_dynamic_lds(const void* fn, int bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) per (device, kernel), raised whenever a larger size is asked for; records the pair only on success

@@ -32,6 +32,8 @@ const LtOptDesc kLtOptDesc[LT_OPT_COUNT] = {
     {"qk_wg_per_cu", 1, 8, 3, false},
     {"prologue_fused", 0, 7, 0, false},
     {"gemm_tail_split", 0, 2, 0, false},
+    {"attn_text_skip", 0, 1, 1, true},
+    {"attn_tail_split", 0, 4, 4, false},
 };
 
 namespace {

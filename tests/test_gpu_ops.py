@@ -1023,6 +1023,109 @@ def test_attention_v4_fused_text_is_bit_identical_to_v3(B, H, Hkv, N, T, valid1)
     assert torch.equal(outs[0], outs[1]), rel_l2(outs[1], outs[0])
 
 
+def _fused_text_inputs(B, H, Hkv, N, T, valid, hd, seed):
+    """inputs of lt_op_attention_fused as the engine hands them over (both K pre-scaled); valid[b] = valid text keys of sample b"""
+    g = torch.Generator().manual_seed(seed)
+    q = bf(torch.randn(B, H, N, hd, generator=g))
+    k = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    v = bf(torch.randn(B, Hkv, N, hd, generator=g))
+    tk = bf(torch.randn(B, Hkv, T, hd, generator=g))
+    tv = bf(torch.randn(B, Hkv, T, hd, generator=g))
+    gate = bf(torch.randn(H, generator=g))
+    mask = torch.ones(B, T)
+    for b_, n_ in enumerate(valid):
+        mask[b_, n_:] = 0
+    bias = torch.where(mask > 0, 0.0, float("-inf"))
+    s_self = math.sqrt(math.log(N, 64) / hd) if N > 64 else 1 / math.sqrt(hd)
+    s_txt = 1 / math.sqrt(hd)
+    L2E = 1.4426950408889634
+    kf = (k.float() * (s_self * L2E)).to(torch.bfloat16)
+    tkf = (tk.float() * (s_txt * L2E)).to(torch.bfloat16)
+    Npad, Tpad = (N + 63) // 64 * 64, (T + 63) // 64 * 64
+    vt = torch.empty(B, Hkv, hd, Npad, device="cuda", dtype=torch.bfloat16)
+    tvt = torch.empty(B, Hkv, hd, Tpad, device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_v_transpose(P(v.permute(0, 2, 1, 3).reshape(B * N, Hkv * hd).contiguous()), Hkv * hd, 0, P(vt), B, N, Npad, Hkv, hd, stream()))
+    ok(lib().lt_op_v_transpose(P(tv.permute(0, 2, 1, 3).reshape(B * T, Hkv * hd).contiguous()), Hkv * hd, 0, P(tvt), B, T, Tpad, Hkv, hd, stream()))
+    bias_dev = torch.full((B, Tpad), float("-inf"), device="cuda", dtype=torch.float32)
+    bias_dev[:, :T] = bias.cuda()
+
+    def run():
+        out = torch.full((B, N, H * hd), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ok(lib().lt_op_attention_fused(P(q), P(kf), P(vt), P(tkf), P(tvt), P(bias_dev), P(gate), P(out), B, H, Hkv, N, N, Npad, T, Tpad,
+                                       hd, stream()), "attention_fused")
+        torch.cuda.synchronize()
+        return out
+
+    def ref():
+        o_self = r16(_attn_ref(q.cpu(), k.cpu(), v.cpu(), s_self))
+        o_txt = r16(_attn_ref(q.cpu(), tk.cpu(), tv.cpu(), s_txt, bias))
+        gt = r16(torch.tanh(gate.float().cpu())).view(1, H, 1, 1)
+        return r16(o_self + r16(o_txt * gt)).permute(0, 2, 1, 3).reshape(B, N, H * hd)
+
+    return run, ref
+
+
+@pytest.mark.parametrize("hd", [72, 96])
+@pytest.mark.parametrize("B,H,Hkv,N,T,valid", [(2, 8, 8, 320, 128, (128, 8)), (2, 4, 2, 512, 256, (70, 8)), (2, 4, 4, 256, 200, (60, 130)),
+                                                (1, 4, 4, 1024, 256, (1,)), (2, 4, 4, 192, 128, (128, 64))])
+def test_attention_text_tile_skip_is_bit_identical(B, H, Hkv, N, T, valid, hd):
+    """round 6, option attn_text_skip: the one-wave kernels do not run the text tiles behind a sample's last valid key (the unconditional
+    half of a CFG pair: 8 valid keys of 128).  Skipped keys are all masked -> exp2(-inf) = 0 into the row sum and O^T, the maximum
+    untouched: the outputs must be equal bit for bit (and right: checked against fp32)"""
+    set_option("attention_variant", 4)
+    run, ref = _fused_text_inputs(B, H, Hkv, N, T, valid, hd, seed=N + T + hd)
+    outs = []
+    try:
+        for skip in (0, 1):
+            set_option("attn_text_skip", skip)
+            outs.append(run())
+    finally:
+        set_option("attn_text_skip", 1)
+    assert not torch.isnan(outs[1].float()).any()
+    assert torch.equal(outs[0], outs[1]), rel_l2(outs[1], outs[0])
+    assert rel_l2(outs[1], ref()) < 6e-3
+
+
+@pytest.mark.parametrize("B,H,Hkv,N,T,valid,parts", [(2, 8, 8, 4160, 128, (128, 8), 4), (1, 8, 2, 2176, 77, (77,), 4), (1, 4, 4, 1088, 64, (64,), 2),
+                                                      (2, 4, 4, 2112, 256, (256, 130), 3), (1, 16, 16, 4160, 0, (), 4), (1, 4, 1, 2688, 0, (), 4)])
+def test_attention_hd96_tail_split(B, H, Hkv, N, T, valid, parts):
+    """round 6, option attn_tail_split: the partial last query block of a head_dim-96 head (64 or 128 rows: Flag-DiT's
+    4160 tokens) runs as `parts` workgroups over disjoint key ranges + a merge launch.  Rows of the whole blocks: bit-identical to the
+    unsplit launch.  Tail rows: a different summation order of the same flash recurrence -> compared at the attention tolerance against
+    fp32, and against the unsplit kernel at a bf16 ulp's worth"""
+    hd = 96
+    set_option("attention_variant", 4)
+    if T:
+        run, ref = _fused_text_inputs(B, H, Hkv, N, T, valid, hd, seed=N + T)
+    else:
+        g = torch.Generator().manual_seed(N)
+        q = bf(torch.randn(B, H, N, hd, generator=g))
+        k = bf(torch.randn(B, Hkv, N, hd, generator=g))
+        v = bf(torch.randn(B, Hkv, N, hd, generator=g))
+        rep = H // Hkv
+        k[:, :, N - 70] = q[:, ::rep, N - 5] * 3.0   # a late maximum for a tail row: the parts' maxima differ by a lot
+        k[:, :, 3] = q[:, ::rep, N - 40] * 2.0
+        scale = math.sqrt(math.log(N, 64) / hd)
+        run = lambda: _run_attn(q, k, v, scale, fold_scale=True).permute(0, 2, 1, 3).reshape(B, N, H * hd).clone()
+        ref = lambda: _attn_ref(q.cpu(), k.cpu(), v.cpu(), scale).permute(0, 2, 1, 3).reshape(B, N, H * hd)
+    outs = {}
+    try:
+        for ts in (0, parts):
+            set_option("attn_tail_split", ts)
+            outs[ts] = run()
+    finally:
+        set_option("attn_tail_split", 4)
+    whole = (N // 256) * 256
+    assert N % 256 in (64, 128)
+    assert not torch.isnan(outs[parts].float()).any()
+    assert torch.equal(outs[0][:, :whole], outs[parts][:, :whole])
+    r = ref()
+    assert rel_l2(outs[parts], r) < 6e-3, rel_l2(outs[parts], r)
+    assert rel_l2(outs[parts][:, whole:], r[:, whole:]) < 6e-3, rel_l2(outs[parts][:, whole:], r[:, whole:])
+    assert rel_l2(outs[parts][:, whole:], outs[0][:, whole:]) < 4e-3, rel_l2(outs[parts][:, whole:], outs[0][:, whole:])
+    assert not torch.equal(outs[parts][:, whole:], torch.zeros_like(outs[parts][:, whole:]))
+
+
 @pytest.mark.parametrize("M,N,K,act", [(2, 1000, 256, 0), (2, 9216, 1024, 1), (1, 37, 128, 1), (8, 64, 2048, 0), (3, 1001, 1024, 1), (5, 7, 64, 0),
                                        (2, 101376, 1024, 1)])
 def test_linear_small_m(M, N, K, act):
