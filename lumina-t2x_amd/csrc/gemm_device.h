@@ -875,6 +875,11 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 #ifndef LT_W4Q_PD
 #define LT_W4Q_PD 3
 #endif
+#ifdef LT_W4Q_PAIRLINE
+#define LT_W4Q_SOFF_MUL 2
+#else
+#define LT_W4Q_SOFF_MUL 1
+#endif
 template <int EPI, int NW16, bool TRACE = false, bool GROUPED = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     constexpr int PD = LT_W4Q_PD;
@@ -955,7 +960,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         if (q >= NP) q -= NW;
         const bool isA = i < PA / NW;
         const int r0 = 16 * (isA ? q : q - PA) + (lane >> 2);
+#ifdef LT_W4Q_PAIRLINE
+        // TIMING PROBE ONLY (round 6; results are garbage on row-major operands): the addresses the stream would issue if A and W were stored
+        // row-pair-interleaved per 32-deep K chunk ([rows / 2][K / 32][2][32]) - a pair of rows' 64-byte slab pieces = ONE 128-byte line, so an
+        // LDS-DMA instruction touches 8 whole lines instead of 16 half lines; the LDS image is the same
+        voff[i] = (r0 >> 1) * (isA ? p.lda : p.ldw) * 4 + (r0 & 1) * 64 + sswz;
+#else
         voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + sswz;
+#endif
         ldsoff[i] = q * 1024;
     }
     const int ncols_out = EPI == 1 ? p.N / 2 : p.N;
@@ -1057,7 +1069,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         const int soff = (TSPLIT ? kbeg_of(t.part) : 0) + slab_in_tile * 64;
 #pragma unroll
         for (int i = 0; i < IP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, i < NGA ? ga[i] : voff[i], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, i < NGA ? ga[i] : voff[i], soff * LT_W4Q_SOFF_MUL, 0, 0);
     };
     stagger_start(p.stagger);
     // prologue (once per workgroup): slabs 0..2 in flight, slab 0 read into the first fragment set, slab 1 landed and visible
@@ -1127,7 +1139,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             }
             if (i % EVERY == EVERY / 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(i / EVERY < PA / NW ? (GROUPED ? gA : dA) : dW, LDS_PTR(db + ldsoff[i / EVERY]), 16,
-                                                         i / EVERY < NGA ? ga[i / EVERY < NGA ? i / EVERY : 0] : voff[i / EVERY], d_soff, 0, 0);
+                                                         i / EVERY < NGA ? ga[i / EVERY < NGA ? i / EVERY : 0] : voff[i / EVERY], d_soff * LT_W4Q_SOFF_MUL, 0, 0);
             // the next body's scalar state, a few instructions under each of the last MFMAs
             if (i == NM - 4) { n_rd = rd_off + SLAB; n_rd = n_rd == 4 * SLAB ? 0 : n_rd; }
             if (i == NM - 3) { n_wr = wr_off + SLAB; n_wr = n_wr == 4 * SLAB ? 0 : n_wr; n_soff = d_soff + 64; }
