@@ -214,6 +214,17 @@ int lt_op_gemm_qkv(const void* A_dev, const void* W_dev, void* C_dev, void* vt_d
                    int32_t tokens, int32_t hd, void* stream);
 /* 1 if the engine runs this QKV projection as ONE launch (lt_op_gemm_qkv's conditions and the options allow it), else 0 */
 int lt_op_gemm_qkv_fusable(int32_t M, int32_t N, int32_t K, int32_t split, int32_t tokens, int32_t hd);
+/* round 6: the ROW-PAIR-INTERLEAVED operand layout of the persistent dense GEMM kernel.  Element (r, k) of a dense [rows][cols] bf16 matrix sits at
+ * (r >> 1) * 2 cols + (k >> 5) * 64 + (r & 1) * 32 + (k & 31): the 64-byte pieces a 32-deep K slab takes from rows 2 i and 2 i + 1 are ONE 128-byte
+ * line, so the kernel's LDS-DMA stream asks the L2 for whole lines (half the requests for the same bytes; the engine keeps the dense blocks'
+ * GEMM weights and their activation operands in it whenever all four GEMMs of the block run on that kernel - lumina_dit_debug.h names the switch).
+ * lt_op_pair_layout converts in place (to_pair 1: row-major -> pair, 0: back; rows even, cols % 32 == 0, cols <= 16384).
+ * lt_op_gemm_bf16_pair = lt_op_gemm_bf16 (no bias, variant 0, shapes that run on the persistent kernel: >= one 256-row tile per CU) with A and W
+ * in the pair layout; pair_c != 0 (epilogue 1 only): the [M][N / 2] output is written in it too.  Same products in the same order as the
+ * row-major call: bit-identical results. */
+int lt_op_pair_layout(void* m_dev, int64_t rows, int32_t cols, int32_t to_pair, void* stream);
+int lt_op_gemm_bf16_pair(const void* A_dev, const void* W_dev, void* C_dev, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t pair_c,
+                         void* stream);
 /* name of the kernel lt_op_gemm_bf16(..., variant) would launch for a dense problem (bench.py labels its roofline line with it) */
 int lt_op_gemm_describe(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t variant, char* out, int32_t cap);
 /* the routing plan of one mixture-of-experts FFN (what replaces the host loop `for i, expert in enumerate(self.experts): batch_idx, nth =

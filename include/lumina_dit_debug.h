@@ -90,6 +90,13 @@ extern "C" {
  *                       1024^2: 4160 tokens = 16 x 256 + 64, the 64 workgroups of a fifth round with one live wave each): that block runs as
  *                       this many workgroups over disjoint key ranges ((O^T, m, l) partials in fp32) and a merge launch writes its rows
  *                       (round 6) | 0, 1: one workgroup per block as before
+ *   "pair_layout"       (0..1, 1): evaluations whose dense blocks run all four GEMMs on the persistent kernel (the fused QKV launch, O, W1 | W3,
+ *                       W2: >= one 256-row tile per CU) and the attention on a one-wave kernel keep the GEMMs' A operands (pre-norm output,
+ *                       attention output, SwiGLU output) and the four weights of every layer in the row-pair-interleaved layout (lumina_dit.h,
+ *                       lt_op_pair_layout): the LDS-DMA stream then fetches whole 128-byte lines - half the requests into the L2, the
+ *                       counter that separated this kernel from the vendor's (round 6).  The weights are converted in place when the
+ *                       regime changes (a 256-token call after a 4096-token one) and before every lt_set_weight; bit-identical results
+ *                       | 0: row-major everywhere
  * (the round-1 names gemm_pipeline / gemm_pp_tail / gemm_persist are accepted with value 0 only: the study kernels they selected were
  *  deleted with csrc/experimental/ in round 5) */
 

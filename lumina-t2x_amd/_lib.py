@@ -95,6 +95,8 @@ _SIGNATURES: Dict[str, tuple] = {
     "lt_profile_set_budget": (_i32, [_vp, _i32, _i64]),
     "lt_profile_set_window": (_i32, [_vp, _i32, _i64, _i64]),
     "lt_op_gemm_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "lt_op_pair_layout": (_i32, [_vp, _i64, _i32, _i32, _vp]),
+    "lt_op_gemm_bf16_pair": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_vt": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_qkv": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lt_op_gemm_qkv_fusable": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),

@@ -973,6 +973,18 @@ bool attention_takes_raw_q(const AttnArgs& a) {
            (!a.tk || a.Tkpad <= 256);
 }
 
+// launch_attention would run this call on one of the one-wave-per-SIMD kernels (hd 72 / 48 / 96: the ones that can write their output in the
+// pair layout, AttnArgs::out_pair) - the same expressions as the dispatch below
+bool attention_is_one_wave(const AttnArgs& a) {
+    const int g_attn_variant = lt_opt(OPT_ATTENTION_VARIANT);
+    if (g_attn_variant >= 4 && a.hd == 72 && a.bias == nullptr && !a.accumulate && !a.nk_batch && a.Nk % 64 == 0 && (!a.tk || a.Tkpad <= 256)) return true;
+    if (g_attn_variant >= 4 && a.hd == 48 && a.bias == nullptr && !a.accumulate && !a.nk_batch && !a.trace && a.Nk % 64 == 0 && !a.tk &&
+        (g_attn_variant == 6 || (long long)a.B * a.H * ((a.N + 255) / 256) >= 200)) return true;
+    if (g_attn_variant >= 4 && a.hd == 96 && a.bias == nullptr && !a.accumulate && !a.nk_batch && !a.trace && a.Nk % 64 == 0 && a.Nk == a.Nkpad &&
+        (!a.tk || (a.Tkpad <= 256 && a.Tkpad % 64 == 0))) return true;
+    return false;
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
     const int g_attn_variant = lt_opt(OPT_ATTENTION_VARIANT);
     LT_REQUIRE(a.H % a.Hkv == 0, "attention: H=%d not a multiple of Hkv=%d", a.H, a.Hkv);
@@ -983,6 +995,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     LT_REQUIRE(!a.accumulate || a.gate != nullptr, "attention: accumulate mode needs a gate");
     LT_REQUIRE(a.scale > 0.f, "attention: softmax scale must be positive");
     LT_REQUIRE(a.q_batch_map == nullptr || a.bias != nullptr, "attention: q_batch_map is built for the masked (text) kernels only");
+    LT_REQUIRE(!a.out_pair || attention_is_one_wave(a), "attention: out_pair (pair layout of the output) is written by the one-wave kernels only");
     const int nqb = (a.N + 127) / 128;
     dim3 grid(a.B * a.H * nqb), block(256);
 #define LAUNCH_V1(HD_) hipLaunchKernelGGL(attn_fwd_kernel<HD_>, grid, block, 2 * (64 * HD_ * 2) + 2 * (HD_ * 128), stream, a)

@@ -436,8 +436,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v4h48(AttnArgs p) {
     // ---- output: through a wave-private LDS strip to row-contiguous 16-byte stores (store_rows_via_lds, common.h) ---------------------
     {
         const int row0 = qb * 256 + wave * 64;
-        store_rows_via_lds<HD, DT>(smem + STG_OFF + wave * (64 * HD * 2), res, lane,
-                                   p.out + ((size_t)b * p.N + row0) * ((size_t)p.H * HD) + (size_t)h * HD, (size_t)p.H * HD, p.N - row0);
+        if (p.out_pair)
+            store_rows_via_lds<HD, DT>(smem + STG_OFF + wave * (64 * HD * 2), res, lane, p.out, (size_t)p.H * HD, p.N - row0, 1, (size_t)b * p.N + row0, h * HD);
+        else
+            store_rows_via_lds<HD, DT>(smem + STG_OFF + wave * (64 * HD * 2), res, lane,
+                                       p.out + ((size_t)b * p.N + row0) * ((size_t)p.H * HD) + (size_t)h * HD, (size_t)p.H * HD, p.N - row0);
     }
     if (p.trace && tid == 0) {  // per workgroup: s_memrealtime (100 MHz) at entry | loop start | loop end | exit, shader clocks of the loop
         unsigned long long* o = p.trace + (size_t)blockIdx.x * 8;

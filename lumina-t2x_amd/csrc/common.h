@@ -100,7 +100,8 @@ __device__ __forceinline__ f32x2 swiglu2(f32x2 x, f32x2 y) {
 // stay in order) and stores them as HD / 8 instructions of 64 consecutive 16-byte chunks - ~7 row segments = ~16 lines each.
 // obase = the output address of the wave's first row (this head's columns); rows_valid = rows of the 64 that exist.
 template <int HD, int DT>
-__device__ __forceinline__ void store_rows_via_lds(char* tb, const u32x2 (&res)[2][DT][4], int lane, u16* obase, size_t row_stride, int rows_valid) {
+__device__ __forceinline__ void store_rows_via_lds(char* tb, const u32x2 (&res)[2][DT][4], int lane, u16* obase, size_t row_stride, int rows_valid,
+                                                   int pair = 0, size_t grow0 = 0, int col0 = 0) {
     const int hi = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
@@ -119,7 +120,14 @@ __device__ __forceinline__ void store_rows_via_lds(char* tb, const u32x2 (&res)[
     for (int i = 0; i < CPR; ++i) {
         const int c = lane + 64 * i;
         const int r = c / CPR, ch = c - r * CPR;
-        if (r < rows_valid) *(u32x4*)(obase + (size_t)r * row_stride + ch * 8) = *(const u32x4*)(tb + r * (HD * 2) + ch * 16);
+        if (r < rows_valid) {
+            // pair != 0: obase is the [rows][row_stride] matrix in the row-pair-interleaved layout (GemmArgs::pair_ab), the strip's first row is
+            // its row grow0 and the strip's first column its column col0
+            const size_t gr = grow0 + r;
+            const int c = col0 + ch * 8;
+            u16* dst = pair ? obase + (gr >> 1) * (2 * row_stride) + (gr & 1) * 32 + c + (c >> 5) * 32 : obase + (size_t)r * row_stride + ch * 8;
+            *(u32x4*)dst = *(const u32x4*)(tb + r * (HD * 2) + ch * 16);
+        }
     }
 }
 

@@ -127,6 +127,10 @@ struct lt_engine {
     int label_rows = 0;
     std::map<std::string, bool> need;
     bool weights_ok = false;
+    // round 6: the dense blocks' four GEMM weights (wqkv, wo, w13, w2 of every layer) are held either row-major or in the row-pair-interleaved
+    // layout the persistent GEMM reads with whole-line requests (GemmArgs::pair_ab); ensure_weight_layout converts all of them in place when an
+    // evaluation needs the other one (a change of regime: >= one tile per CU <-> the small-M kernels).  last_pair: what the last run_forward used.
+    bool w_pair = false, last_pair = false;
     // workspace
     u16 *x = nullptr, *h = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr;
     u16 *o = nullptr, *u = nullptr, *patches = nullptr, *frows = nullptr, *mod = nullptr;
@@ -185,7 +189,7 @@ struct lt_engine {
     // HIP graphs of one model evaluation (forward_graphed): fixed staging buffers the captured kernels read / write, a private
     // stream to capture on (the caller's stream may be the legacy null stream, which cannot capture), cached executables
     struct GraphTally { double flops[3] = {0, 0, 0}; long long launches[3] = {0, 0, 0}; };  // what one replay stands for, per kernel class
-    struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int uses = 0; bool failed = false; GraphTally tally; };
+    struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int uses = 0; bool failed = false; bool pair = false; GraphTally tally; };
     GraphTally* tally = nullptr;  // set while a graph is being captured: ProfScope counts into it instead of timing
     std::vector<GraphEntry> graphs;
     void *g_x = nullptr, *g_out = nullptr;
@@ -252,10 +256,11 @@ void prefetch_rider(lt_engine* e, PrefetchRider* r, const u16* A, int lda, const
 
 // ystat_slots (optional, out): > 0 when the launch left the rows' sum-of-squares partials in e->ystat (option grn_ystat; GemmArgs::ystat)
 int gemm(lt_engine* e, const u16* A, int lda, const u16* W, int ldw, u16* C, int ldc, int M, int N, int K,
-         const u16* bias, int epi, hipStream_t s, int* ystat_slots = nullptr) {
+         const u16* bias, int epi, hipStream_t s, int* ystat_slots = nullptr, int pair_ab = 0, int pair_c = 0) {
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.bias_dtype = bias ? 1 : -1;
+    g.pair_ab = pair_ab; g.pair_c = pair_c;
     g.splitk_part = e->splitk_part; g.splitk_cnt = e->splitk_cnt; g.splitk_tiles = e->splitk_tiles;  // (the launcher decides)
     if (ystat_slots) {
         *ystat_slots = 0;
@@ -501,6 +506,21 @@ struct PackedDesc {
     const int32_t* hw;          // [B][2] latent (H_b, W_b), host
 };
 
+// all four GEMM weights of every dense block -> the row-pair-interleaved layout (want) or back to row-major, in place, on stream s
+int ensure_weight_layout(lt_engine* e, bool want, hipStream_t s) {
+    if (e->w_pair == want) return 0;
+    LT_REQUIRE(e->E == 0, "pair layout: dense blocks only");
+    for (int l = 0; l < e->L; ++l) {
+        LayerW& w = e->lw[l];
+        if (launch_pair_layout(w.wqkv, e->qkvn, e->d, want, s)) return 1;
+        if (launch_pair_layout(w.wo, e->d, e->d, want, s)) return 1;
+        if (launch_pair_layout(w.w13, 2LL * e->F, e->d, want, s)) return 1;
+        if (launch_pair_layout(w.w2, e->d, e->F, want, s)) return 1;
+    }
+    e->w_pair = want;
+    return 0;
+}
+
 int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, const lt_step_args* a, int use_cfg,
                 hipStream_t s, const PackedDesc* pk = nullptr) {
     const lt_config& c = e->cfg;
@@ -624,12 +644,49 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         }
     }
     auto chunk = [&](int layer, int idx) -> const u16* { return idx < 0 ? nullptr : e->mod + (size_t)layer * cd + (size_t)idx * d; };
+    // round 6, option pair_layout: when every GEMM of the dense block runs on the persistent kernel (>= one tile per CU: the fused QKV launch,
+    // O, W1 | W3, W2) and the attention on a one-wave kernel, their A operands (h, the attention output, the SwiGLU output) and the four
+    // weights are kept in the row-pair-interleaved layout (GemmArgs::pair_ab): the GEMM's LDS-DMA stream then asks the L2 for whole 128-byte
+    // lines - half the requests.  Same products in the same order: bit-identical to the row-major path.
+    bool pair = false;
+    if (lt_opt(OPT_PAIR_LAYOUT) && e->E == 0 && !pk && M % 2 == 0 && d % 32 == 0 && F % 32 == 0 && F <= 16384 && d <= 16384 && !(v.text && e->reg_Y > 0) &&
+        (!v.text || attention_fuses_text(hd))) {
+        GemmArgs gq;
+        gq.A = e->h; gq.W = e->lw[0].wqkv; gq.C = e->qkv; gq.bias = nullptr; gq.bias_dtype = -1; gq.M = M; gq.N = d + 2 * dkv; gq.K = d;
+        gq.lda = d; gq.ldw = d; gq.ldc = e->qkvn; gq.VT = e->vt; gq.vt_split = d + dkv; gq.vt_tokens = N; gq.vt_hd = hd; gq.vt_npad = Npad;
+        const bool vt_epi0 = lt_opt(OPT_QKV_VT_EPILOGUE) && N % 64 == 0 && (long long)((M + 255) / 256) * ((dkv + 255) / 256) >= 128;
+        GemmArgs go, g13, g2;
+        go.A = e->attn; go.W = e->lw[0].wo; go.C = e->o; go.bias = nullptr; go.bias_dtype = -1; go.M = M; go.N = d; go.K = d; go.lda = d; go.ldw = d; go.ldc = d;
+        g13 = go; g13.A = e->h; g13.W = e->lw[0].w13; g13.C = e->u; g13.N = 2 * F; g13.ldc = F;
+        g2 = go; g2.A = e->u; g2.W = e->lw[0].w2; g2.K = F; g2.lda = F; g2.ldw = F;
+        AttnArgs at0;
+        at0.q = e->q; at0.k = e->k; at0.vt = e->vt; at0.bias = nullptr; at0.out = e->attn; at0.gate = nullptr; at0.accumulate = 0;
+        at0.B = B; at0.H = H; at0.Hkv = Hkv; at0.N = N; at0.Nk = N; at0.Nkpad = Npad; at0.hd = hd; at0.scale = sm_scale; at0.k_prescaled = 1;
+        at0.nk_batch = ntok_dev;
+        if (v.text) { at0.tk = e->lw[0].ky; at0.tvt = e->lw[0].vty; at0.tbias = e->txt_bias; at0.tgate = e->lw[0].gate; at0.Tk = e->prompt_T; at0.Tkpad = e->prompt_Tpad; }
+        pair = vt_epi0 && lt_opt(OPT_QKV_FUSED_GEMM) && gemm_qkv_fusable(gq) && gemm_runs_w4q_dense(go, 0) && gemm_runs_w4q_dense(g13, 1) &&
+               gemm_runs_w4q_dense(g2, 0) && attention_is_one_wave(at0);
+    }
+    if (e->w_pair != pair) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) {
+            if (ensure_weight_layout(e, pair, s)) return 1;
+        } else {
+            // inside a capture (the caller's own graph) a layout change would be baked into every replay: run on the layout the weights are in
+            LT_REQUIRE(!e->w_pair, "this evaluation runs on the small-M kernels, which read row-major weights, but the engine's weights are in the "
+                                   "pair layout of the last large evaluation and the stream is capturing: run one eager evaluation of this shape first");
+            pair = false;
+        }
+    }
+    e->last_pair = pair;
     // first pre-norm: modulate(attention_norm(x), [shift,] scale) (model.py:599 / models.py:785 / lumina_t2i model.py:600)
     {
         ProfScope ps(e, 2, 0, s);
         NormModArgs n;
         n.x = e->x; n.w = v.pre_w ? e->lw[0].attn_norm1 : nullptr; n.scale = chunk(0, v.i_scale[0]); n.shift = chunk(0, v.i_shift[0]);
         n.out = e->h; n.rows = M; n.rows_per_batch = N; n.d = d; n.ld_mod = e->ld_mod; n.eps = c.norm_eps; n.scale_pre = 1;
+        n.out_pair = pair;
         if (launch_rmsnorm_mod(n, s)) return 1;
     }
     const int post_mode = v.post ? 1 : 0, gate_mode = 0;  // gates arrive ready (tanh applied above where the family has it)
@@ -686,6 +743,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             raw_q = lt_opt(OPT_ATTN_Q_FUSED) && c.qk_norm && !v.rope_1d && !pk && !regional && (fuse_text || !v.text) && attention_takes_raw_q(at) &&
                     bn > 0 && d % bn == 0 && 2 * d / bn <= 32;
             if (raw_q) { gq.qstat = e->qstat; gq.qstat_cols = d; gq.qstat_slots = 2 * d / bn; }
+            gq.pair_ab = pair;
             ProfScope ps(e, 0, 2.0 * M * (double)(d + 2 * dkv) * d, s, true);
             if (launch_gemm_bf16(gq, 3, 0, s, ps.ev0(), ps.ev1())) return 1;
         } else if (vt_epi) {
@@ -733,6 +791,8 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 if (!vt_epi && launch_v_transpose(e->qkv, e->qkvn, d + dkv, e->vt, B, N, Npad, Hkv, hd, s)) return 1;
             }
         }
+        LT_REQUIRE(!pair || (!small_fused && vt_epi && gq.pair_ab && !regional && (fuse_text || !v.text)), "pair layout: the block left the path it was chosen for");
+        at.out_pair = pair;
         if (!small_fused && attention(e, at, s)) return 1;
         if (regional) {
             // compositional Next-DiT (lumina_next_compositional_generation/models/model.py:422-446): every caption attends the
@@ -751,7 +811,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             if (attention(e, at, s)) return 1;
         }
         int ys_o = 0, ys_f = 0;
-        if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s, &ys_o)) return 1;
+        if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s, &ys_o, pair)) return 1;
         {   // x += gate' * post(attn) ; h = pre_ffn(x) * (1 + scale) [+ shift]
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
@@ -759,15 +819,15 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             g.x = e->x; g.y = e->o; g.post_w = v.post ? w.attn_norm2 : nullptr; g.gate = chunk(l, v.i_gate[0]);
             g.post_mode = post_mode; g.gate_mode = gate_mode;
             g.next_w = v.pre_w ? w.ffn_norm1 : nullptr; g.next_scale = chunk(l, v.i_scale[1]); g.next_shift = chunk(l, v.i_shift[1]);
-            g.next_mode = 1; g.h = e->h;
+            g.next_mode = 1; g.h = e->h; g.h_pair = pair;
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
             if (e->E == 0) prefetch_rider(e, &g.pf, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, 1);
             if (launch_gated_residual_norm(g, s)) return 1;
         }
         const u16 *last_post_w, *last_gate;
         if (e->E == 0) {
-            if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s)) return 1;
-            if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s, &ys_f)) return 1;
+            if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s, nullptr, pair, pair)) return 1;
+            if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s, &ys_f, pair)) return 1;
             last_post_w = v.post ? w.ffn_norm2 : nullptr;
             last_gate = chunk(l, v.i_gate[1]);
         } else if (e->moe_mode != 0) {  // one MoE FFN in the ImageNet block (models.py:755-758: time-routed; models1.py: per token)
@@ -807,7 +867,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             g.rows = M; g.rows_per_batch = N; g.d = d; g.ld_mod = e->ld_mod; g.eps = c.norm_eps; g.eps_next = 1e-6f; g.scale_pre = 1;
             if (l + 1 < L) {
                 g.next_w = v.pre_w ? e->lw[l + 1].attn_norm1 : nullptr; g.next_scale = chunk(l + 1, v.i_scale[0]);
-                g.next_shift = chunk(l + 1, v.i_shift[0]); g.next_mode = 1;
+                g.next_shift = chunk(l + 1, v.i_shift[0]); g.next_mode = 1; g.h_pair = pair;
             } else {  // final layer: LayerNorm(no affine, 1e-6) * (1 + scale) [+ shift] (model.py:657-661 / models.py:829-832)
                 const u16* fin = e->mod + (size_t)L * cd;
                 g.next_w = nullptr; g.next_mode = 2;
@@ -883,7 +943,11 @@ int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* ou
         ge = &e->graphs.back();
         ge->key = key;
     }
-    if (ge->failed || ge->uses++ == 0) return run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+    if (ge->failed || ge->uses++ == 0) {
+        const int rc = run_forward(e, x_in, t_dev, out, a, use_cfg, s);
+        ge->pair = e->last_pair;  // (the weight layout this key's evaluations run on; a function of the key)
+        return rc;
+    }
     // a caller that is capturing ITS stream (torch.cuda.graph around the sampler) cannot launch a graph or start a second capture
     // from inside: hand it plain launches, which its own capture records
     hipStreamCaptureStatus caller_cap = hipStreamCaptureStatusNone;
@@ -892,6 +956,8 @@ int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* ou
     // the RoPE table is ONE shared buffer outside every graph (it is rebuilt only when scale / ntk change): a replay of key A after
     // key B changed the table must rebuild it first - before every replay, not only before the capture
     if (ensure_rope(e, a, s)) return 1;
+    // ... and so are the GEMM weights' layouts (row-major / pair): evaluations of another regime may have converted them since
+    if (ensure_weight_layout(e, ge->pair, s)) return 1;
     if (!ge->exec) {
         if (!e->cap_stream) LT_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
         hipGraph_t graph = nullptr;
@@ -902,6 +968,7 @@ int forward_graphed(lt_engine* e, const void* x_in, const float* t_dev, void* ou
             e->tally = &ge->tally;
             rc = run_forward(e, e->g_x, e->g_t, e->g_out, a, use_cfg, e->cap_stream);
             e->tally = nullptr;
+            if (rc == 0 && e->last_pair != ge->pair) { lt_set_error("graph capture: the evaluation's operand layout changed between the eager run and the capture"); rc = 1; }
             ok = hipStreamEndCapture(e->cap_stream, &graph) == hipSuccess && rc == 0 && graph != nullptr;
         }
         if (ok) ok = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -1173,6 +1240,7 @@ extern "C" int lt_set_weight(lt_engine* e, const char* key, const void* src_dev,
     for (int i = 0; i < ndim; ++i) LT_REQUIRE(shape[i] > 0, "weight '%s': shape[%d] = %lld", key, i, (long long)shape[i]);
     Slot s;
     if (find_slot(e, key, &s)) return 2;
+    if (ensure_weight_layout(e, false, (hipStream_t)stream)) return 1;  // uploads write row-major rows
     long long n = 1;
     for (int i = 0; i < ndim; ++i) n *= shape[i];
     LT_REQUIRE(n == (long long)s.rows * s.cols, "weight '%s': %lld elements given, %lld expected (%d x %d)", key, n,
@@ -1622,6 +1690,20 @@ extern "C" int lt_op_gemm_bf16(const void* A, const void* W, const void* bias, i
     g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = bias ? bias_dtype : -1;
     return launch_gemm_bf16(g, epilogue, variant, (hipStream_t)stream);
+}
+
+// round 6: the row-pair-interleaved operand layout of the persistent GEMM (GemmArgs::pair_ab) at the op level
+extern "C" int lt_op_pair_layout(void* m, int64_t rows, int32_t cols, int32_t to_pair, void* stream) {
+    LT_REQUIRE(m, "lt_op_pair_layout: null pointer");
+    return launch_pair_layout((u16*)m, rows, cols, to_pair, (hipStream_t)stream);
+}
+extern "C" int lt_op_gemm_bf16_pair(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t pair_c,
+                                    void* stream) {
+    LT_REQUIRE(A && W && C, "lt_op_gemm_bf16_pair: null pointer");
+    GemmArgs g;
+    g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = -1; g.pair_ab = 1; g.pair_c = pair_c;
+    return launch_gemm_bf16(g, epilogue, 0, (hipStream_t)stream);
 }
 
 extern "C" int lt_op_gemm_vt(const void* A, const void* W, void* vt, int32_t M, int32_t N, int32_t K, int32_t tokens, int32_t hd,

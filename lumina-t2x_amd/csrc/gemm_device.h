@@ -875,11 +875,6 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 #ifndef LT_W4Q_PD
 #define LT_W4Q_PD 3
 #endif
-#ifdef LT_W4Q_PAIRLINE
-#define LT_W4Q_SOFF_MUL 2
-#else
-#define LT_W4Q_SOFF_MUL 1
-#endif
 template <int EPI, int NW16, bool TRACE = false, bool GROUPED = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     constexpr int PD = LT_W4Q_PD;
@@ -952,6 +947,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     // staging: wave w copies pieces w + 4 i; piece q < PA = A rows 16 q .., else W rows 16 (q - PA) ..; lane -> row lane >> 2, 16-byte
     // position lane & 3, fetched from source chunk pos ^ (3 * ((row >> 3) & 1))
     const int sswz = ((lane & 3) ^ (((lane >> 5) & 1) * 3)) * 16;
+    const bool pair = !GROUPED && p.pair_ab != 0;
+    const int psh = pair ? 1 : 0;  // a slab's step along K in bytes: 64 << psh
     static_assert(IP <= 9, "staging slots per wave");
     int voff[9], ldsoff[9];  // fixed size: a dependent bound here breaks host-side substitution (hipcc 7.2)
 #pragma unroll
@@ -960,14 +957,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         if (q >= NP) q -= NW;
         const bool isA = i < PA / NW;
         const int r0 = 16 * (isA ? q : q - PA) + (lane >> 2);
-#ifdef LT_W4Q_PAIRLINE
-        // TIMING PROBE ONLY (round 6; results are garbage on row-major operands): the addresses the stream would issue if A and W were stored
-        // row-pair-interleaved per 32-deep K chunk ([rows / 2][K / 32][2][32]) - a pair of rows' 64-byte slab pieces = ONE 128-byte line, so an
-        // LDS-DMA instruction touches 8 whole lines instead of 16 half lines; the LDS image is the same
-        voff[i] = (r0 >> 1) * (isA ? p.lda : p.ldw) * 4 + (r0 & 1) * 64 + sswz;
-#else
-        voff[i] = r0 * (isA ? p.lda : p.ldw) * 2 + sswz;
-#endif
+        // GemmArgs::pair_ab (round 6): A and W are stored row-pair-interleaved per 32-deep K chunk ([rows / 2][K / 32][2][32]: the two rows'
+        // 64-byte slab pieces side by side = ONE 128-byte line), so an LDS-DMA instruction touches 8 whole lines instead of 16 half lines -
+        // half the requests into the L2 for the same bytes; the LDS image, the fragment reads and the arithmetic are the same
+        voff[i] = pair ? (r0 >> 1) * (isA ? p.lda : p.ldw) * 4 + (r0 & 1) * 64 + sswz : r0 * (isA ? p.lda : p.ldw) * 2 + sswz;
         ldsoff[i] = q * 1024;
     }
     const int ncols_out = EPI == 1 ? p.N / 2 : p.N;
@@ -1069,7 +1062,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         const int soff = (TSPLIT ? kbeg_of(t.part) : 0) + slab_in_tile * 64;
 #pragma unroll
         for (int i = 0; i < IP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, i < NGA ? ga[i] : voff[i], soff * LT_W4Q_SOFF_MUL, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, i < NGA ? ga[i] : voff[i], soff << psh, 0, 0);
     };
     stagger_start(p.stagger);
     // prologue (once per workgroup): slabs 0..2 in flight, slab 0 read into the first fragment set, slab 1 landed and visible
@@ -1109,6 +1102,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         constexpr bool FIRST = decltype(first_tag)::value, SWAP = decltype(swap_tag)::value;
         const char* sb = smem + rd_off;
         char* db = smem + wr_off;
+        const int d_soff_b = d_soff << psh;  // (pair layout: 128 bytes per slab)
         int n_rd = rd_off, n_wr = wr_off, n_soff = d_soff, n_kend = d_kend;
         __amdgpu_buffer_rsrc_t nA = dA, nW = dW;
         int n_ga[NGA];
@@ -1139,7 +1133,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             }
             if (i % EVERY == EVERY / 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(i / EVERY < PA / NW ? (GROUPED ? gA : dA) : dW, LDS_PTR(db + ldsoff[i / EVERY]), 16,
-                                                         i / EVERY < NGA ? ga[i / EVERY < NGA ? i / EVERY : 0] : voff[i / EVERY], d_soff * LT_W4Q_SOFF_MUL, 0, 0);
+                                                         i / EVERY < NGA ? ga[i / EVERY < NGA ? i / EVERY : 0] : voff[i / EVERY], d_soff_b, 0, 0);
             // the next body's scalar state, a few instructions under each of the last MFMAs
             if (i == NM - 4) { n_rd = rd_off + SLAB; n_rd = n_rd == 4 * SLAB ? 0 : n_rd; }
             if (i == NM - 3) { n_wr = wr_off + SLAB; n_wr = n_wr == 4 * SLAB ? 0 : n_wr; n_soff = d_soff + 64; }
@@ -1208,6 +1202,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int row_off = (wm * (MT * 16) + mt * 16 + l15) * p.ldc * 2;  // bytes from the tile's first C row (< 2^31: launcher)
+            const int row_off_pc = ((wm * (MT * 16) + mt * 16 + l15) >> 1) * p.ldc * 4 + (l15 & 1) * 64;  // ... in the pair layout (tiles start on even rows)
             st1[mt] = 0.f; st2[mt] = 0.f;
             if constexpr (EPI != 1) {
 #pragma unroll
@@ -1249,7 +1244,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
                     auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
                     const int col = nbase / 2 + j * 32 + (q4 & 1) * 16 + (q4 >> 1) * 8;
                     const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                    const int off = col < ncols_out ? row_off + col * 2 : (int)0x80000000u;
+                    // GemmArgs::pair_c: the output (the W2 projection's A operand) in the row-pair-interleaved layout
+                    const int cb = p.pair_c ? row_off_pc + col * 2 + (col >> 5) * 64 : row_off + col * 2;
+                    const int off = col < ncols_out ? cb : (int)0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b128(o, rC, off, 0, 0);
                 }
             }

@@ -42,6 +42,11 @@ struct GemmArgs {
     // qstat_cols (= the Q width) adds, per row and per wave column-half, (sum, sum of squares) of its bf16-ROUNDED outputs to
     // qstat[row][slot] with slot = 2 * (n0 / BN) + wn  (float2; qstat_slots = 2 * qstat_cols / BN per row).  The attention kernel's
     // prologue reduces the slots to the row's mean / rstd and applies q_norm + RoPE itself (AttnArgs::q_raw): Q is never re-written.
+    // round 6, persistent dense kernel only (gemm_runs_w4q_dense): A and W in the ROW-PAIR-INTERLEAVED layout - element (r, k) of a
+    // [rows][ld] matrix at (r >> 1) * 2 * ld + (k >> 5) * 64 + (r & 1) * 32 + (k & 31): the 64-byte pieces a 32-deep slab takes from rows 2 i and
+    // 2 i + 1 are one 128-byte line (launch_pair_layout converts in place; rows even, K % 32 == 0).  pair_c: epilogue 1 writes its output
+    // (ldc = N / 2 columns) in that layout.  The products and their order do not depend on it: results are bit-identical.
+    int pair_ab = 0, pair_c = 0;
     float* qstat = nullptr;
     int qstat_cols = 0, qstat_slots = 0;
     // round 5 (small-M tiles of gemm_bf16_pp, plain epilogue): rowstat[row][column tile of 128] = (sum, sum of squares) of that tile's
@@ -95,6 +100,7 @@ struct NormModArgs {
     float eps;
     int scale_pre = 0;  // 1: `scale` already holds bf16(1 + scale) (engine: prepared once per NFE by launch_prep_mod)
     int apex = 0;       // set by the launcher from option rmsnorm_apex: the weight multiplies in fp32 before the one rounding
+    int out_pair = 0;   // `out` in the row-pair-interleaved layout (GemmArgs::pair_ab: it is a persistent GEMM's A operand); rows even, d % 32 == 0
 };
 int launch_rmsnorm_mod(const NormModArgs& a, hipStream_t stream);
 
@@ -132,6 +138,7 @@ struct GatedResArgs {
     // launch resident at once) instead of "load the row, reduce, apply".  Ignored (the kernel reduces y itself) by every other combination.
     const float* ystat = nullptr;
     int ystat_slots = 0;
+    int h_pair = 0;  // next_mode 1: `h` in the row-pair-interleaved layout (GemmArgs::pair_ab); rows even, d % 32 == 0
 };
 int launch_gated_residual_norm(const GatedResArgs& a, hipStream_t stream);
 
@@ -203,6 +210,7 @@ struct AttnArgs {
     int tail_split = 0, tail_rows = 0;
     float* tail_ws = nullptr;
     size_t tail_ws_bytes = 0;
+    int out_pair = 0;  // one-wave kernels: `out` ([B * N][H * hd]) in the row-pair-interleaved layout (the O projection's A operand, GemmArgs::pair_ab)
     unsigned long long* trace = nullptr;  // diagnostics only (lt_op_attention_trace)
     // round 4 (attn_fwd_kernel_v4<72> only; attention_takes_raw_q() says whether a call qualifies): q == nullptr and the workgroup
     // makes its 256 query rows itself from the QKV projection's row-major output - q_norm (full-width affine LayerNorm in fp32; the
@@ -255,9 +263,11 @@ int launch_attention_v4(const AttnArgs& a, hipStream_t stream);  // hd 72, 4 wav
 int launch_attention_v4_hd48(const AttnArgs& a, hipStream_t stream);  // hd 48, the same structure, softmax-bound (attention_v4_48.hip)
 int launch_attention_v4_hd96(const AttnArgs& a, hipStream_t stream);  // hd 96, the same structure without pad slots (attention_v4_96.hip)
 size_t attention_tail_ws_floats(int heads, int parts, int rows);  // AttnArgs::tail_ws of launch_attention_v4_hd96's tail split, in floats
+bool attention_is_one_wave(const AttnArgs& a);  // launch_attention would run this call on a one-wave-per-SIMD kernel (hd 72 / 48 / 96): these write AttnArgs::out_pair
 bool attention_takes_raw_q(const AttnArgs& a);  // launch_attention would run this call on attn_fwd_kernel_v4<72> (the kernel with the q_raw prologue)
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
 int ensure_dynamic_lds(const void* fn, int bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) per (device, kernel), raised whenever a larger size is asked for; records the pair only on success
+bool gemm_runs_w4q_dense(const GemmArgs& a, int epilogue);  // launch_gemm_bf16 would run this (variant 0) call on the persistent dense kernel, the one that reads the pair layout
 const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant);  // name of the kernel launch_gemm_bf16 would run
 
 // ---- mixture-of-experts routing (moe.hip; Next-DiT-MoE/models/models2.py:451-506) --------------------------------
@@ -343,3 +353,5 @@ int launch_rope_table_2d(float* out, int len, int hd, float theta, float scale_f
 int launch_rope_table(float* out, int len, int hd, int step, float theta0, float lin0, float theta1, float lin1,
                       int lin_on_pos, hipStream_t stream, float* out_t = nullptr);  // out_t: the same as [b][fi][pos]
 int launch_fill_rows_bf16(u16* dst, const u16* row, long long rows, int d, hipStream_t stream);
+// in-place conversion of a dense [rows][cols] bf16 matrix to (to_pair 1) / from (0) the row-pair-interleaved layout of GemmArgs::pair_ab
+int launch_pair_layout(u16* m, long long rows, int cols, int to_pair, hipStream_t stream);

@@ -560,6 +560,42 @@ int launch_label_gather(const u16* table, const int32_t* labels, u16* out, int B
     return 0;
 }
 
+// ---- row-pair-interleaved layout (GemmArgs::pair_ab, round 6) -------------------------------------------------------------------------
+// In place, one workgroup per pair of rows of a dense [rows][cols] matrix: element (r, k) <-> (r >> 1) * 2 cols + (k >> 5) * 64 + (r & 1) * 32 +
+// (k & 31).  A 16-byte chunk c of row rr sits at chunk rr * (cols / 8) + c of the pair's row-major image and at chunk (c >> 2) * 8 + rr * 4 +
+// (c & 3) of its interleaved one.  The whole pair is read into registers before the first store (cols <= 16384: 16 chunks per thread).
+namespace {
+__global__ __launch_bounds__(256) void pair_layout_kernel(u16* __restrict__ m, int cols, int to_pair) {
+    u16* base = m + (size_t)blockIdx.x * 2 * cols;
+    const int cpr = cols >> 3, n = 2 * cpr;
+    bf8_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < n) v[i] = *(const bf8_t*)(base + (size_t)c * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = threadIdx.x + 256 * i;  // chunk index in the SOURCE image
+        if (c < n) {
+            int dst;
+            if (to_pair) { const int rr = c >= cpr ? 1 : 0, cc = c - rr * cpr; dst = (cc >> 2) * 8 + rr * 4 + (cc & 3); }
+            else { const int rr = (c >> 2) & 1, cc = (c >> 3) * 4 + (c & 3); dst = rr * cpr + cc; }
+            *(bf8_t*)(base + (size_t)dst * 8) = v[i];
+        }
+    }
+}
+}  // namespace
+
+int launch_pair_layout(u16* m, long long rows, int cols, int to_pair, hipStream_t stream) {
+    LT_REQUIRE(m && rows > 0 && rows % 2 == 0 && cols > 0 && cols % 32 == 0 && cols <= 16384 && rows / 2 < 0x7fffffffLL,
+               "pair_layout: an even number of rows of 32 k <= 16384 columns (got %lld x %d)", rows, cols);
+    hipLaunchKernelGGL(pair_layout_kernel, dim3((unsigned)(rows / 2)), dim3(256), 0, stream, m, cols, to_pair);
+    LT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_fill_rows_bf16(u16* dst, const u16* row, long long rows, int d, hipStream_t stream) {
     int g = nblk(rows * d, 256);
     if (g > 8192) g = 8192;

@@ -60,7 +60,7 @@ __device__ __forceinline__ float row_sumsq(const RowRaw<MAXCH>& r) {
 template <int MAXCH>
 __device__ __forceinline__ void apply_rms_mod_store(const RowRaw<MAXCH>& r, float rinv, const u16* w, const u16* scale,
                                                     const u16* shift, int scale_pre, u16* out, int nch, int lane, int apex = 0,
-                                                    const u16* route_w = nullptr, int route_E = 0, int d = 0, float* route_acc = nullptr) {
+                                                    const u16* route_w = nullptr, int route_E = 0, int d = 0, float* route_acc = nullptr, int pair = 0) {
     const f32x2 rv = {rinv, rinv};
     const f32x2 one = {1.f, 1.f};
 #pragma unroll
@@ -79,7 +79,7 @@ __device__ __forceinline__ void apply_rms_mod_store(const RowRaw<MAXCH>& r, floa
                 if (shift) n = bfr2(n) + unpk_bf(hv.w[k]);
                 o.w[k] = pk_bf(n);
             }
-            *(bf8_t*)(out + ch * 8) = o;
+            *(bf8_t*)(out + ch * 8 + (pair ? (ch >> 2) * 32 : 0)) = o;  // (pair: `out` = the row's base in the row-pair-interleaved layout)
             if (route_w) {  // (a literal nullptr from every instantiation but the MoE ones: folds away)
                 float (&ra)[LT_MOE_MAX_E] = *reinterpret_cast<float (*)[LT_MOE_MAX_E]>(route_acc);
                 route_accumulate(o, route_w, route_E, d, ch, ra);
@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(NormModArgs p) {
     load_row(p.x + (size_t)row * p.d, nch, lane, r);
     const float rinv = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
     apply_rms_mod_store(r, rinv, p.w, p.scale ? p.scale + (size_t)b * p.ld_mod : nullptr,
-                        p.shift ? p.shift + (size_t)b * p.ld_mod : nullptr, p.scale_pre, p.out + (size_t)row * p.d, nch, lane, p.apex);
+                        p.shift ? p.shift + (size_t)b * p.ld_mod : nullptr, p.scale_pre,
+                        p.out_pair ? p.out + (size_t)(row >> 1) * (2 * p.d) + (row & 1) * 32 : p.out + (size_t)row * p.d, nch, lane, p.apex, nullptr, 0, 0, nullptr,
+                        p.out_pair);
 }
 
 // PM / GM / NM >= 0: post_mode / gate_mode / next_mode fixed at compile time (the engine's combinations; selected by
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
     if (next_mode == 0) return;
     const u16* nscale = p.next_scale ? p.next_scale + (size_t)b * p.ld_mod : nullptr;
     const u16* nshift = p.next_shift ? p.next_shift + (size_t)b * p.ld_mod : nullptr;
-    u16* hrow = p.h + (size_t)row * p.d;
+    const int hp = next_mode == 1 ? p.h_pair : 0;
+    u16* hrow = hp ? p.h + (size_t)(row >> 1) * (2 * p.d) + (row & 1) * 32 : p.h + (size_t)row * p.d;
     if (next_mode == 1) {
         const float r2 = rsqrtf(row_sumsq(r) / (float)p.d + p.eps);
         if constexpr (MOE) {
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256) void gated_residual_norm_kernel(GatedResArgs p
                 return;
             }
         }
-        apply_rms_mod_store(r, r2, p.next_w, nscale, nshift, p.scale_pre, hrow, nch, lane, apex);
+        apply_rms_mod_store(r, r2, p.next_w, nscale, nshift, p.scale_pre, hrow, nch, lane, apex, nullptr, 0, 0, nullptr, hp);
     } else {
         // affine-free LayerNorm in fp32, modulate in fp32, one rounding (the cast autocast applies at the
         // final Linear) -- model.py:634-638, :660-661
@@ -322,7 +325,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RPW == 1 ? 
             }
         const float r2 = rsqrtf(wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) / (float)p.d + p.eps);
         const f32x2 r2v = {r2, r2};
-        u16* hrow = p.h + (size_t)row * p.d + lane * 4;
+        // (h_pair: column c = 4 lane + 256 i of row `row` sits at (row >> 1) * 2 d + (row & 1) * 32 + c + (c >> 5) * 32)
+        u16* hrow = p.h_pair ? p.h + (size_t)(row >> 1) * (2 * p.d) + (row & 1) * 32 + lane * 4 + (lane >> 3) * 32 : p.h + (size_t)row * p.d + lane * 4;
+        const int hstep = p.h_pair ? 512 : 256;
         // h = bfr(bfr(bfr(x' * r2) * w) * (1 + scale)) with (1 + scale) prepared in bf16: apply_rms_mod_store, 8 bytes at a time
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RPW == 1 ? 
             if (i + 1 < NH) { wn = *(const nt_u32x2*)(nw + 256 * (i + 1)); sn = *(const nt_u32x2*)(nscale + 256 * (i + 1)); }
 #pragma unroll
             for (int k = 0; k < 2; ++k) o[k] = pk_bf(bfr2(bfr2(unpk_bf(xv[r][i][k]) * r2v) * unpk_bf(w2[k])) * unpk_bf(s2[k]));
-            *(nt_u32x2*)(hrow + 256 * i) = o;
+            *(nt_u32x2*)(hrow + hstep * i) = o;
             w2 = wn; s2 = sn;
         }
     }
@@ -356,6 +361,7 @@ int launch_rmsnorm_mod(const NormModArgs& a_in, hipStream_t stream) {
     a.apex = lt_opt(OPT_RMSNORM_APEX);
     LT_REQUIRE(a.d % 8 == 0 && a.d <= 64 * 8 * MAXCH_LIMIT, "rmsnorm_mod: d=%d must be a multiple of 8 and <= 4096", a.d);
     LT_REQUIRE(a.rows_per_batch > 0 && a.rows > 0, "rmsnorm_mod: empty input");
+    LT_REQUIRE(!a.out_pair || (a.rows % 2 == 0 && a.d % 32 == 0), "rmsnorm_mod: the pair layout needs an even row count and d %% 32 == 0");
     LT_DISPATCH_CHUNKS(rmsnorm_mod_kernel, dim3((a.rows + 3) / 4), a);
     LT_CHECK_HIP(hipGetLastError());
     return 0;
@@ -370,6 +376,7 @@ int launch_gated_residual_norm(const GatedResArgs& a_in, hipStream_t stream) {
     LT_REQUIRE(a.y != nullptr || a.moe_pos != nullptr, "gated_residual_norm: branch output missing");
     LT_REQUIRE(a.post_mode == 0 || a.post_w != nullptr, "gated_residual_norm: post-norm weight missing");
     LT_REQUIRE(a.next_mode == 0 || a.h != nullptr, "gated_residual_norm: h output missing");
+    LT_REQUIRE(!a.h_pair || (a.next_mode == 1 && !a.moe_pos && a.rows % 2 == 0 && a.d % 32 == 0), "gated_residual_norm: h in the pair layout: dense next_mode 1, even row count, d %% 32 == 0");
     LT_REQUIRE(a.route_w == nullptr || (a.moe_pos && a.next_mode == 1 && a.route_sel && a.route_wts && a.route_E >= 2 && a.route_E <= LT_MOE_MAX_E),
                "gated_residual_norm: routing on the way out needs the MoE kernel, next_mode 1, 2 <= E <= %d and the sel / wts outputs", LT_MOE_MAX_E);
     int nblk = (a.rows + 3) / 4;

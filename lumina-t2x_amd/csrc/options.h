@@ -14,7 +14,7 @@ enum LtOpt {
     OPT_GRAPH = 0, OPT_ATTENTION_VARIANT, OPT_QKV_POST_FUSED, OPT_QKV_VT_EPILOGUE, OPT_QKV_FUSED_GEMM, OPT_QK_POST_PAIR, OPT_ATTN_Q_FUSED,
     OPT_NORM_SPECIALIZE, OPT_GEMM_W4Q, OPT_GEMM_PREFETCH, OPT_GEMM_SPLITK, OPT_GEMM_W4Q_GROUPED, OPT_GEMM_GROUP, OPT_GEMM_STAGGER,
     OPT_GEMM_VARIANT, OPT_RMSNORM_APEX, OPT_ATTN_SMALL_FUSED, OPT_MOE_ROUTE_FUSED, OPT_GEMM_SPLITK4, OPT_MOE_TIME_PLAN_HOIST,
-    OPT_GRN_YSTAT, OPT_QK_WG_PER_CU, OPT_PROLOGUE_FUSED, OPT_GEMM_TAIL_SPLIT, OPT_ATTN_TEXT_SKIP, OPT_ATTN_TAIL_SPLIT,
+    OPT_GRN_YSTAT, OPT_QK_WG_PER_CU, OPT_PROLOGUE_FUSED, OPT_GEMM_TAIL_SPLIT, OPT_ATTN_TEXT_SKIP, OPT_ATTN_TAIL_SPLIT, OPT_PAIR_LAYOUT,
     LT_OPT_COUNT
 };
 constexpr int LT_OPT_INHERIT = INT_MIN;  // per-engine slot: no override

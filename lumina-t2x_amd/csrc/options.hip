@@ -34,6 +34,7 @@ const LtOptDesc kLtOptDesc[LT_OPT_COUNT] = {
     {"gemm_tail_split", 0, 2, 0, false},
     {"attn_text_skip", 0, 1, 1, true},
     {"attn_tail_split", 0, 4, 4, false},
+    {"pair_layout", 0, 1, 1, true},
 };
 
 namespace {

@@ -1023,6 +1023,55 @@ def test_attention_v4_fused_text_is_bit_identical_to_v3(B, H, Hkv, N, T, valid1)
     assert torch.equal(outs[0], outs[1]), rel_l2(outs[1], outs[0])
 
 
+def _to_pair_ref(m):
+    """row-pair-interleaved image of a [rows][cols] matrix (include/lumina_dit.h): (r, k) -> (r >> 1) * 2 cols + (k >> 5) * 64 + (r & 1) * 32 + (k & 31)"""
+    rows, cols = m.shape
+    return m.view(rows // 2, 2, cols // 32, 32).permute(0, 2, 1, 3).reshape(rows, cols).contiguous()
+
+
+@pytest.mark.parametrize("rows,cols", [(2, 32), (6, 2304), (256, 6144), (12288, 2304), (8320, 3072), (64, 16384)])
+def test_pair_layout_in_place_conversion(rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    m = bf(torch.randn(rows, cols, generator=g))
+    buf = torch.full((rows * cols + 64,), 7.0, device="cuda", dtype=torch.bfloat16)
+    w = buf[:rows * cols].view(rows, cols)
+    w.copy_(m)
+    ok(lib().lt_op_pair_layout(P(w), rows, cols, 1, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(w, _to_pair_ref(m))
+    ok(lib().lt_op_pair_layout(P(w), rows, cols, 0, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(w, m) and torch.all(buf[rows * cols:] == 7.0)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(8192, 2304, 2304, 0), (8192, 2304, 6144, 0), (8192, 12288, 2304, 1), (8192, 6912, 2304, 0), (8320, 3072, 3072, 0),
+                                       (8320, 16384, 3072, 1), (8190, 2304, 2304, 0), (16384, 12288, 2304, 1)])
+def test_gemm_pair_layout_is_bit_identical(M, N, K, epi):
+    """round 6: the persistent GEMM reading A and W in the row-pair-interleaved layout (whole 128-byte lines per LDS-DMA request) multiplies
+    the same slabs in the same order as on row-major operands - outputs equal bit for bit; with the SwiGLU epilogue the output can be
+    written in the pair layout too (it is the W2 projection's A operand)"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    No = N // 2 if epi else N
+    ref = torch.full((M, No), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ok(lib().lt_op_gemm_bf16(P(A), P(W), P(None), 1, P(ref), M, N, K, epi, 0, stream()), "gemm")
+    Ap, Wp = A.clone(), W.clone()
+    ok(lib().lt_op_pair_layout(P(Ap), M, K, 1, stream()))
+    ok(lib().lt_op_pair_layout(P(Wp), N, K, 1, stream()))
+    for pair_c in ((0, 1) if epi else (0,)):
+        buf = torch.full((M * No + 64,), float("nan"), device="cuda", dtype=torch.bfloat16)
+        out = buf[:M * No].view(M, No)
+        buf[M * No:] = 7.0
+        ok(lib().lt_op_gemm_bf16_pair(P(Ap), P(Wp), P(out), M, N, K, epi, pair_c, stream()), "gemm pair")
+        if pair_c:
+            ok(lib().lt_op_pair_layout(P(out), M, No, 0, stream()))
+        torch.cuda.synchronize()
+        assert torch.all(buf[M * No:] == 7.0)
+        assert not torch.isnan(out.float()).any()
+        assert torch.equal(out, ref), (pair_c, rel_l2(out, ref))
+
+
 def _fused_text_inputs(B, H, Hkv, N, T, valid, hd, seed):
     """inputs of lt_op_attention_fused as the engine hands them over (both K pre-scaled); valid[b] = valid text keys of sample b"""
     g = torch.Generator().manual_seed(seed)
