@@ -18,7 +18,16 @@ A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
 W = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 s = torch.cuda.current_stream().cuda_stream
-for _ in range(6):
+PAIR = os.environ.get("LT_PMC_PAIR", "0") == "1"  # round 6: A and W in the row-pair-interleaved layout (whole-line requests), same kernel
+if PAIR:
+    _lib.check(lib.lt_op_pair_layout(C.c_void_p(A.data_ptr()), M, K, 1, C.c_void_p(s)), "pair A")
+    _lib.check(lib.lt_op_pair_layout(C.c_void_p(W.data_ptr()), N, K, 1, C.c_void_p(s)), "pair W")
+for _ in range(6 if PAIR else 0):
+    _lib.check(lib.lt_op_gemm_bf16_pair(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()), M, N, K, 0, 0, C.c_void_p(s)), "lt_op_gemm_bf16_pair")
+if PAIR:
+    _lib.check(lib.lt_op_pair_layout(C.c_void_p(A.data_ptr()), M, K, 0, C.c_void_p(s)), "unpair A")
+    _lib.check(lib.lt_op_pair_layout(C.c_void_p(W.data_ptr()), N, K, 0, C.c_void_p(s)), "unpair W")
+for _ in range(0 if PAIR else 6):
     _lib.check(lib.lt_op_gemm_bf16(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(None), 1, C.c_void_p(out.data_ptr()), M, N, K, 0, VAR, C.c_void_p(s)), "lt_op_gemm_bf16")
 for _ in range(6 if os.environ.get("LT_PMC_VENDOR", "1") == "1" else 0):
     torch.matmul(A, W.t(), out=out)

@@ -659,6 +659,22 @@ def test_pair_layout_is_bit_identical_and_survives_a_change_of_regime():
     for i in (1, 2, 3, 5, 8):
         assert torch.equal(outs[1][i], outs[1][0]), i
     assert torch.equal(outs[1][6], outs[1][4]) and torch.equal(outs[1][7], outs[1][4])
+    # the weights are in the pair layout now (the last call was a large one): an upload converts them back first, and the next large
+    # evaluation converts the NEW weights again
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda", torch.bfloat16)
+    assert torch.equal(small(), outs[1][4])
+    assert torch.equal(big(), outs[1][0])
+    sd2 = {k: (v * 1.5 if k.endswith("attention.wo.weight") else v) for k, v in sd.items()}
+    model.load_state_dict(sd2, strict=True)
+    model = model.to("cuda", torch.bfloat16)
+    changed = big()
+    assert torch.isfinite(changed.float()).all() and not torch.equal(changed, outs[1][0])
+    set_option("pair_layout", 0)
+    try:
+        assert torch.equal(big(), changed)
+    finally:
+        set_option("pair_layout", 1)
 
 
 @pytest.mark.parametrize("opt", ["qk_post_pair", "qkv_vt_epilogue", "qkv_fused_gemm", "gemm_w4q", "norm_specialize", "attn_q_fused"])
