@@ -423,7 +423,8 @@ int ensure_rope(lt_engine* e, const lt_step_args* a, hipStream_t s) {
 // one MoE feed-forward (branch 0 = TimeMoeLayer on the timestep embedding, 1 = SpaceMoeLayer on the tokens;
 // models2.py:451-506): e->h -> e->o
 // routed: sel / wts of this (token-routed) branch were already written by the row kernel that produced its input (GatedResArgs::route_*)
-int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B, hipStream_t s, bool routed = false) {
+// pair: the experts' weights are in the pair layout (run_forward decided; ensure_weight_layout), and so is the SwiGLU output e->moe_us
+int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B, hipStream_t s, bool routed = false, bool pair = false) {
     const int d = e->d, F = e->F;
     MoeArgs m;
     m.x = e->h; m.rows = M; m.rows_per_sample = N; m.d = d; m.E = e->E;
@@ -467,6 +468,7 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
         // (A = the un-sorted FFN input: the GEMM gathers its rows through the plan's inverse map, no expert-sorted copy)
         g.A = e->h; g.a_row_map = m.src; g.a_map_rows = M; g.W = branch == 0 ? w.w13_t : w.w13_s; g.C = e->moe_us; g.M = P; g.N = 2 * F; g.K = d;
         g.lda = d; g.ldw = d; g.ldc = F; g.w_expert_stride = (long long)2 * F * d;
+        g.pair_ab = pair ? 2 : 0; g.pair_c = pair;  // (A is gathered row by row from e->h: row-major)
         ProfScope ps(e, 0, 2.0 * (2.0 * M) * (2.0 * F) * d, s, true);  // algorithmic: every token visits two experts
         if (launch_gemm_bf16(g, 1, 0, s, ps.ev0(), ps.ev1())) return 1;
     }
@@ -474,6 +476,7 @@ int moe_ffn(lt_engine* e, LayerW& w, int layer, int branch, int M, int N, int B,
         g.A = e->moe_us; g.a_row_map = nullptr; g.a_map_rows = 0; g.W = branch == 0 ? w.w2_t : w.w2_s; g.C = e->moe_ys; g.M = P; g.N = d; g.K = F;
         if (lt_opt(OPT_GEMM_TAIL_SPLIT) && e->tail_part) { g.tail_part = e->tail_part; g.tail_cnt = e->tail_cnt; g.tail_cap_parts = e->tail_cap_parts; g.tail_max_parts = lt_opt(OPT_GEMM_TAIL_SPLIT) == 2 ? 2 : 4; }
         g.lda = F; g.ldw = F; g.ldc = d; g.w_expert_stride = (long long)d * F;
+        g.pair_ab = pair ? 3 : 0; g.pair_c = 0;
         ProfScope ps(e, 0, 2.0 * (2.0 * M) * (double)d * F, s, true);
         if (launch_gemm_bf16(g, 0, 0, s, ps.ev0(), ps.ev1())) return 1;
     }
@@ -509,13 +512,17 @@ struct PackedDesc {
 // all four GEMM weights of every dense block -> the row-pair-interleaved layout (want) or back to row-major, in place, on stream s
 int ensure_weight_layout(lt_engine* e, bool want, hipStream_t s) {
     if (e->w_pair == want) return 0;
-    LT_REQUIRE(e->E == 0, "pair layout: dense blocks only");
     for (int l = 0; l < e->L; ++l) {
         LayerW& w = e->lw[l];
-        if (launch_pair_layout(w.wqkv, e->qkvn, e->d, want, s)) return 1;
-        if (launch_pair_layout(w.wo, e->d, e->d, want, s)) return 1;
-        if (launch_pair_layout(w.w13, 2LL * e->F, e->d, want, s)) return 1;
-        if (launch_pair_layout(w.w2, e->d, e->F, want, s)) return 1;
+        if (e->E == 0) {
+            if (launch_pair_layout(w.wqkv, e->qkvn, e->d, want, s)) return 1;
+            if (launch_pair_layout(w.wo, e->d, e->d, want, s)) return 1;
+            if (launch_pair_layout(w.w13, 2LL * e->F, e->d, want, s)) return 1;
+            if (launch_pair_layout(w.w2, e->d, e->F, want, s)) return 1;
+        } else {  // MoE families: the experts' weights only ([E][2 F][d] / [E][d][F]: an expert's rows are an even count, pairs stay inside it)
+            for (u16* w13 : {w.w13_t, w.w13_s}) if (w13 && launch_pair_layout(w13, 2LL * e->E * e->F, e->d, want, s)) return 1;
+            for (u16* w2 : {w.w2_t, w.w2_s}) if (w2 && launch_pair_layout(w2, (long long)e->E * e->d, e->F, want, s)) return 1;
+        }
     }
     e->w_pair = want;
     return 0;
@@ -667,19 +674,35 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         pair = vt_epi0 && lt_opt(OPT_QKV_FUSED_GEMM) && gemm_qkv_fusable(gq) && gemm_runs_w4q_dense(go, 0) && gemm_runs_w4q_dense(g13, 1) &&
                gemm_runs_w4q_dense(g2, 0) && attention_is_one_wave(at0);
     }
-    if (e->w_pair != pair) {
+    // the MoE families: the experts' grouped GEMMs on the persistent kernel (>= 1.5 tiles per CU: the 600M MoE at 1024^2) read their weights in the
+    // pair layout, and the SwiGLU output between the two (e->moe_us) is written / read in it; the W1 | W3 launch gathers its A rows one by one
+    // from e->h, which stays row-major (a gathered row's line mate is not its neighbour in the tile)
+    bool pair_moe = false;
+    if (lt_opt(OPT_PAIR_LAYOUT) && e->E > 0 && d % 32 == 0 && F % 32 == 0 && F <= 16384 && d <= 16384) {
+        const int tiles = (int)((2 * (size_t)M + (size_t)e->E * 255 + 255) / 256);
+        GemmArgs g13, g2;
+        g13.bias = nullptr; g13.bias_dtype = -1; g13.tile_expert = e->moe_tile_expert;
+        g13.A = e->h; g13.a_row_map = e->moe_src; g13.a_map_rows = M; g13.W = e->lw[0].w13_t ? e->lw[0].w13_t : e->lw[0].w13_s; g13.C = e->moe_us;
+        g13.M = tiles * 256; g13.N = 2 * F; g13.K = d; g13.lda = d; g13.ldw = d; g13.ldc = F; g13.w_expert_stride = (long long)2 * F * d;
+        g2 = g13;
+        g2.A = e->moe_us; g2.a_row_map = nullptr; g2.a_map_rows = 0; g2.W = e->lw[0].w2_t ? e->lw[0].w2_t : e->lw[0].w2_s; g2.C = e->moe_ys;
+        g2.N = d; g2.K = F; g2.lda = F; g2.ldw = F; g2.ldc = d; g2.w_expert_stride = (long long)d * F;
+        pair_moe = gemm_runs_w4q_grouped(g13, 1) && gemm_runs_w4q_grouped(g2, 0);
+    }
+    const bool pair_any = pair || pair_moe;
+    if (e->w_pair != pair_any) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
         if (cs == hipStreamCaptureStatusNone) {
-            if (ensure_weight_layout(e, pair, s)) return 1;
+            if (ensure_weight_layout(e, pair_any, s)) return 1;
         } else {
             // inside a capture (the caller's own graph) a layout change would be baked into every replay: run on the layout the weights are in
             LT_REQUIRE(!e->w_pair, "this evaluation runs on the small-M kernels, which read row-major weights, but the engine's weights are in the "
                                    "pair layout of the last large evaluation and the stream is capturing: run one eager evaluation of this shape first");
-            pair = false;
+            pair = false; pair_moe = false;
         }
     }
-    e->last_pair = pair;
+    e->last_pair = pair || pair_moe;
     // first pre-norm: modulate(attention_norm(x), [shift,] scale) (model.py:599 / models.py:785 / lumina_t2i model.py:600)
     {
         ProfScope ps(e, 2, 0, s);
@@ -743,7 +766,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             raw_q = lt_opt(OPT_ATTN_Q_FUSED) && c.qk_norm && !v.rope_1d && !pk && !regional && (fuse_text || !v.text) && attention_takes_raw_q(at) &&
                     bn > 0 && d % bn == 0 && 2 * d / bn <= 32;
             if (raw_q) { gq.qstat = e->qstat; gq.qstat_cols = d; gq.qstat_slots = 2 * d / bn; }
-            gq.pair_ab = pair;
+            gq.pair_ab = pair ? 3 : 0;
             ProfScope ps(e, 0, 2.0 * M * (double)(d + 2 * dkv) * d, s, true);
             if (launch_gemm_bf16(gq, 3, 0, s, ps.ev0(), ps.ev1())) return 1;
         } else if (vt_epi) {
@@ -811,7 +834,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
             if (attention(e, at, s)) return 1;
         }
         int ys_o = 0, ys_f = 0;
-        if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s, &ys_o, pair)) return 1;
+        if (gemm(e, e->attn, d, w.wo, d, e->o, d, M, d, d, nullptr, 0, s, &ys_o, pair ? 3 : 0)) return 1;
         {   // x += gate' * post(attn) ; h = pre_ffn(x) * (1 + scale) [+ shift]
             ProfScope ps(e, 2, 0, s);
             GatedResArgs g;
@@ -826,16 +849,16 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
         }
         const u16 *last_post_w, *last_gate;
         if (e->E == 0) {
-            if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s, nullptr, pair, pair)) return 1;
-            if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s, &ys_f, pair)) return 1;
+            if (gemm(e, e->h, d, w.w13, d, e->u, F, M, 2 * F, d, nullptr, 1, s, nullptr, pair ? 3 : 0, pair)) return 1;
+            if (gemm(e, e->u, F, w.w2, F, e->o, d, M, d, F, nullptr, 0, s, &ys_f, pair ? 3 : 0)) return 1;
             last_post_w = v.post ? w.ffn_norm2 : nullptr;
             last_gate = chunk(l, v.i_gate[1]);
         } else if (e->moe_mode != 0) {  // one MoE FFN in the ImageNet block (models.py:755-758: time-routed; models1.py: per token)
-            if (moe_ffn(e, w, l, e->moe_mode == 1 ? 0 : 1, M, N, B, s)) return 1;
+            if (moe_ffn(e, w, l, e->moe_mode == 1 ? 0 : 1, M, N, B, s, false, pair_moe)) return 1;
             last_post_w = w.ffn_norm2;
             last_gate = chunk(l, v.i_gate[1]);
         } else {  // time MoE -> residual -> space MoE (models2.py:793-800)
-            if (moe_ffn(e, w, l, 0, M, N, B, s)) return 1;
+            if (moe_ffn(e, w, l, 0, M, N, B, s, false, pair_moe)) return 1;
             {
                 ProfScope ps(e, 2, 0, s);
                 GatedResArgs g;
@@ -853,7 +876,7 @@ int run_forward(lt_engine* e, const void* x_in, const float* t_dev, void* out, c
                 }
                 if (launch_gated_residual_norm(g, s)) return 1;
             }
-            if (moe_ffn(e, w, l, 1, M, N, B, s, lt_opt(OPT_MOE_ROUTE_FUSED) != 0)) return 1;
+            if (moe_ffn(e, w, l, 1, M, N, B, s, lt_opt(OPT_MOE_ROUTE_FUSED) != 0, pair_moe)) return 1;
             last_post_w = w.norm_space;
             last_gate = chunk(l, 5);
         }
@@ -1702,7 +1725,7 @@ extern "C" int lt_op_gemm_bf16_pair(const void* A, const void* W, void* C, int32
     LT_REQUIRE(A && W && C, "lt_op_gemm_bf16_pair: null pointer");
     GemmArgs g;
     g.A = (const u16*)A; g.W = (const u16*)W; g.C = (u16*)C; g.bias = nullptr; g.M = M; g.N = N; g.K = K;
-    g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = -1; g.pair_ab = 1; g.pair_c = pair_c;
+    g.lda = K; g.ldw = K; g.ldc = epilogue == 1 ? N / 2 : N; g.bias_dtype = -1; g.pair_ab = 3; g.pair_c = pair_c;
     return launch_gemm_bf16(g, epilogue, 0, (hipStream_t)stream);
 }
 

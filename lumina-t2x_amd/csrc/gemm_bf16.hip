@@ -276,6 +276,10 @@ GemmPlan plan(const GemmArgs& a, int epilogue, int variant) {
 }  // namespace
 
 const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant) { return kGemmKernelName[plan(a, epilogue, variant).k]; }
+bool gemm_runs_w4q_grouped(const GemmArgs& a, int epilogue) {
+    const GemmKernel k = plan(a, epilogue, 0).k;
+    return k == GK_W4Q256_GROUPED || k == GK_W4Q256_SWIGLU_GROUPED;
+}
 bool gemm_runs_w4q_dense(const GemmArgs& a, int epilogue) {
     const GemmKernel k = plan(a, epilogue, 0).k;
     return k == GK_W4Q256 || k == GK_W4Q288 || k == GK_W4Q256_SWIGLU || k == GK_W4Q288_QKV || k == GK_W4Q256_QKV;
@@ -318,8 +322,10 @@ int launch_gemm_bf16(const GemmArgs& a0, int epilogue, int variant, hipStream_t 
         LT_REQUIRE(a.a_map_rows > 0 && (long long)a.a_map_rows * a.lda * 2 < 0x40000000LL, "gemm: a_row_map needs 0 < a_map_rows * lda * 2 < 2^30");
     }
     if (a.pair_ab || a.pair_c) {
-        LT_REQUIRE(k == GK_W4Q256 || k == GK_W4Q288 || k == GK_W4Q256_SWIGLU || k == GK_W4Q288_QKV || k == GK_W4Q256_QKV,
-                   "gemm: the row-pair-interleaved operand layout is read by the persistent dense kernel only (this problem runs %s)", kGemmKernelName[k]);
+        LT_REQUIRE(k == GK_W4Q256 || k == GK_W4Q288 || k == GK_W4Q256_SWIGLU || k == GK_W4Q288_QKV || k == GK_W4Q256_QKV || k == GK_W4Q256_GROUPED ||
+                   k == GK_W4Q256_SWIGLU_GROUPED,
+                   "gemm: the row-pair-interleaved operand layout is read by the persistent kernel only (this problem runs %s)", kGemmKernelName[k]);
+        LT_REQUIRE(!(a.pair_ab & 1) || !a.a_row_map, "gemm: a gathered A operand (a_row_map) cannot be in the pair layout");
         LT_REQUIRE(a.M % 2 == 0 && a.N % 2 == 0 && a.K % 32 == 0 && (!a.pair_c || (epilogue == 1 && a.ldc % 32 == 0)),
                    "gemm: pair layout needs even row counts, K %% 32 == 0 and (pair_c) the SwiGLU epilogue with ldc %% 32 == 0");
     }

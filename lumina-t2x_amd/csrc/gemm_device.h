@@ -947,8 +947,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
     // staging: wave w copies pieces w + 4 i; piece q < PA = A rows 16 q .., else W rows 16 (q - PA) ..; lane -> row lane >> 2, 16-byte
     // position lane & 3, fetched from source chunk pos ^ (3 * ((row >> 3) & 1))
     const int sswz = ((lane & 3) ^ (((lane >> 5) & 1) * 3)) * 16;
-    const bool pair = !GROUPED && p.pair_ab != 0;
-    const int psh = pair ? 1 : 0;  // a slab's step along K in bytes: 64 << psh
+    // pair_ab bit 0: A, bit 1: W in the pair layout (the dense engine path sets both; the grouped expert GEMMs: W always, A where it is not
+    // gathered row by row - a gathered row's line mate is not the next row of the tile)
+    const bool pair_a = (p.pair_ab & 1) != 0 && !(GROUPED && p.a_row_map != nullptr), pair_w = (p.pair_ab & 2) != 0;
+    const int psh_a = pair_a ? 1 : 0, psh_w = pair_w ? 1 : 0;  // a slab's step along K in bytes: 64 << psh
     static_assert(IP <= 9, "staging slots per wave");
     int voff[9], ldsoff[9];  // fixed size: a dependent bound here breaks host-side substitution (hipcc 7.2)
 #pragma unroll
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         // GemmArgs::pair_ab (round 6): A and W are stored row-pair-interleaved per 32-deep K chunk ([rows / 2][K / 32][2][32]: the two rows'
         // 64-byte slab pieces side by side = ONE 128-byte line), so an LDS-DMA instruction touches 8 whole lines instead of 16 half lines -
         // half the requests into the L2 for the same bytes; the LDS image, the fragment reads and the arithmetic are the same
-        voff[i] = pair ? (r0 >> 1) * (isA ? p.lda : p.ldw) * 4 + (r0 & 1) * 64 + sswz : r0 * (isA ? p.lda : p.ldw) * 2 + sswz;
+        voff[i] = (isA ? pair_a : pair_w) ? (r0 >> 1) * (isA ? p.lda : p.ldw) * 4 + (r0 & 1) * 64 + sswz : r0 * (isA ? p.lda : p.ldw) * 2 + sswz;
         ldsoff[i] = q * 1024;
     }
     const int ncols_out = EPI == 1 ? p.N / 2 : p.N;
@@ -1036,7 +1038,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         for (int i = 0; i < NGA; ++i) {
             const int r = 16 * (wave + NW * i) + (ln >> 2);
             const int src = t.c_bytes == 0 ? -1 : (map ? map[r] : t.m0 + r);  // the null tile behind the last one: every lane out of range
-            o[i] = (src >= 0 ? src * p.lda * 2 : 0x40000000) + swz;
+            o[i] = (src >= 0 ? (pair_a ? (src >> 1) * p.lda * 4 + (src & 1) * 64 : src * p.lda * 2) : 0x40000000) + swz;
         }
     };
     // GROUPED: ONE loop-invariant descriptor over all of A (< 2^30 bytes, launcher) - a descriptor carried from tile to tile ended up in
@@ -1062,7 +1064,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         const int soff = (TSPLIT ? kbeg_of(t.part) : 0) + slab_in_tile * 64;
 #pragma unroll
         for (int i = 0; i < IP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, i < NGA ? ga[i] : voff[i], soff << psh, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < PA / NW ? rA : rW, LDS_PTR(base + ldsoff[i]), 16, i < NGA ? ga[i] : voff[i], soff << (i < PA / NW ? psh_a : psh_w), 0, 0);
     };
     stagger_start(p.stagger);
     // prologue (once per workgroup): slabs 0..2 in flight, slab 0 read into the first fragment set, slab 1 landed and visible
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
         constexpr bool FIRST = decltype(first_tag)::value, SWAP = decltype(swap_tag)::value;
         const char* sb = smem + rd_off;
         char* db = smem + wr_off;
-        const int d_soff_b = d_soff << psh;  // (pair layout: 128 bytes per slab)
+        const int d_soff_a = d_soff << psh_a, d_soff_w = d_soff << psh_w;  // (pair layout: 128 bytes per slab)
         int n_rd = rd_off, n_wr = wr_off, n_soff = d_soff, n_kend = d_kend;
         __amdgpu_buffer_rsrc_t nA = dA, nW = dW;
         int n_ga[NGA];
@@ -1133,7 +1135,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4q(GemmArgs p) {
             }
             if (i % EVERY == EVERY / 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(i / EVERY < PA / NW ? (GROUPED ? gA : dA) : dW, LDS_PTR(db + ldsoff[i / EVERY]), 16,
-                                                         i / EVERY < NGA ? ga[i / EVERY < NGA ? i / EVERY : 0] : voff[i / EVERY], d_soff_b, 0, 0);
+                                                         i / EVERY < NGA ? ga[i / EVERY < NGA ? i / EVERY : 0] : voff[i / EVERY], i / EVERY < PA / NW ? d_soff_a : d_soff_w, 0, 0);
             // the next body's scalar state, a few instructions under each of the last MFMAs
             if (i == NM - 4) { n_rd = rd_off + SLAB; n_rd = n_rd == 4 * SLAB ? 0 : n_rd; }
             if (i == NM - 3) { n_wr = wr_off + SLAB; n_wr = n_wr == 4 * SLAB ? 0 : n_wr; n_soff = d_soff + 64; }

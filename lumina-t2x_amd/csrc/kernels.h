@@ -46,6 +46,7 @@ struct GemmArgs {
     // [rows][ld] matrix at (r >> 1) * 2 * ld + (k >> 5) * 64 + (r & 1) * 32 + (k & 31): the 64-byte pieces a 32-deep slab takes from rows 2 i and
     // 2 i + 1 are one 128-byte line (launch_pair_layout converts in place; rows even, K % 32 == 0).  pair_c: epilogue 1 writes its output
     // (ldc = N / 2 columns) in that layout.  The products and their order do not depend on it: results are bit-identical.
+    // pair_ab: bit 0 = A, bit 1 = W (3 = both: the dense block; the grouped expert GEMMs: W, and A where it is not gathered through a_row_map)
     int pair_ab = 0, pair_c = 0;
     float* qstat = nullptr;
     int qstat_cols = 0, qstat_slots = 0;
@@ -267,6 +268,7 @@ bool attention_is_one_wave(const AttnArgs& a);  // launch_attention would run th
 bool attention_takes_raw_q(const AttnArgs& a);  // launch_attention would run this call on attn_fwd_kernel_v4<72> (the kernel with the q_raw prologue)
 bool attention_fuses_text(int hd);  // hd-72 ping-pong kernel: text cross-attention rides in the self-attention launch
 int ensure_dynamic_lds(const void* fn, int bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) per (device, kernel), raised whenever a larger size is asked for; records the pair only on success
+bool gemm_runs_w4q_grouped(const GemmArgs& a, int epilogue);  // ... on the persistent kernel's grouped (expert) mode
 bool gemm_runs_w4q_dense(const GemmArgs& a, int epilogue);  // launch_gemm_bf16 would run this (variant 0) call on the persistent dense kernel, the one that reads the pair layout
 const char* lt_gemm_describe(const GemmArgs& a, int epilogue, int variant);  // name of the kernel launch_gemm_bf16 would run
 

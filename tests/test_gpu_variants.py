@@ -313,6 +313,35 @@ def test_moe_600m_width_two_layers_vs_oracle():
     assert rel_l2(got, floor) < max(3e-2, 1.5 * f_all), (rel_l2(got, floor), f_all)
 
 
+def test_moe_pair_layout_is_bit_identical():
+    """round 6, option pair_layout for the MoE families: at 1024^2 (16 384 routed rows per MoE FFN) the experts' grouped GEMMs run on the
+    persistent kernel and read their weights - and the SwiGLU output between them - in the row-pair-interleaved layout; the W1 | W3 launch's
+    gathered A rows stay row-major.  Same products, same order: bit-identical, also after a 256-token call (small-M kernels: row-major
+    weights) in between."""
+    from gpu_util import set_option
+    cfg = synth.NextDiTConfig(dim=1536, n_layers=2, n_heads=32, family="moe")
+    sd = synth.synth_state_dict(cfg, seed=43)
+    z, t, y = synth.synth_inputs(cfg, latent_hw=(128, 128), seed=44)
+    zs, ts, _ = synth.synth_inputs(cfg, latent_hw=(32, 32), seed=45)
+    model = models.moe.DiT_Llama(**cfg.ctor_kwargs())
+    model.load_state_dict(sd, strict=True)
+    model = model.eval().to("cuda", torch.bfloat16)
+    zb, zsb = z.to("cuda", torch.bfloat16), zs.to("cuda", torch.bfloat16)
+    big = lambda: model.forward_with_cfg(zb, t.cuda(), y.cuda(), 4.0).clone()
+    small = lambda: model.forward_with_cfg(zsb, ts.cuda(), y.cuda(), 4.0).clone()
+    outs = {}
+    try:
+        for v in (0, 1):
+            set_option("pair_layout", v)
+            outs[v] = [big(), big(), big(), small(), big(), small()]
+    finally:
+        set_option("pair_layout", 1)
+    for i, (a, b) in enumerate(zip(outs[0], outs[1])):
+        assert torch.isfinite(b.float()).all()
+        assert torch.equal(a, b), (i, rel_l2(b, a))
+    assert torch.equal(outs[1][4], outs[1][0]) and torch.equal(outs[1][5], outs[1][3])
+
+
 def test_moe_many_rows_takes_the_generic_plan_walk():
     """moe_plan holds a thread's entries in registers up to 32 per thread (round 4); beyond 16 384 rows (2 x 8464 tokens here: 33 856
     (token, expert) entries, 34 per thread) it falls back to the round-3 walk over memory - time branch routed inside the kernel
