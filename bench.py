@@ -658,7 +658,10 @@ def main():
             },
             "kernel_time_ms_per_step": dict(breakdown, note=f"untimed pass of {nb} NFE with events around every launch"),
             "attention_tflops_per_s": attn_tf,
-            "kernel_variants": {"attention": args.attn_variant or 4, "gemm": args.gemm_variant or 0},
+            "kernel_variants": {"attention": args.attn_variant or 4, "gemm": args.gemm_variant or 0,
+                                # round 6: the persistent GEMM's A / W operands (and the four weights of every layer) in the row-pair-interleaved layout:
+                                # whole 128-byte lines per LDS-DMA request (include/lumina_dit.h, lt_op_pair_layout); bit-identical results
+                                "gemm_operand_layout": "row-major" if "pair_layout=0" in args.opt else "row-pair-interleaved"},
             "hip_graph_replays": eng.graph_replays(),
             "power": power.report(dt, nfe_flops * args.steps / 1e12),
             "parity_fixture": wl["parity"],
